@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference engine
+(/root/reference/src/LanPaint/lanpaint.py) on CPU fp32.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+The reference is imported, never copied.  torch.randn_like is wrapped so the
+exact xi stream the reference consumed is stored next to its outputs; the
+oracle and the HIP path are then fed that same stream.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)      # ROOT first: both trees have a `tests` package
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+from src.LanPaint.lanpaint import LanPaint as RefLanPaint          # noqa: E402  (reference, imported)
+from src.LanPaint.earlystop import _boundary_weight, _weighted_mse  # noqa: E402
+
+from tests import golden_cases as gc                                # noqa: E402
+from tests.stubs import MODELS                                      # noqa: E402
+
+
+class XiRecorder:
+    def __init__(self):
+        self.draws = []
+        self._orig = torch.randn_like
+
+    def __enter__(self):
+        def rec(t, *a, **k):
+            out = self._orig(t, *a, **k)
+            self.draws.append(out.detach().clone().numpy())
+            return out
+        torch.randn_like = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._orig
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def ref_engine(case, model):
+    h = case["hyper"]
+    return RefLanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"],
+                       IS_FLUX=case.get("flux", False), IS_FLOW=case["flow"], MinStepFrac=h["MinStepFrac"])
+
+
+def audio_tensors(case):
+    a = case["audio"]
+    shape = case["shape"]
+    ai = np.zeros(shape, dtype=np.float32)
+    ai[..., a["split"]:] = 1.0
+    flow_a = np.asarray([a["flow_a"]], dtype=np.float32)
+    abt_a = (1 - flow_a) ** 2 / ((1 - flow_a) ** 2 + flow_a ** 2)
+    ve_a = flow_a / (1 - flow_a)
+    corr = ((1.0 - ai) + a["corr"] * ai).astype(np.float32)
+    return ai, (ve_a.astype(np.float32), abt_a.astype(np.float32), flow_a), corr
+
+
+def run_case(name):
+    case = gc.build_case(name)
+    torch.manual_seed(1000 + len(name))
+    model = MODELS[case["model"]](flow=case["flow"] or case["flux"])
+    eng = ref_engine(case, model)
+    x = _t(case["x"].copy())
+    kw = {}
+    extra = {}
+    if case["audio"] is not None:
+        ai, times_a, corr = audio_tensors(case)
+        kw = dict(current_times_audio=tuple(_t(t) for t in times_a), audio_indicator=_t(ai), audio_correction=_t(corr))
+        extra = dict(audio_indicator=ai, ve_a=times_a[0], abt_a=times_a[1], flow_a=times_a[2], audio_correction=corr)
+    mo = case["model_options"]
+    if mo is not None:
+        mo = {k: dict(v) if isinstance(v, dict) else v for k, v in mo.items()}
+        mo["lanpaint_semantic_trace"] = []
+    with XiRecorder() as rec:
+        out = eng(x, _t(case["y"]), _t(case["noise"]), _t(case["sigma"]), _t(case["mask"]),
+                  tuple(_t(t) for t in case["times"]), mo, 0, n_steps=case["n_steps"], **kw)
+    rec_d = dict(x_in=case["x"], y=case["y"], noise=case["noise"], mask=case["mask"], sigma=case["sigma"],
+                 ve=case["times"][0], abt=case["times"][1], flow_t=case["times"][2],
+                 x_out=x.numpy(), out=out.numpy(), n_draws=np.int64(len(rec.draws)),
+                 model_calls=np.int64(model.calls), **extra)
+    for i, d in enumerate(rec.draws):
+        rec_d[f"xi_{i}"] = d
+    if mo is not None:
+        tr = mo["lanpaint_semantic_trace"]
+        rec_d["trace_dist"] = np.asarray([t["dist"] for t in tr], dtype=np.float64)
+        rec_d["trace_counter"] = np.asarray([t["patience_counter"] for t in tr], dtype=np.int64)
+        rec_d["trace_stopped"] = np.asarray([t["stopped"] for t in tr], dtype=np.bool_)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec_d)
+    return len(rec.draws), model.calls
+
+
+def run_schedule(name):
+    sc = gc.build_schedule(name)
+    torch.manual_seed(77)
+    model = MODELS[sc["model"]](flow=sc["flow"])
+    eng = ref_engine(dict(hyper=sc["hyper"], flow=sc["flow"]), model)
+    x = _t(sc["x"].copy())
+    y, noise, mask = _t(sc["y"]), _t(sc["noise"]), _t(sc["mask"])
+    sig = sc["sigmas"]
+    b = sc["shape"][0]
+    denoised_all = []
+    with XiRecorder() as rec:
+        for i in range(len(sig) - 1):
+            s = torch.full((b,), float(sig[i]), dtype=torch.float32)
+            ve, abt, ft = gc.times_from_sigma(s, sc["flow"])
+            den = eng(x, y, noise, s, mask, (ve, abt, ft), None, 0)
+            denoised_all.append(den.numpy().copy())
+            d = (x - den) / float(sig[i])
+            x = x + d * float(sig[i + 1] - sig[i])
+    rec_d = dict(x_in=sc["x"], y=sc["y"], noise=sc["noise"], mask=sc["mask"], sigmas=sig,
+                 x_final=x.numpy(), denoised=np.stack(denoised_all), n_draws=np.int64(len(rec.draws)))
+    for i, d in enumerate(rec.draws):
+        rec_d[f"xi_{i}"] = d
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec_d)
+    return len(rec.draws)
+
+
+def coefficient_kat():
+    """Known answers straight from the reference's own prepare_step_size + OU closed
+    form (float64 of its fp32 outputs), for the per-region coefficient table."""
+    rows = []
+    for flow, sig, msf in ((False, 2.0, 0.0), (False, 2.0, 1.0), (True, 0.5, 0.0), (False, 0.0292, 0.0),
+                           (False, 14.6146, 0.0), (True, 0.97, 0.0), (True, 0.05, 1.0)):
+        eng = RefLanPaint(None, 5, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, MinStepFrac=msf)
+        eng.img_dim_size = 4
+        s = torch.tensor([sig], dtype=torch.float32)
+        ve, abt, ft = gc.times_from_sigma(s, flow)
+        step = eng.add_none_dims(0.2 * (1 - abt).clamp(min=msf))
+        one = eng.add_none_dims(abt ** 0)
+        _, abt_o, dtx, dty, _, _, a_x, a_y, d_x, d_y = eng.prepare_step_size((ve, abt, ft), step, one, one)
+        rows.append([float(flow), sig, msf, float(abt), float(dtx), float(dty), float(a_x), float(a_y), float(d_x)])
+    np.savez_compressed(os.path.join(HERE, "kat_step_coefficients.npz"),
+                        table=np.asarray(rows, dtype=np.float64),
+                        columns=np.asarray(["flow", "sigma", "min_step_frac", "abt", "dtx", "dty", "A_x", "A_y", "D"]))
+
+
+def boundary_kat():
+    """earlystop.py ring weight + weighted MSE on a few masks."""
+    rng = np.random.default_rng(5)
+    masks, rings, mses = [], [], []
+    for k in range(4):
+        m = (rng.random((2, 3, 9, 11)) > (0.3 + 0.15 * k)).astype(np.float32)
+        a = rng.standard_normal(m.shape, dtype=np.float32)
+        b = rng.standard_normal(m.shape, dtype=np.float32)
+        inp = (1 - _t(m)).float()
+        ring = _boundary_weight(_t(m), inp)
+        masks.append(m)
+        rings.append(ring.numpy())
+        mses.append([_weighted_mse(_t(a), _t(b), inp), _weighted_mse(_t(a), _t(b), ring)])
+    np.savez_compressed(os.path.join(HERE, "kat_boundary.npz"), masks=np.stack(masks), rings=np.stack(rings),
+                        mses=np.asarray(mses, dtype=np.float64), seed=np.int64(5))
+
+
+def main():
+    for name in gc.CASES:
+        nd, mc = run_case(name)
+        print(f"{name:24s} draws={nd:3d} model_calls={mc}")
+    for name in gc.SCHEDULES:
+        print(f"{name:24s} draws={run_schedule(name)}")
+    coefficient_kat()
+    boundary_kat()
+
+
+if __name__ == "__main__":
+    main()

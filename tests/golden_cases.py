@@ -1,0 +1,152 @@
+"""Case table for the golden fixtures (tests/golden/*.npz).
+
+Each case is ONE engine call at one sigma (or a short sigma schedule) with all
+inputs derived from a numpy seed, so the inputs can be rebuilt anywhere; the
+.npz stores the inputs too, plus the reference's recorded xi stream and outputs.
+`make_golden.py` (needs /root/reference) writes the fixtures; tests read them."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle.lanpaint_oracle import times_from_sigma
+
+HYPER_DEFAULT = dict(NSteps=5, Friction=15.0, Lambda=5.0, Beta=1.0, StepSize=0.2, MinStepFrac=0.0)
+
+
+def box_mask(shape, frac=0.5):
+    m = np.zeros(shape, dtype=np.float32)
+    w = shape[-1]
+    m[..., : int(w * frac)] = 1.0
+    return m
+
+
+def _inputs(seed, shape, sigma0):
+    rng = np.random.default_rng(seed)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    sig = np.asarray(sigma0, dtype=np.float32).reshape((-1,) + (1,) * (len(shape) - 1))
+    x = (y + noise * sig).astype(np.float32)
+    return x, y, noise
+
+
+def build_case(name):
+    c = dict(CASES[name])
+    shape = tuple(c["shape"])
+    flow = bool(c.get("flow", False))
+    sigma = np.asarray(c["sigma"], dtype=np.float32)
+    x, y, noise = _inputs(c.get("seed", 0), shape, sigma)
+    if flow:   # rectified-flow x_t = t*noise + (1-t)*y
+        t = sigma.reshape((-1,) + (1,) * (len(shape) - 1))
+        x = (t * noise + (1 - t) * y).astype(np.float32)
+    if c.get("mask") == "soft":
+        mask = np.random.default_rng(1234).random(shape, dtype=np.float32)
+    elif c.get("mask") == "ones":
+        mask = np.ones(shape, dtype=np.float32)
+    elif c.get("mask") == "zeros":
+        mask = np.zeros(shape, dtype=np.float32)
+    elif c.get("mask") == "checker":
+        idx = np.indices(shape).sum(axis=0)
+        mask = (idx % 2).astype(np.float32)
+    elif c.get("mask") == "blob":
+        mask = np.ones(shape, dtype=np.float32)
+        h, w = shape[-2], shape[-1]
+        mask[..., h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 0.0
+    else:
+        mask = box_mask(shape)
+    if c.get("zero_noise"):
+        noise = np.zeros_like(noise)
+    ve, abt, flow_t = times_from_sigma(sigma.astype(np.float32), flow)
+    hyper = dict(HYPER_DEFAULT)
+    hyper.update(c.get("hyper", {}))
+    return dict(name=name, shape=shape, flow=flow, flux=bool(c.get("flux", False)), sigma=sigma,
+                x=x, y=y, noise=noise, mask=mask,
+                times=(ve.astype(np.float32), abt.astype(np.float32), flow_t.astype(np.float32)),
+                hyper=hyper, model=c.get("model", "linear_tuple"), n_steps=c.get("n_steps", None),
+                model_options=c.get("model_options", None), audio=c.get("audio", None))
+
+
+CASES = {
+    # VE (SD1.5 / SDXL notation)
+    "ve_basic":        dict(shape=(1, 4, 8, 8), sigma=[2.0]),
+    "ve_msf1":         dict(shape=(1, 4, 8, 8), sigma=[0.5], hyper=dict(MinStepFrac=1.0), seed=1),
+    "ve_big_sigma":    dict(shape=(1, 4, 8, 8), sigma=[14.6146], seed=2),
+    "ve_small_sigma":  dict(shape=(1, 4, 8, 8), sigma=[0.05], seed=3, hyper=dict(NSteps=3)),
+    "ve_tiny_sigma":   dict(shape=(1, 4, 8, 8), sigma=[0.0292], seed=4),
+    "ve_n0":           dict(shape=(1, 4, 8, 8), sigma=[1.0], n_steps=0, seed=5),
+    "ve_n1":           dict(shape=(1, 4, 8, 8), sigma=[1.0], n_steps=1, seed=6),
+    "ve_n2":           dict(shape=(1, 4, 8, 8), sigma=[1.0], n_steps=2, seed=7),
+    "ve_single_out":   dict(shape=(1, 4, 8, 8), sigma=[1.5], model="denoiser_single", seed=8),
+    "ve_list_one":     dict(shape=(1, 4, 8, 8), sigma=[1.5], model="list_one", seed=9),
+    "ve_offset":       dict(shape=(2, 4, 6, 10), sigma=[3.0, 3.0], model="offset_tuple", seed=10),
+    "ve_batch_rows":   dict(shape=(3, 4, 8, 8), sigma=[2.0, 0.7, 5.0], model="denoiser_single", seed=11),
+    "ve_soft_mask":    dict(shape=(1, 4, 8, 8), sigma=[2.0], mask="soft", seed=12),
+    "ve_all_known":    dict(shape=(1, 4, 8, 8), sigma=[2.0], mask="ones", seed=13),
+    "ve_all_inpaint":  dict(shape=(1, 4, 8, 8), sigma=[2.0], mask="zeros", seed=14),
+    "ve_checker":      dict(shape=(1, 4, 7, 9), sigma=[0.8], mask="checker", seed=15),
+    "ve_odd_numel":    dict(shape=(1, 3, 5, 7), sigma=[1.2], seed=16),
+    "ve_zero_noise":   dict(shape=(1, 4, 8, 8), sigma=[2.0], zero_noise=True, seed=17),
+    "ve_lambda_beta":  dict(shape=(1, 4, 8, 8), sigma=[2.0], hyper=dict(Lambda=8.0, Beta=0.5, StepSize=0.15), seed=18),
+    "ve_sdxl_shape":   dict(shape=(1, 4, 32, 32), sigma=[1.0], seed=19),
+    # flow / flux (Flux, Wan, SD3 notation)
+    "flow_basic":      dict(shape=(1, 16, 4, 4), sigma=[0.7], flow=True, seed=20),
+    "flow_flux_flag":  dict(shape=(1, 16, 4, 4), sigma=[0.5], flux=True, seed=21),
+    "flow_low_t":      dict(shape=(1, 16, 4, 4), sigma=[0.15], flow=True, seed=22),
+    "flow_high_t":     dict(shape=(1, 16, 4, 4), sigma=[0.97], flow=True, seed=23),
+    "flow_batch":      dict(shape=(2, 16, 4, 4), sigma=[0.9, 0.3], flow=True, seed=24),
+    "flow_video5d":    dict(shape=(1, 4, 3, 4, 6), sigma=[0.6], flow=True, seed=25),
+    "flow_msf1":       dict(shape=(1, 16, 4, 4), sigma=[0.1], flow=True, hyper=dict(MinStepFrac=1.0), seed=26),
+    "flow_beta":       dict(shape=(1, 16, 4, 4), sigma=[0.6], flow=True, hyper=dict(Beta=0.5, Lambda=8.0), seed=27),
+    # inner early stop (earlystop.py), default metric
+    "ve_earlystop":    dict(shape=(1, 4, 8, 8), sigma=[1.0], mask="blob", seed=28, hyper=dict(NSteps=10),
+                            model_options={"lanpaint_semantic_stop": {"threshold": 0.3, "patience": 1}}),
+    "ve_earlystop_fast": dict(shape=(1, 4, 8, 8), sigma=[1.0], mask="blob", seed=32, hyper=dict(NSteps=10),
+                            model_options={"lanpaint_semantic_stop": {"threshold": 5.0, "patience": 2}}),
+    "ve_earlystop_run_all": dict(shape=(1, 4, 8, 8), sigma=[1.0], mask="blob", seed=29, hyper=dict(NSteps=6),
+                            model_options={"lanpaint_semantic_stop": {"threshold": 1e-9, "patience": 2}}),
+    # MiniMax-H3 style flat AV pack: per-element times (general path)
+    "av_flat_pack":    dict(shape=(1, 1, 24), sigma=[0.5], flow=True, seed=30, mask="soft",
+                            audio=dict(split=15, flow_a=0.2, corr=0.625)),
+    "av_flat_binary":  dict(shape=(1, 2, 16), sigma=[0.6], flow=True, seed=31,
+                            audio=dict(split=10, flow_a=0.35, corr=0.8)),
+}
+
+# short sigma schedules driven by a host-side Euler sampler (k-diffusion sample_euler form)
+SCHEDULES = {
+    "sched_ve_karras6": dict(shape=(1, 4, 8, 8), flow=False, n_sigmas=6, sigma_max=14.6146, sigma_min=0.0292,
+                             hyper=dict(NSteps=3), seed=40),
+    "sched_flow5":      dict(shape=(1, 16, 4, 4), flow=True, n_sigmas=5, hyper=dict(NSteps=2), seed=41),
+    "sched_ve_batch2":  dict(shape=(2, 4, 8, 8), flow=False, n_sigmas=4, sigma_max=10.0, sigma_min=0.1,
+                             hyper=dict(NSteps=2, MinStepFrac=1.0), seed=42),
+}
+
+
+def karras_sigmas(n, sigma_min=0.0292, sigma_max=14.6146, rho=7.0):
+    ramp = np.linspace(0, 1, n, dtype=np.float64)
+    min_inv, max_inv = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    s = (max_inv + ramp * (min_inv - max_inv)) ** rho
+    return np.concatenate([s, [0.0]]).astype(np.float32)
+
+
+def flow_sigmas(n, shift=3.0):
+    t = np.linspace(1.0, 0.0, n + 1, dtype=np.float64)[:-1]
+    t = shift * t / (1 + (shift - 1) * t)
+    t = np.clip(t, 0.0, 0.999)          # t == 1 makes VE_sigma infinite (nodes.py:245)
+    return np.concatenate([t, [0.0]]).astype(np.float32)
+
+
+def build_schedule(name):
+    c = dict(SCHEDULES[name])
+    shape = tuple(c["shape"])
+    flow = c["flow"]
+    sig = flow_sigmas(c["n_sigmas"]) if flow else karras_sigmas(c["n_sigmas"], c["sigma_min"], c["sigma_max"])
+    rng = np.random.default_rng(c["seed"])
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    if flow:
+        x = (sig[0] * noise + (1 - sig[0]) * y).astype(np.float32)
+    else:
+        x = (y + noise * sig[0]).astype(np.float32)
+    hyper = dict(HYPER_DEFAULT)
+    hyper.update(c.get("hyper", {}))
+    return dict(name=name, shape=shape, flow=flow, sigmas=sig, x=x, y=y, noise=noise, mask=box_mask(shape),
+                hyper=hyper, model="linear_tuple")
