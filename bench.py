@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""bench.py -- Langevin think-iterations/sec of the HIP path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path over the whole sigma schedule of the workload
+(C2: SDXL 1x4x128x128 latent per GPU, 30 Karras sigmas x 5 think iterations = 150
+think iterations + 30 final denoise calls), engine driven directly,
+stub backbone x -> (0.9x, 0.8x), synthetic inputs resident in HBM before the timed
+region.  value = think iterations of ALL ranks / max-over-ranks wall time.
+One process per GPU; ranks are independent replicas (mask / known latent are
+broadcast from rank 0 over RCCL at setup; no collective inside the loop) -> weak scaling.
+
+The same JSON line carries
+  roofline     : the dominant kernel (steady-state fused lp_step) -- algorithmic bytes
+                 per launch / mean launch duration measured with HIP events on the
+                 launch stream in an instrumented replay of the timed region
+  cpu_baseline : the CPU oracle (op-for-op port of the reference engine) on torch-CPU
+                 tensors, timed on this box's host cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (per-GPU latent shape, flow?, n_sigmas, think iterations per sigma)
+    "c1_sd15":  ((1, 4, 64, 64), False, 20, 5),
+    "c2_sdxl":  ((1, 4, 128, 128), False, 30, 5),
+    "c3_sdxl_b4": ((4, 4, 128, 128), False, 30, 5),
+    "c4_flux":  ((1, 16, 64, 64), True, 28, 10),
+    "c5_wan":   ((1, 16, 21, 60, 104), True, 30, 5),
+}
+HYPER = dict(NSteps=5, Friction=15.0, Lambda=5.0, Beta=1.0, StepSize=0.2, MinStepFrac=0.0)
+BYTES_PER_EL_STEADY = 36          # read x_t,x0,x0_BIG,y,m,C ; write x_t,C,x_in (fp32, in-kernel RNG)
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable copy)
+
+
+def karras_sigmas(n, sigma_min=0.0292, sigma_max=14.6146, rho=7.0):
+    ramp = np.linspace(0, 1, n, dtype=np.float64)
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    return ((hi + ramp * (lo - hi)) ** rho).astype(np.float32)
+
+
+def flow_sigmas(n, shift=3.0):
+    t = np.linspace(1.0, 0.0, n + 1, dtype=np.float64)[:-1]
+    t = np.clip(shift * t / (1 + (shift - 1) * t), 0.0, 0.999)
+    return t.astype(np.float32)
+
+
+def times_from_sigma(s, flow):
+    if flow:
+        abt = (1 - s) ** 2 / ((1 - s) ** 2 + s ** 2)
+        return s / (1 - s), abt, s
+    abt = 1 / (1 + s ** 2)
+    return s, abt, (1 - abt) ** 0.5 / ((1 - abt) ** 0.5 + abt ** 0.5)
+
+
+class StubSampling:
+    def __init__(self, flow):
+        self.lanpaint_noise_scaling_kind = "flow" if flow else "ve"
+        self.noise_scale = 1.0
+        self.flow = flow
+
+    def noise_scaling(self, sigma, noise, latent_image, max_denoise=False):
+        if self.flow:
+            return sigma * noise + (1.0 - sigma) * latent_image
+        return latent_image + noise * sigma
+
+
+class StubBackbone:
+    """x -> (0.9 x, 0.8 x): isolates the Langevin path (SURVEY.md 8d backbone stand-in (i))."""
+
+    def __init__(self, flow):
+        self.inner_model = self
+        self.model_sampling = StubSampling(flow)
+
+    def __call__(self, x, t, model_options=None, seed=None):
+        return 0.9 * x, 0.8 * x
+
+
+def make_inputs(shape, flow, sigma0, seed, device, xp):
+    g = np.random.default_rng(seed)
+    y = g.standard_normal(shape, dtype=np.float32)
+    noise = g.standard_normal(shape, dtype=np.float32)
+    x = (sigma0 * noise + (1 - sigma0) * y) if flow else (y + noise * sigma0)
+    mask = np.zeros(shape, dtype=np.float32)
+    mask[..., : shape[-1] // 2] = 1.0          # 50 % box, 1 = known
+    return tuple(xp(a.astype(np.float32)) for a in (x, y, noise, mask))
+
+
+def euler_ratios(sig_list, ndim):
+    """(sigma_{i+1} - sigma_i) / sigma_i, broadcastable over the latent."""
+    return [((sig_list[i + 1] - sig_list[i]) / sig_list[i]).reshape((-1,) + (1,) * (ndim - 1))
+            for i in range(len(sig_list) - 1)]
+
+
+def schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think):
+    """One step of the bench: the whole sigma schedule, Euler update between sigmas
+    (k-diffusion sample_euler form), x mutated in place by the engine each sigma."""
+    x = x0.clone()
+    ns = len(sig_list)
+    for i in range(ns):
+        den = engine(x, y, noise, sig_list[i], mask, times_list[i], None, 0, n_steps=n_think)
+        if i + 1 < ns:
+            x = x + (x - den) * ratios[i]
+    return x
+
+
+def run_gpu(args):
+    import torch.distributed as dist
+    from lanpaint_amd import LanPaint, _cabi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # backend "nccl" IS RCCL on ROCm
+
+    shape, flow, n_sig, n_think = WORKLOADS[args.workload]
+    sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed + rank, dev, tt)
+    if world > 1:      # all replicas inpaint the same image with the same mask: one RCCL broadcast at setup
+        dist.broadcast(mask, src=0)
+        dist.broadcast(y, src=0)
+        x0 = (float(sig_np[0]) * noise + (1 - float(sig_np[0])) * y) if flow else (y + noise * float(sig_np[0]))
+    b = shape[0]
+    sig_list = [torch.full((b,), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+    times_list = [times_from_sigma(s, flow) for s in sig_list]
+    ratios = euler_ratios(sig_list, len(shape))
+
+    engine = LanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
+                      HYPER["StepSize"], IS_FLOW=flow, MinStepFrac=HYPER["MinStepFrac"], rng=args.rng,
+                      philox_seed=args.seed + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+    barrier()
+    it0 = engine.iterations_run
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x_last = schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    iters_local = engine.iterations_run - it0
+    assert torch.isfinite(x_last).all(), "bench produced non-finite latents"
+
+    tmax, iters_total = elapsed, iters_local
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = torch.tensor([iters_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        tmax, iters_total = float(t.item()), int(n.item())
+
+    roofline = None
+    if rank == 0:
+        roofline = measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, args.cpu_seconds)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    n_el = int(np.prod(shape))
+    line = {
+        "metric": "langevin_think_iterations_per_sec",
+        "value": iters_total / tmax,
+        "unit": "think-iterations/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * tmax / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: latent {'x'.join(map(str, shape))} per GPU, {n_sig} sigmas x "
+                               f"{n_think} think iterations, 50% box mask, stub backbone x->(0.9x,0.8x), "
+                               f"{'flow' if flow else 'VE/Karras'} schedule",
+                   "rng": args.rng, "replicas": args.gpus, "iterations_per_step": n_sig * n_think,
+                   "latent_elements_per_gpu": n_el, "lambda": HYPER["Lambda"], "beta": HYPER["Beta"],
+                   "step_size": HYPER["StepSize"]},
+        "latent_rows_x_iterations_per_s": iters_total * b / tmax,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+
+
+def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args):
+    """Instrumented replay of the timed region: a HIP event pair on the launch stream
+    around every steady-state lp_step (POST_STEADY|PRE_HALF|EMIT) launch."""
+    steady = _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT
+    events = []
+    orig = engine._launch_step
+
+    def timed_launch(stream):
+        if engine._desc.phases == steady:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            orig(stream)
+            b.record()
+            events.append((a, b))
+        else:
+            orig(stream)
+
+    engine._launch_step = timed_launch
+    try:
+        for _ in range(max(1, min(args.steps, 3))):
+            schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        torch.cuda.synchronize()
+    finally:
+        engine._launch_step = orig
+    if not events:
+        return None
+    durs = np.asarray([a.elapsed_time(b) for a, b in events]) * 1e-3      # seconds
+    n_el = x0.numel()
+    bytes_per_launch = BYTES_PER_EL_STEADY * n_el
+    mean_s = float(durs.mean())
+    achieved = bytes_per_launch / mean_s / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": "lp_step_kernel<4,false> phases=POST_STEADY|PRE_HALF|EMIT",
+            "algorithmic_bytes_per_launch": bytes_per_launch, "mean_launch_us": mean_s * 1e6,
+            "median_launch_us": float(np.median(durs)) * 1e6, "launches_timed": len(events),
+            "timer": "hipEvent pair per launch on the launch stream"}
+
+
+def cpu_baseline(workload, budget_s):
+    """The CPU oracle (port of the reference engine, same op chain on torch-CPU tensors,
+    all host threads) on the same workload, bounded to ~budget_s seconds."""
+    from oracle.lanpaint_oracle import OracleLanPaint, TorchBackend
+    shape, flow, n_sig, n_think = WORKLOADS[workload]
+    sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))   # noqa: E731
+    x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), 0, "cpu", tt)
+    b = shape[0]
+    sig_list = [torch.full((b,), float(s), dtype=torch.float32) for s in sig_np]
+    times_list = [times_from_sigma(s, flow) for s in sig_list]
+    ratios = euler_ratios(sig_list, len(shape))
+    eng = OracleLanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
+                         HYPER["StepSize"], is_flow=flow, min_step_frac=HYPER["MinStepFrac"], backend=TorchBackend())
+    threads = torch.get_num_threads()
+    schedule_pass(eng, x0, y, noise, mask, sig_list[:3], times_list[:3], ratios[:2], n_think)      # warm-up, discarded
+    it0, t0, passes = eng.iterations_run, time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        passes += 1
+    dt = time.perf_counter() - t0
+    return {"value": (eng.iterations_run - it0) / dt, "unit": "think-iterations/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{passes} full passes of the {workload} schedule ({n_sig} sigmas x {n_think}) in {dt:.1f} s; "
+                      f"oracle/lanpaint_oracle.py on torch-CPU fp32 tensors ({threads} threads of "
+                      f"{os.cpu_count()} host CPUs)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2_sdxl", choices=sorted(WORKLOADS))
+    ap.add_argument("--rng", default="philox", choices=["philox", "torch"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    run_gpu(args)
+
+
+if __name__ == "__main__":
+    main()

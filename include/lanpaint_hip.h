@@ -1,0 +1,218 @@
+/* lanpaint_hip.h -- C ABI of liblanpaint_hip.so (MI355X / gfx950).
+ *
+ * The reference (scraed/LanPaint v2.1.0) has NO native code and NO FFI: its hot
+ * path is ~330 lines of eager PyTorch (src/LanPaint/lanpaint.py).  Every entry
+ * point below therefore REPLACES a span of eager ATen ops in the reference; the
+ * span is cited as file:line (relative to the reference root) on each function.
+ * The binding a reference maintainer would add is a ctypes stub -- see
+ * INTEGRATION.md and lanpaint_amd/_cabi.py (the one this repo ships).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / ATen types.
+ *   - every function returns int: 0 = ok, <0 = LP_E_* (lp_strerror() names it).
+ *     No exception crosses the boundary.
+ *   - all tensor pointers are DEVICE pointers owned by the caller (torch
+ *     allocations); the library allocates nothing, keeps no global state, is
+ *     re-entrant, enqueues on the caller's HIP stream and never synchronises --
+ *     so it is safe under hipGraph capture.
+ *   - tensors are dense row-major fp32 in the latent's own layout
+ *     [B, C, (F), H, W] flattened: n_el = B * el_per_row.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ */
+#ifndef LANPAINT_HIP_H
+#define LANPAINT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LP_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+#define LP_OK             0
+#define LP_E_INVALID     -1   /* null / inconsistent argument                  */
+#define LP_E_UNSUPPORTED -2   /* layout or flag combination not implemented   */
+#define LP_E_LAUNCH      -3   /* hipLaunchKernel failed (hipGetLastError)      */
+#define LP_E_ALIGN       -4   /* pointer not aligned for the requested layout */
+
+/* ---- per-row coefficient table ------------------------------------------ */
+/* One row of LP_COEF_STRIDE floats per batch row, produced on the device by
+ * lp_coeffs() so the think loop needs no host<->device sync (the reference
+ * recomputes these ~40 tiny ops + 1 host sync EVERY iteration:
+ * lanpaint.py:205,295-328).  Region r: 0 = inpaint ("x" branch, mask==0),
+ * 1 = known ("y" branch, mask==1).                                          */
+#define LP_COEF_STRIDE   32
+#define LP_C_SCALE        0   /* flow: sqrt(abt)+sqrt(1-abt); VE: sqrt(1+sigma^2)  (lanpaint.py:96-99) */
+#define LP_C_SQRT_ABT     1
+#define LP_C_OMA          2   /* 1 - abt                                         */
+#define LP_C_ABT          3
+#define LP_C_RSIGMA       4   /* sigma used by the replace step (lanpaint.py:94) */
+#define LP_C_DTX          5   /* dt of the inpaint branch  = step                */
+#define LP_C_DTY          6   /* dt of the known branch    = beta*step           */
+#define LP_C_AX           7   /* 1/(1-abt)          (lanpaint.py:315,319)        */
+#define LP_C_AY           8   /* (1+lambda)/(1-abt) (lanpaint.py:316,320)        */
+#define LP_C_DX           9   /* sqrt(2)            (lanpaint.py:326)            */
+#define LP_C_DY          10
+#define LP_C_VALID       11   /* 1.0 if step > 0 else 0.0 (lanpaint.py:205)      */
+#define LP_C_REGION0     12   /* 10 floats per region, see LP_R_*                */
+#define LP_C_REGION1     22
+#define LP_R_E_FULL       0   /* exp(-A dt)                  (lanpaint.py:242)   */
+#define LP_R_K_FULL       1   /* (1-exp(-A dt))/A            (lanpaint.py:247)   */
+#define LP_R_STD_FULL     2   /* sqrt(D^2 (1-exp(-2A dt))/(2A)) (lanpaint.py:249-252) */
+#define LP_R_E_HALF       3   /* same three at dt/2                              */
+#define LP_R_K_HALF       4
+#define LP_R_STD_HALF     5
+#define LP_R_DT           6
+#define LP_R_A            7
+#define LP_R_CX0          8   /* sqrt(abt)/(1-abt): C = CX0*x0s + CXT*x_t (lanpaint.py:219) */
+#define LP_R_CXT          9   /* A - 1/(1-abt)                                   */
+
+typedef struct lp_hyper {
+    float    lambda;          /* LanPaint_Lambda   (lanpaint.py:11)             */
+    float    beta;            /* LanPaint_Beta     (lanpaint.py:17,188-190)     */
+    float    step_size;       /* LanPaint_StepSize (lanpaint.py:14,81)          */
+    float    min_step_frac;   /* MinStepFrac       (lanpaint.py:18,81)          */
+    int32_t  is_flow;         /* IS_FLUX or IS_FLOW (lanpaint.py:96,144,161)    */
+    float    one_plus_lambda; /* fp32(1 + Lambda) with the sum taken in double,
+                                 as Python evaluates `(1 + lamb)` (lanpaint.py:183,316) */
+} lp_hyper;
+
+/* ---- phases of the fused step kernel -------------------------------------- */
+/* The model call is the only unavoidable cut in the loop, so one launch does
+ * [everything after model call i] + [everything before model call i+1].      */
+#define LP_PH_REPLACE      (1u << 0) /* x = x(1-m)+known*m; x_t = VP(x)   lanpaint.py:94-99           */
+#define LP_PH_POST_FIRST   (1u << 1) /* C = coefC; x_t = OU(x_t,dt,C)     lanpaint.py:275-277         */
+#define LP_PH_POST_STEADY  (1u << 2) /* C'=coefC; x_t+=(C'-C)dt; x_t=OU(x_t,dt/2,C_old); C=C'  :281-284 */
+#define LP_PH_PRE_HALF     (1u << 3) /* x_t = OU(x_t,dt/2,C) -- first half of the NEXT iteration  :280  */
+#define LP_PH_EMIT         (1u << 4) /* x_in = model-space(x_t)           lanpaint.py:144-147,163,168 */
+
+/* ---- flags ---------------------------------------------------------------- */
+#define LP_FL_FLOW          (1u << 0)  /* flow/flux VP scaling, else VE                        */
+#define LP_FL_MASK_DENOISE  (1u << 1)  /* mask buffer is ComfyUI's denoise_mask: kernel applies
+                                          m = 1 - (dm > 0.5)              (nodes.py:281-283)  */
+#define LP_FL_MASK_U8       (1u << 2)  /* mask buffer is uint8 0/1 (1 = known)                 */
+#define LP_FL_WRITE_X0S     (1u << 3)  /* also store x0s (LangevinState.x0; early stop)        */
+#define LP_FL_X0_BF16       (1u << 4)  /* x0 / x0_big are bf16                                 */
+#define LP_FL_X0_F16        (1u << 5)  /* x0 / x0_big are fp16                                 */
+#define LP_FL_XIN_BF16      (1u << 6)  /* x_in is written as bf16                              */
+#define LP_FL_XIN_F16       (1u << 7)  /* x_in is written as fp16                              */
+#define LP_FL_PER_ELEMENT   (1u << 8)  /* abt_el/ve_el/... per-element times (AV packs,
+                                          lanpaint.py:60-74): general path                     */
+#define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
+                                          langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
+
+/* replace-step source (lanpaint.py:84-94) */
+#define LP_REPLACE_KNOWN    0   /* `known` = model_sampling.noise_scaling(...) computed by the caller */
+#define LP_REPLACE_VE       1   /* y + n*sigma                                                        */
+#define LP_REPLACE_FLOW     2   /* sigma*(noise_scale*n) + (1-sigma)*y                                */
+
+typedef struct lp_step_desc {
+    int64_t   n_el;            /* total latent elements                                   */
+    int64_t   el_per_row;      /* elements per batch row (C*(F)*H*W)                      */
+    int32_t   rows;            /* B                                                       */
+    uint32_t  phases;          /* LP_PH_*                                                 */
+    uint32_t  flags;           /* LP_FL_*                                                 */
+    int32_t   replace_kind;    /* LP_REPLACE_*                                            */
+    float     lambda;          /* duplicated from lp_hyper for the per-element path       */
+    float     one_plus_lambda;
+    float     beta;
+    float     step_size;
+    float     min_step_frac;
+    float     noise_scale;     /* model_sampling.noise_scale (lanpaint.py:91)             */
+    const float* coef;         /* [rows][LP_COEF_STRIDE] from lp_coeffs()                 */
+    const float* x;            /* REPLACE: sampler latent (model space)                   */
+    const float* known;        /* REPLACE, LP_REPLACE_KNOWN                               */
+    const float* noise;        /* REPLACE, VE/FLOW kinds                                  */
+    const float* y;            /* latent_image (clean known latent)                       */
+    const void*  mask;         /* fp32 (default) or u8, full latent shape                 */
+    float*       x_t;          /* VP-space state, read+written                            */
+    float*       C;            /* LangevinState.C, read+written                           */
+    float*       x0s;          /* LangevinState.x0 out (LP_FL_WRITE_X0S) or NULL          */
+    const void*  x0;           /* model output head 0                                     */
+    const void*  x0_big;       /* model output head 1 (may alias x0)                      */
+    void*        x_in;         /* EMIT: model-space latent for the next model call        */
+    const float* xi_post;      /* host-supplied N(0,1) for POST_* (NULL => Philox)        */
+    const float* xi_pre;       /* host-supplied N(0,1) for PRE_HALF (NULL => Philox)      */
+    uint64_t     rng_seed;     /* Philox key                                              */
+    uint64_t     rng_offset;   /* Philox launch sequence number (unique per launch)       */
+    const uint64_t* rng_offset_ptr; /* optional device u64 added to rng_offset (graph replay) */
+    const float* abt_el;       /* LP_FL_PER_ELEMENT: per-element abt                      */
+    const float* ve_el;        /*                    per-element VE sigma                 */
+    const float* rsig_el;      /*                    per-element replace sigma            */
+    const float* corr_el;      /* audio_correction (lanpaint.py:173-180) or NULL          */
+} lp_step_desc;
+
+typedef struct lp_final_desc {
+    int64_t   n_el;
+    uint32_t  flags;           /* LP_FL_MASK_*, LP_FL_X0_BF16/F16 (dtype of model_out)    */
+    int32_t   reserved0;
+    const void*  model_out;    /* final denoise, head 0 (lanpaint.py:151-153)             */
+    const float* y;
+    const void*  mask;
+    const float* x_src;        /* final model-space x (the last EMIT)                     */
+    float*       x_dst;        /* sampler latent, overwritten IN PLACE (lanpaint.py:156); NULL = skip */
+    float*       out;          /* out*(1-m) + y*m (lanpaint.py:154)                       */
+    uint64_t*    rng_bump_ptr; /* optional: *ptr += rng_bump after the launch (graph replay) */
+    uint64_t     rng_bump;
+} lp_final_desc;
+
+/* ---- entry points --------------------------------------------------------- */
+int lp_abi_version(void);
+const char* lp_strerror(int code);
+
+/* K1  per-row coefficient table on the device.
+ * Replaces: KSamplerX0Inpaint scalars feeding LanPaint.LanPaint (lanpaint.py:81-82),
+ *           prepare_step_size (lanpaint.py:295-328) and the closed-form OU
+ *           factors of advance_time_overdamped (lanpaint.py:241-252).
+ * ve_sigma / abt / replace_sigma: device fp32, `rows` entries each, or 1 entry
+ * broadcast when the matching *_stride is 0.  step_override (nullable): explicit
+ * per-row step size (the `step_size` argument of the public langevin_dynamics,
+ * lanpaint.py:192) instead of StepSize*max(1-abt, MinStepFrac).               */
+int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const float* abt, int abt_stride,
+              const float* replace_sigma, int rs_stride, const float* step_override, int step_stride,
+              int rows, float* coef_table, void* stream);
+
+/* K0 / K_first / K2  the fused step (phases select the work).
+ * Replaces: lanpaint.py:94-99 (REPLACE), :159-184 + :212-220 (score split + Coef_C),
+ *           :232-254 (exact OU + noise injection), :274-286 (the scheme),
+ *           :144-147 / :163 / :168 (EMIT).                                     */
+int lp_step(const lp_step_desc* desc, void* stream);
+
+/* K3  finalise: known-region reprojection + in-place write-back.
+ * Replaces: lanpaint.py:154,156.                                               */
+int lp_finalize(const lp_final_desc* desc, void* stream);
+
+/* Standalone N(0,1) fill with the same Philox4x32-10 + Box-Muller the fused
+ * kernel uses (slot 0 = POST stream, 1 = PRE stream) -- lets tests reproduce
+ * the in-kernel noise exactly.  Replaces torch.randn_like (lanpaint.py:252).  */
+int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream);
+
+/* K4  inner early-stop metric (earlystop.py:32-55).
+ * lp_boundary_ring: ring[i] = (mask<=0.5) & any 4-neighbour(H,W) known, as fp32
+ *                   (planes = B*C images of H x W).
+ * lp_wmse_pair:     acc[0..3] = { sum(w1 d^2), sum(w1), sum(w2 d^2), sum(w2) }
+ *                   with d = a - b, w1 = 1 - mask (inpaint weight), w2 = ring
+ *                   (NULL => acc[2..3] = 0).  acc is a device double[4]; the
+ *                   reduction order is fixed, so results are deterministic.
+ *                   block_scratch: device double[4 * scratch_blocks].          */
+int lp_boundary_ring(const float* mask, float* ring, int64_t planes, int32_t height, int32_t width, void* stream);
+int lp_wmse_pair(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el,
+                 double* acc, double* block_scratch, int32_t scratch_blocks, void* stream);
+
+/* K5  mask preparation (nodes.py:59-133), exact integer index math.
+ * dst[b][c][f][h][w] = max over the temporal window (video: 5 taps, -inf pad;
+ * else 1 tap) of src[f_src(f+k)][h_src(h)][w_src(w)], with
+ * idx_src(i) = min(((2i+1)*in)/(2*out), in-1)  (== F.interpolate nearest-exact),
+ * with dst batch b reading src batch b % src_b and dst channel c reading src
+ * channel c % src_c (the reference's repeat + slice).  `binarize`: 0 = copy value,
+ * 1 = also apply 1 - (v > 0.5) (nodes.py:281-283).                              */
+int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
+                    float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
+                    int32_t temporal_taps, int32_t binarize, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANPAINT_HIP_H */

@@ -1,0 +1,13 @@
+"""lanpaint_amd -- LanPaint's Langevin "think" loop as hand-written HIP kernels for
+MI355X (gfx950), behind the reference's own Python API.
+
+    from lanpaint_amd import LanPaint            # engine, same signature as the reference
+    from lanpaint_amd.nodes import KSamplerX0Inpaint, reshape_mask, NODE_CLASS_MAPPINGS
+
+Importing the engine loads liblanpaint_hip.so and fails loudly when it is missing.
+"""
+from .types import LangevinState  # noqa: F401
+from .lanpaint import LanPaint  # noqa: F401
+
+__all__ = ["LanPaint", "LangevinState"]
+__version__ = "0.1.0"

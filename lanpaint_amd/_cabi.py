@@ -1,0 +1,110 @@
+"""ctypes binding of liblanpaint_hip.so (include/lanpaint_hip.h).
+
+This is the whole host<->native boundary: plain pointers (`tensor.data_ptr()`),
+sizes and two POD descriptors.  No pybind, no ATen linkage.  The library MUST be
+present: there is no CPU or PyTorch fallback for the hot path -- a missing or
+stale .so raises at import of the engine.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "liblanpaint_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+ABI_VERSION = 1
+
+# --- constants mirrored from include/lanpaint_hip.h -------------------------------
+LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
+LP_COEF_STRIDE = 32
+(LP_C_SCALE, LP_C_SQRT_ABT, LP_C_OMA, LP_C_ABT, LP_C_RSIGMA, LP_C_DTX, LP_C_DTY, LP_C_AX, LP_C_AY, LP_C_DX, LP_C_DY,
+ LP_C_VALID) = range(12)
+LP_C_REGION0, LP_C_REGION1 = 12, 22
+(LP_R_E_FULL, LP_R_K_FULL, LP_R_STD_FULL, LP_R_E_HALF, LP_R_K_HALF, LP_R_STD_HALF, LP_R_DT, LP_R_A, LP_R_CX0,
+ LP_R_CXT) = range(10)
+
+LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT = 1, 2, 4, 8, 16
+LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
+LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
+LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN = 256, 512
+LP_REPLACE_KNOWN, LP_REPLACE_VE, LP_REPLACE_FLOW = 0, 1, 2
+
+
+class LpHyper(C.Structure):
+    _fields_ = [("lambda_", C.c_float), ("beta", C.c_float), ("step_size", C.c_float), ("min_step_frac", C.c_float),
+                ("is_flow", C.c_int32), ("one_plus_lambda", C.c_float)]
+
+
+class LpStepDesc(C.Structure):
+    _fields_ = [
+        ("n_el", C.c_int64), ("el_per_row", C.c_int64), ("rows", C.c_int32), ("phases", C.c_uint32),
+        ("flags", C.c_uint32), ("replace_kind", C.c_int32),
+        ("lambda_", C.c_float), ("one_plus_lambda", C.c_float), ("beta", C.c_float), ("step_size", C.c_float),
+        ("min_step_frac", C.c_float), ("noise_scale", C.c_float),
+        ("coef", C.c_void_p), ("x", C.c_void_p), ("known", C.c_void_p), ("noise", C.c_void_p), ("y", C.c_void_p),
+        ("mask", C.c_void_p), ("x_t", C.c_void_p), ("C", C.c_void_p), ("x0s", C.c_void_p), ("x0", C.c_void_p),
+        ("x0_big", C.c_void_p), ("x_in", C.c_void_p), ("xi_post", C.c_void_p), ("xi_pre", C.c_void_p),
+        ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64), ("rng_offset_ptr", C.c_void_p),
+        ("abt_el", C.c_void_p), ("ve_el", C.c_void_p), ("rsig_el", C.c_void_p), ("corr_el", C.c_void_p),
+    ]
+
+
+class LpFinalDesc(C.Structure):
+    _fields_ = [
+        ("n_el", C.c_int64), ("flags", C.c_uint32), ("reserved0", C.c_int32),
+        ("model_out", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p), ("x_src", C.c_void_p),
+        ("x_dst", C.c_void_p), ("out", C.c_void_p), ("rng_bump_ptr", C.c_void_p), ("rng_bump", C.c_uint64),
+    ]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "lp_abi_version": (C.c_int, []),
+    "lp_strerror": (C.c_char_p, [C.c_int]),
+    "lp_coeffs": (C.c_int, [C.POINTER(LpHyper), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                            C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "lp_step": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p]),
+    "lp_finalize": (C.c_int, [C.POINTER(LpFinalDesc), C.c_void_p]),
+    "lp_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "lp_boundary_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "lp_wmse_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                               C.c_int32, C.c_void_p]),
+    "lp_reshape_mask": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]),
+}
+
+
+class LanPaintHipError(RuntimeError):
+    """A C-ABI call returned a negative status (the reference raises Python
+    exceptions only; C codes are mapped to RuntimeError here)."""
+
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen the HIP library once; raise loudly when it is missing or stale."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("LANPAINT_AMD_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python -m lanpaint_amd.build`). lanpaint_amd has no CPU / PyTorch fallback for the Langevin path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype, fn.argtypes = res, args
+    v = lib.lp_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"{p}: ABI version {v}, expected {ABI_VERSION}; rebuild the extension")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "lanpaint_hip"):
+    if code != LP_OK:
+        msg = load().lp_strerror(code)
+        raise LanPaintHipError(f"{what}: {msg.decode() if msg else code} (code {code})")

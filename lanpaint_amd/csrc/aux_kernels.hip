@@ -1,0 +1,327 @@
+// aux_kernels.hip -- the small kernels around the fused step (gfx950, wave64):
+//   K1 lp_coeffs        per-row coefficient table on the device (no host sync)
+//   K3 lp_finalize      known-region reprojection + in-place write-back
+//      lp_philox_normal standalone N(0,1) fill (same generator as the fused step)
+//   K4 lp_boundary_ring / lp_wmse_pair   inner early-stop metric: mask-edge stencil
+//                        via wave ballots + an LDS tile of row bitmasks, and a
+//                        deterministic weighted-MSE reduction
+//   K5 lp_reshape_mask  exact-integer nearest-exact resample + temporal union
+#include "lp_common.h"
+
+namespace lp {
+
+// ---------------------------------------------------------------------------------
+// K1: one thread per batch row.  fp32 fields mirror the reference's own op order
+// (prepare_step_size, lanpaint.py:295-328); the per-region closed-form factors are
+// evaluated in double from those fp32 inputs (lanpaint.py:241-252 in exact arithmetic).
+// ---------------------------------------------------------------------------------
+__global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int ve_stride,
+                                 const float* __restrict__ abt, int abt_stride, const float* __restrict__ rs,
+                                 int rs_stride, const float* __restrict__ step_ov, int step_stride, int rows,
+                                 float* __restrict__ table) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float abt_f = abt[static_cast<int64_t>(r) * abt_stride];
+    const float ve_f = ve ? ve[static_cast<int64_t>(r) * ve_stride] : 0.0f;
+    const float rs_f = rs ? rs[static_cast<int64_t>(r) * rs_stride] : 0.0f;
+    float* c = table + static_cast<int64_t>(r) * LP_COEF_STRIDE;
+
+    const float oma = 1.0f - abt_f;
+    const float step = step_ov ? step_ov[static_cast<int64_t>(r) * step_stride]
+                               : h.step_size * fmaxf(oma, h.min_step_frac);  // lanpaint.py:81
+    const float dtx2 = 2.0f * step * 1.0f, dty2 = 2.0f * step * h.beta;        // :300-301
+    const float atx = (1.0f / oma) * dtx2 / 2.0f;                              // :315
+    const float aty = (h.one_plus_lambda / oma) * dty2 / 2.0f;                 // :316
+    const float dtx = dtx2 / 2.0f, dty = dty2 / 2.0f;                          // :328
+    const bool valid = step > 0.0f;                                            // :205 (per row)
+    c[LP_C_SCALE] = h.is_flow ? (sqrtf(abt_f) + sqrtf(1.0f - abt_f)) : sqrtf(1.0f + ve_f * ve_f);   // :96-99
+    c[LP_C_SQRT_ABT] = sqrtf(abt_f);
+    c[LP_C_OMA] = oma;
+    c[LP_C_ABT] = abt_f;
+    c[LP_C_RSIGMA] = rs_f;
+    c[LP_C_DTX] = dtx;
+    c[LP_C_DTY] = dty;
+    c[LP_C_AX] = atx / dtx;                                                    // :319
+    c[LP_C_AY] = aty / dty;                                                    // :320
+    c[LP_C_DX] = sqrtf(2.0f);                                                  // :326-327
+    c[LP_C_DY] = sqrtf(2.0f);
+    c[LP_C_VALID] = valid ? 1.0f : 0.0f;
+
+    const double oma_d = static_cast<double>(oma);
+    const double cx0 = sqrt(static_cast<double>(abt_f)) / oma_d;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);
+        const double a = (g ? static_cast<double>(h.one_plus_lambda) : 1.0) / oma_d;
+        const double dt = static_cast<double>(g ? dty : dtx);
+        double e[2], k[2], sd[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const double tau = s ? dt * 0.5 : dt;
+            e[s] = exp(-a * tau);
+            k[s] = -expm1(-a * tau) / a;
+            const double k2 = -expm1(-2.0 * a * tau) / (2.0 * a);
+            sd[s] = sqrt(fmax(2.0 * k2, 0.0));
+        }
+        q[LP_R_E_FULL] = static_cast<float>(e[0]);
+        q[LP_R_K_FULL] = static_cast<float>(k[0]);
+        q[LP_R_STD_FULL] = static_cast<float>(sd[0]);
+        q[LP_R_E_HALF] = static_cast<float>(e[1]);
+        q[LP_R_K_HALF] = static_cast<float>(k[1]);
+        q[LP_R_STD_HALF] = static_cast<float>(sd[1]);
+        q[LP_R_DT] = static_cast<float>(dt);
+        q[LP_R_A] = static_cast<float>(a);
+        q[LP_R_CX0] = static_cast<float>(cx0);
+        q[LP_R_CXT] = g ? static_cast<float>(a - 1.0 / oma_d) : 0.0f;
+    }
+}
+
+int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const float* abt, int abt_stride,
+                    const float* rs, int rs_stride, const float* step_ov, int step_stride, int rows, float* table,
+                    hipStream_t stream) {
+    if (!h || !abt || !table || rows <= 0) return LP_E_INVALID;
+    if (!h->is_flow && !ve) return LP_E_INVALID;
+    const int block = 64;
+    hipLaunchKernelGGL(lp_coeffs_kernel, dim3((rows + block - 1) / block), dim3(block), 0, stream, *h, ve, ve_stride,
+                       abt, abt_stride, rs, rs_stride, step_ov, step_stride, rows, table);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------
+// K3: out = model_out*(1-m) + y*m ; x_dst <- x_src      (lanpaint.py:154,156)
+// ---------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d) {
+    const int64_t groups = d.n_el / VEC;
+    const int dt = x0_dtype(d.flags);
+    for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < groups;
+         g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t i = g * VEC;
+        float m[VEC], mo[VEC], yv[VEC], o[VEC];
+        load_mask<VEC>(d.mask, d.flags, i, m);
+        load_any<VEC>(d.model_out, dt, i, mo);
+        load_f32<VEC>(d.y, i, yv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o[k] = mo[k] * (1.0f - m[k]) + yv[k] * m[k];
+        store_f32<VEC>(d.out, i, o);
+        if (d.x_dst) {
+            float xs[VEC];
+            load_f32<VEC>(d.x_src, i, xs);
+            store_f32<VEC>(d.x_dst, i, xs);
+        }
+    }
+    if (d.rng_bump_ptr && blockIdx.x == 0 && threadIdx.x == 0) *d.rng_bump_ptr += d.rng_bump;
+}
+
+static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
+    if (!dp) return LP_E_INVALID;
+    const lp_final_desc& d = *dp;
+    if (d.n_el <= 0 || !d.model_out || !d.y || !d.mask || !d.out) return LP_E_INVALID;
+    if (d.x_dst && !d.x_src) return LP_E_INVALID;
+    const bool half = x0_dtype(d.flags) != DT_F32;
+    const bool vec4 = (d.n_el % 4 == 0) && aligned(d.model_out, half ? 8 : 16) && aligned(d.y, 16) &&
+                      aligned(d.mask, (d.flags & LP_FL_MASK_U8) ? 4 : 16) && aligned(d.x_src, 16) &&
+                      aligned(d.x_dst, 16) && aligned(d.out, 16);
+    const int vec = vec4 ? 4 : 1;
+    const int64_t groups = d.n_el / vec;
+    const int block = groups <= 64 * 1024 ? 64 : 256;
+    int64_t bx = (groups + block - 1) / block;
+    if (bx > 2048) bx = 2048;
+    if (vec4)
+        hipLaunchKernelGGL(lp_finalize_kernel<4>, dim3(static_cast<unsigned>(bx)), dim3(block), 0, stream, d);
+    else
+        hipLaunchKernelGGL(lp_finalize_kernel<1>, dim3(static_cast<unsigned>(bx)), dim3(block), 0, stream, d);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------
+// standalone Philox fill: element e <- normal4(e >> 2)[e & 3]
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lp_philox_kernel(float* __restrict__ out, int64_t n_el, uint64_t seed,
+                                                        uint64_t offset, uint32_t slot) {
+    const int64_t quads = (n_el + 3) / 4;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < quads;
+         q += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float z[4];
+        normal4(static_cast<uint64_t>(q), offset, slot, seed, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (q * 4 + k < n_el) out[q * 4 + k] = z[k];
+    }
+}
+
+int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream) {
+    if (!out || n_el <= 0) return LP_E_INVALID;
+    int64_t bx = ((n_el + 3) / 4 + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(lp_philox_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, out, n_el, seed,
+                       offset, slot);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------
+// K4a: mask-edge ring (earlystop.py:32-49).  A block owns a 32-row x 62-column tile
+// of one H x W plane.  Each wave turns a 64-pixel row segment (tile + 1-pixel halo)
+// into ONE 64-bit word with __ballot(known); the 34 row words of the tile (+halo)
+// are staged in LDS; the 4-neighbour stencil then runs on whole words:
+//   ring = ~k & ((k << 1) | (k >> 1) | up | down)
+// ring value = (1 - mask) on ring pixels (boundary.float() * inpaint_weight), else 0.
+// ---------------------------------------------------------------------------------
+constexpr int kRingRows = 32, kRingCols = 62;
+
+__global__ __launch_bounds__(256) void lp_ring_kernel(const float* __restrict__ mask, float* __restrict__ ring,
+                                                      int height, int width) {
+    __shared__ unsigned long long rowbits[kRingRows + 2];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int x0 = blockIdx.x * kRingCols - 1, y0 = blockIdx.y * kRingRows - 1;
+    const int64_t plane = static_cast<int64_t>(blockIdx.z) * height * width;
+    const int x = x0 + lane;
+    const bool x_in = x >= 0 && x < width;
+
+    for (int j = wave; j < kRingRows + 2; j += 4) {
+        const int y = y0 + j;
+        bool known = false;
+        if (x_in && y >= 0 && y < height) known = mask[plane + static_cast<int64_t>(y) * width + x] > 0.5f;
+        const unsigned long long bits = __ballot(known);
+        if (lane == 0) rowbits[j] = bits;
+    }
+    __syncthreads();
+    for (int j = 1 + wave; j <= kRingRows; j += 4) {
+        const int y = y0 + j;
+        if (y >= height) break;
+        const unsigned long long k = rowbits[j];
+        const unsigned long long nb = (k << 1) | (k >> 1) | rowbits[j - 1] | rowbits[j + 1];
+        const unsigned long long rb = ~k & nb;
+        if (lane >= 1 && lane <= kRingCols && x_in) {
+            const int64_t idx = plane + static_cast<int64_t>(y) * width + x;
+            ring[idx] = ((rb >> lane) & 1ull) ? (1.0f - mask[idx]) : 0.0f;
+        }
+    }
+}
+
+int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream) {
+    if (!mask || !ring || planes <= 0 || height <= 0 || width <= 0) return LP_E_INVALID;
+    if (planes > 65535) return LP_E_UNSUPPORTED;
+    dim3 grid((width + kRingCols - 1) / kRingCols, (height + kRingRows - 1) / kRingRows, static_cast<unsigned>(planes));
+    if (grid.y > 65535) return LP_E_UNSUPPORTED;
+    hipLaunchKernelGGL(lp_ring_kernel, grid, dim3(256), 0, stream, mask, ring, height, width);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------
+// K4b: { sum(w1 d^2), sum(w1), sum(w2 d^2), sum(w2) }, d = a-b, w1 = 1-mask, w2 = ring.
+// fp32 per-thread partials, double from the wave reduction upward, fixed order.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void lp_wmse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ mask,
+                                                              const float* __restrict__ ring, int64_t n_el,
+                                                              double* __restrict__ scratch) {
+    __shared__ double part[4][4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_el;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const float dv = a[i] - b[i];
+        const float d2 = dv * dv;
+        const float w1 = 1.0f - mask[i];
+        s[0] += d2 * w1;
+        s[1] += w1;
+        if (ring) {
+            const float w2 = ring[i];
+            s[2] += d2 * w2;
+            s[3] += w2;
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double v = wave_sum(static_cast<double>(s[k]));
+        if (lane == 0) part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        scratch[static_cast<int64_t>(blockIdx.x) * 4 + k] = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+    }
+}
+
+__global__ void lp_wmse_final_kernel(const double* __restrict__ scratch, int blocks, double* __restrict__ acc) {
+    const int k = threadIdx.x;
+    if (k >= 4) return;
+    double v = 0.0;
+    for (int bidx = 0; bidx < blocks; ++bidx) v += scratch[static_cast<int64_t>(bidx) * 4 + k];
+    acc[k] = v;
+}
+
+int wmse_dispatch(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
+                  double* scratch, int scratch_blocks, hipStream_t stream) {
+    if (!a || !b || !mask || !acc || !scratch || n_el <= 0 || scratch_blocks <= 0) return LP_E_INVALID;
+    int64_t bx = (n_el + 255) / 256;
+    if (bx > scratch_blocks) bx = scratch_blocks;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(lp_wmse_partial_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, a, b, mask, ring,
+                       n_el, scratch);
+    if (hipGetLastError() != hipSuccess) return LP_E_LAUNCH;
+    hipLaunchKernelGGL(lp_wmse_final_kernel, dim3(1), dim3(64), 0, stream, scratch, static_cast<int>(bx), acc);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------
+// K5: reshape_mask (nodes.py:59-133) as an output-indexed gather.  All index math is
+// 64-bit integer: src(i) = min(((2i+1)*in) / (2*out), in-1) == nearest-exact.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_exact(int i, int in_size, int out_size) {
+    const long long s = ((2ll * i + 1) * in_size) / (2ll * out_size);
+    return static_cast<int>(s < in_size - 1 ? s : in_size - 1);
+}
+
+__global__ __launch_bounds__(256) void lp_reshape_mask_kernel(const float* __restrict__ src, int sb, int sc, int sf,
+                                                              int sh, int sw, float* __restrict__ dst, int db, int dc,
+                                                              int df, int dh, int dw, int taps, int binarize) {
+    const int64_t total = static_cast<int64_t>(db) * dc * df * dh * dw;
+    const int half = taps / 2;
+    for (int64_t o = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; o < total;
+         o += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        int64_t t = o;
+        const int w = static_cast<int>(t % dw); t /= dw;
+        const int h = static_cast<int>(t % dh); t /= dh;
+        const int f = static_cast<int>(t % df); t /= df;
+        const int c = static_cast<int>(t % dc); t /= dc;
+        const int b = static_cast<int>(t);
+        const int ws = nearest_exact(w, sw, dw), hs = nearest_exact(h, sh, dh);
+        const int64_t plane = (static_cast<int64_t>(b % sb) * sc + (c % sc)) * sf;
+        float v = -INFINITY;
+        for (int k = -half; k <= half; ++k) {           // max_pool3d (5,1,1), pad (2,0,0) with -inf
+            const int ff = f + k;
+            if (ff < 0 || ff >= df) continue;
+            const int fs = nearest_exact(ff, sf, df);
+            const float s = src[((plane + fs) * sh + hs) * sw + ws];
+            v = (s > v || s != s) ? s : v;              // NaN propagates like torch's max_pool
+        }
+        if (binarize) v = 1.0f - ((v > 0.5f) ? 1.0f : 0.0f);
+        dst[o] = v;
+    }
+}
+
+int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int sw, float* dst, int db, int dc, int df,
+                          int dh, int dw, int taps, int binarize, hipStream_t stream) {
+    if (!src || !dst || sb <= 0 || sc <= 0 || sf <= 0 || sh <= 0 || sw <= 0 || db <= 0 || dc <= 0 || df <= 0 ||
+        dh <= 0 || dw <= 0)
+        return LP_E_INVALID;
+    if (taps < 1 || (taps % 2) == 0) return LP_E_INVALID;
+    const int64_t total = static_cast<int64_t>(db) * dc * df * dh * dw;
+    int64_t bx = (total + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(lp_reshape_mask_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, src, sb, sc, sf,
+                       sh, sw, dst, db, dc, df, dh, dw, taps, binarize);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+}  // namespace lp

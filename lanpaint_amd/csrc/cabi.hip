@@ -1,0 +1,68 @@
+// cabi.hip -- extern "C" surface of liblanpaint_hip.so (declared in include/lanpaint_hip.h).
+// Plain pointers and sizes in, int status out; nothing is allocated, no global state,
+// every launch goes to the caller's stream and nothing here synchronises.
+#include "lp_common.h"
+
+namespace lp {
+int step_dispatch(const lp_step_desc* d, hipStream_t stream);
+int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const float* abt, int abt_stride,
+                    const float* rs, int rs_stride, const float* step_ov, int step_stride, int rows, float* table,
+                    hipStream_t stream);
+int finalize_dispatch(const lp_final_desc* d, hipStream_t stream);
+int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream);
+int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream);
+int wmse_dispatch(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
+                  double* scratch, int scratch_blocks, hipStream_t stream);
+int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int sw, float* dst, int db, int dc, int df,
+                          int dh, int dw, int taps, int binarize, hipStream_t stream);
+}  // namespace lp
+
+static inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int lp_abi_version(void) { return LP_ABI_VERSION; }
+
+const char* lp_strerror(int code) {
+    switch (code) {
+        case LP_OK: return "ok";
+        case LP_E_INVALID: return "invalid argument (null pointer or inconsistent sizes/phases)";
+        case LP_E_UNSUPPORTED: return "unsupported layout or flag combination";
+        case LP_E_LAUNCH: return "HIP kernel launch failed";
+        case LP_E_ALIGN: return "pointer not aligned for the requested layout";
+        default: return "unknown lanpaint_hip error code";
+    }
+}
+
+int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const float* abt, int abt_stride,
+              const float* replace_sigma, int rs_stride, const float* step_override, int step_stride, int rows,
+              float* coef_table, void* stream) {
+    return lp::coeffs_dispatch(hyper, ve_sigma, ve_stride, abt, abt_stride, replace_sigma, rs_stride, step_override,
+                               step_stride, rows, coef_table, as_stream(stream));
+}
+
+int lp_step(const lp_step_desc* desc, void* stream) { return lp::step_dispatch(desc, as_stream(stream)); }
+
+int lp_finalize(const lp_final_desc* desc, void* stream) { return lp::finalize_dispatch(desc, as_stream(stream)); }
+
+int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream) {
+    return lp::philox_dispatch(out, n_el, seed, offset, slot, as_stream(stream));
+}
+
+int lp_boundary_ring(const float* mask, float* ring, int64_t planes, int32_t height, int32_t width, void* stream) {
+    return lp::ring_dispatch(mask, ring, planes, height, width, as_stream(stream));
+}
+
+int lp_wmse_pair(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
+                 double* block_scratch, int32_t scratch_blocks, void* stream) {
+    return lp::wmse_dispatch(a, b, mask, ring, n_el, acc, block_scratch, scratch_blocks, as_stream(stream));
+}
+
+int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
+                    float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
+                    int32_t temporal_taps, int32_t binarize, void* stream) {
+    return lp::reshape_mask_dispatch(src, src_b, src_c, src_f, src_h, src_w, dst, batch, channels, dst_f, dst_h, dst_w,
+                                     temporal_taps, binarize, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,391 @@
+// step_kernel.hip -- the fused Langevin "think" step for gfx950 (CDNA4, wave64).
+//
+// One launch = [everything after backbone call i] + [everything before call i+1],
+// one pass over the latent: 16 B/lane coalesced loads straight HBM -> VGPR -> HBM
+// (no element is reused inside the pass, so an LDS stage would only add latency;
+// LDS is used where there IS reuse: the mask-edge stencil in aux_kernels.hip).
+// blockIdx.y = batch row, so the per-row coefficient table lands in SGPRs via
+// scalar loads and the binary-mask path needs no transcendental per element.
+//
+// Math restated from the reference (file:line = /root/reference/src/LanPaint/):
+//   replace + VP rescale        lanpaint.py:94-99
+//   masked score split, Coef_C  lanpaint.py:159-184, 212-220
+//   exact OU step + noise       lanpaint.py:232-254
+//   overdamped scheme           lanpaint.py:274-286 (second half-step uses the OLD C)
+//   back to model space         lanpaint.py:144-147, 163, 168
+#include "lp_common.h"
+
+namespace lp {
+
+struct RegionCoef {
+    float e_full, k_full, std_full, e_half, k_half, std_half, dt, a, cx0, cxt;
+};
+
+struct RowCoef {
+    float scale, sqrt_abt, oma, abt, rsigma, dtx, dty, ax, ay, dx, dy, valid;
+    RegionCoef reg[2];
+};
+
+__device__ __forceinline__ RowCoef load_row(const float* __restrict__ coef, int row) {
+    const float* c = coef + static_cast<int64_t>(row) * LP_COEF_STRIDE;   // wave-uniform -> s_load
+    RowCoef r;
+    r.scale = c[LP_C_SCALE]; r.sqrt_abt = c[LP_C_SQRT_ABT]; r.oma = c[LP_C_OMA]; r.abt = c[LP_C_ABT];
+    r.rsigma = c[LP_C_RSIGMA]; r.dtx = c[LP_C_DTX]; r.dty = c[LP_C_DTY]; r.ax = c[LP_C_AX]; r.ay = c[LP_C_AY];
+    r.dx = c[LP_C_DX]; r.dy = c[LP_C_DY]; r.valid = c[LP_C_VALID];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);
+        r.reg[g] = RegionCoef{q[LP_R_E_FULL], q[LP_R_K_FULL], q[LP_R_STD_FULL], q[LP_R_E_HALF], q[LP_R_K_HALF],
+                              q[LP_R_STD_HALF], q[LP_R_DT], q[LP_R_A], q[LP_R_CX0], q[LP_R_CXT]};
+    }
+    return r;
+}
+
+// per-element coefficient set of the GENERAL path (soft masks, per-element times);
+// op order mirrors prepare_step_size (lanpaint.py:295-328) + lanpaint.py:212-214.
+struct ElemCoef {
+    float a, d, dt, sqrt_abt, oma, scale;
+    bool valid;
+};
+
+__device__ __forceinline__ ElemCoef elem_from_row(const RowCoef& rc, float m) {
+    const float om = 1.0f - m;
+    ElemCoef e;
+    e.a = rc.ax * om + rc.ay * m;
+    e.d = rc.dx * om + rc.dy * m;
+    e.dt = rc.dtx * om + rc.dty * m;
+    e.sqrt_abt = rc.sqrt_abt;
+    e.oma = rc.oma;
+    e.scale = rc.scale;
+    e.valid = rc.valid != 0.0f;
+    return e;
+}
+
+__device__ __forceinline__ ElemCoef elem_from_times(float abt, float ve, float m, bool flow, float opl, float beta,
+                                                    float step_size, float min_step_frac) {
+    const float oma = 1.0f - abt;
+    const float step = step_size * fmaxf(oma, min_step_frac);        // lanpaint.py:81
+    const float dtx2 = 2.0f * step * 1.0f, dty2 = 2.0f * step * beta;  // :300-301 (sigma_x = 1, sigma_y = beta)
+    const float atx = (1.0f / oma) * dtx2 / 2.0f;                     // :315
+    const float aty = (opl / oma) * dty2 / 2.0f;                // :316
+    const float ax = atx / (dtx2 / 2.0f), ay = aty / (dty2 / 2.0f);   // :319-320
+    const float dxy = sqrtf(2.0f);                                    // :326-327
+    const float om = 1.0f - m;
+    ElemCoef e;
+    e.a = ax * om + ay * m;
+    e.d = dxy * om + dxy * m;
+    e.dt = (dtx2 / 2.0f) * om + (dty2 / 2.0f) * m;
+    e.sqrt_abt = sqrtf(abt);
+    e.oma = oma;
+    e.scale = flow ? (sqrtf(abt) + sqrtf(1.0f - abt)) : sqrtf(1.0f + ve * ve);
+    e.valid = step > 0.0f;
+    return e;
+}
+
+// advance_time_overdamped, lanpaint.py:232-254 (general form, fp32 like the reference)
+__device__ __forceinline__ float ou_general(float x, float tau, float a, float c, float d, float xi) {
+    const float adt = a * tau;
+    const float e = expf(-adt);
+    float k, k2;
+    if (fabsf(a) < 1e-8f) {
+        k = tau;
+        k2 = tau;
+    } else {
+        k = (-expm1f(-adt)) / a;
+        k2 = (-expm1f(-2.0f * adt)) / (2.0f * a);
+    }
+    const float mean = e * x + k * c;
+    const float var = (d * d) * k2;
+    return mean + xi * sqrtf(fmaxf(var, 0.0f));
+}
+
+template <int VEC, bool PER_EL>
+__global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
+    const int row = blockIdx.y;
+    const uint32_t ph = d.phases, fl = d.flags;
+    const bool flow = fl & LP_FL_FLOW;
+    const int x0dt = x0_dtype(fl), xindt = xin_dtype(fl);
+    const int64_t groups = d.el_per_row / VEC;
+    const int64_t row_base = static_cast<int64_t>(row) * d.el_per_row;
+    const float lam = d.lambda, opl = d.one_plus_lambda;
+
+    RowCoef rc;
+    if constexpr (!PER_EL) rc = load_row(d.coef, row);
+
+    uint64_t seq = d.rng_offset;
+    if (d.rng_offset_ptr) seq += *d.rng_offset_ptr;
+
+    for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < groups;
+         g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t i = row_base + g * VEC;
+
+        float m[VEC], xt[VEC], yv[VEC];
+        load_mask<VEC>(d.mask, fl, i, m);
+
+        float abt_e[VEC], ve_e[VEC];
+        if constexpr (PER_EL) {
+            load_f32<VEC>(d.abt_el, i, abt_e);
+            if (!flow) load_f32<VEC>(d.ve_el, i, ve_e);
+        }
+
+        // ---- REPLACE: x = x(1-m) + known*m ; x_t = VP(x) ------------------------
+        if (ph & LP_PH_REPLACE) {
+            float xv[VEC], kn[VEC];
+            load_f32<VEC>(d.x, i, xv);
+            if (d.replace_kind == LP_REPLACE_KNOWN) {
+                load_f32<VEC>(d.known, i, kn);
+            } else {
+                float nv[VEC], rs[VEC];
+                load_f32<VEC>(d.noise, i, nv);
+                load_f32<VEC>(d.y, i, yv);
+                if constexpr (PER_EL) {
+                    load_f32<VEC>(d.rsig_el, i, rs);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) rs[k] = rc.rsigma;
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    kn[k] = (d.replace_kind == LP_REPLACE_VE) ? (yv[k] + nv[k] * rs[k])
+                                                              : (rs[k] * (d.noise_scale * nv[k]) + (1.0f - rs[k]) * yv[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float xr = xv[k] * (1.0f - m[k]) + kn[k] * m[k];
+                float sc;
+                if constexpr (PER_EL) {
+                    sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
+                } else {
+                    sc = rc.scale;
+                }
+                xt[k] = flow ? xr * sc : xr / sc;
+            }
+        } else {
+            load_f32<VEC>(d.x_t, i, xt);
+        }
+
+        const bool post = ph & (LP_PH_POST_FIRST | LP_PH_POST_STEADY);
+        float cv[VEC];
+        if (post || (ph & LP_PH_PRE_HALF)) {
+            if (ph & LP_PH_POST_FIRST) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) cv[k] = 0.0f;
+            } else {
+                load_f32<VEC>(d.C, i, cv);
+            }
+        }
+
+        // Philox quad index follows the FLAT element index so the stream does not
+        // depend on VEC or on the row split.
+        float xi_a[VEC], xi_b[VEC];
+        auto draw = [&](const float* host_xi, uint32_t slot, float (&z)[VEC]) {
+            if (host_xi) {
+                load_f32<VEC>(host_xi, i, z);
+            } else if constexpr (VEC == 4) {
+                normal4(static_cast<uint64_t>(i) >> 2, seq, slot, d.rng_seed, z);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float z4[4];
+                    normal4(static_cast<uint64_t>(i + k) >> 2, seq, slot, d.rng_seed, z4);
+                    z[k] = z4[(i + k) & 3];
+                }
+            }
+        };
+
+        // ---- POST: score split -> x0s, C' ; drift correction ; OU -----------------
+        if (post) {
+            float x0[VEC], x0b[VEC], x0s[VEC];
+            load_any<VEC>(d.x0, x0dt, i, x0);
+            if (d.x0_big == d.x0 || (fl & LP_FL_X0S_GIVEN)) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) x0b[k] = x0[k];
+            } else {
+                load_any<VEC>(d.x0_big, x0dt, i, x0b);
+            }
+            if (fl & LP_FL_X0S_GIVEN) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) yv[k] = 0.0f;
+            } else {
+                load_f32<VEC>(d.y, i, yv);
+            }
+            draw(d.xi_post, 0u, xi_a);
+            float corr[VEC];
+            const bool given = fl & LP_FL_X0S_GIVEN;
+            const bool has_corr = d.corr_el != nullptr && !given;
+            if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
+
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float mk = m[k];
+                const bool binary = (mk == 0.0f) || (mk == 1.0f);
+                if (!PER_EL && binary && !has_corr) {
+                    // table path: two regions per row, no transcendental per element
+                    if (rc.valid != 0.0f) {
+                        const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
+                        const float s0 = (given || mk != 1.0f) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
+                        const float cn = q.cx0 * s0 + q.cxt * xt[k];
+                        x0s[k] = s0;
+                        if (ph & LP_PH_POST_FIRST) {
+                            xt[k] = q.e_full * xt[k] + q.k_full * cn + q.std_full * xi_a[k];
+                        } else {
+                            const float xd = xt[k] + (cn - cv[k]) * q.dt;
+                            xt[k] = q.e_half * xd + q.k_half * cv[k] + q.std_half * xi_a[k];
+                        }
+                        cv[k] = cn;
+                    } else {
+                        x0s[k] = x0[k];
+                    }
+                } else {
+                    ElemCoef e;
+                    if constexpr (PER_EL) {
+                        e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size,
+                                            d.min_step_frac);
+                    } else {
+                        e = elem_from_row(rc, mk);
+                    }
+                    float h0 = x0[k], h1 = x0b[k];
+                    if (has_corr) {           // lanpaint.py:173-180
+                        const float xm = flow ? xt[k] / e.scale : xt[k] * e.scale;
+                        h0 = xm + corr[k] * (h0 - xm);
+                        h1 = xm + corr[k] * (h1 - xm);
+                    }
+                    if (e.valid) {
+                        float s0 = h0;
+                        if (!given) {
+                            const float score_x = -(xt[k] - h0);
+                            const float score_y = -opl * (xt[k] - yv[k]) + lam * (xt[k] - h1);
+                            s0 = xt[k] + (score_x * (1.0f - mk) + score_y * mk);
+                        }
+                        const float cn = (e.sqrt_abt * s0 - xt[k]) / e.oma + e.a * xt[k];
+                        x0s[k] = s0;
+                        if (ph & LP_PH_POST_FIRST) {
+                            xt[k] = ou_general(xt[k], e.dt, e.a, cn, e.d, xi_a[k]);
+                        } else {
+                            const float xd = xt[k] + (cn - cv[k]) * e.dt;
+                            xt[k] = ou_general(xd, e.dt / 2.0f, e.a, cv[k], e.d, xi_a[k]);
+                        }
+                        cv[k] = cn;
+                    } else {
+                        x0s[k] = h0;
+                    }
+                }
+            }
+            if (fl & LP_FL_WRITE_X0S) store_f32<VEC>(d.x0s, i, x0s);
+        }
+
+        // ---- PRE_HALF: first half-step of the next iteration (uses the new C) ------
+        if (ph & LP_PH_PRE_HALF) {
+            draw(d.xi_pre, 1u, xi_b);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float mk = m[k];
+                const bool binary = (mk == 0.0f) || (mk == 1.0f);
+                if (!PER_EL && binary) {
+                    if (rc.valid != 0.0f) {
+                        const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
+                        xt[k] = q.e_half * xt[k] + q.k_half * cv[k] + q.std_half * xi_b[k];
+                    }
+                } else {
+                    ElemCoef e;
+                    if constexpr (PER_EL) {
+                        e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size,
+                                            d.min_step_frac);
+                    } else {
+                        e = elem_from_row(rc, mk);
+                    }
+                    if (e.valid) xt[k] = ou_general(xt[k], e.dt / 2.0f, e.a, cv[k], e.d, xi_b[k]);
+                }
+            }
+        }
+
+        if (post) store_f32<VEC>(d.C, i, cv);
+        if (ph & (LP_PH_REPLACE | LP_PH_POST_FIRST | LP_PH_POST_STEADY | LP_PH_PRE_HALF)) store_f32<VEC>(d.x_t, i, xt);
+
+        // ---- EMIT: model-space latent for the next backbone call ---------------------
+        if (ph & LP_PH_EMIT) {
+            float xo[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float sc;
+                if constexpr (PER_EL) {
+                    sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
+                } else {
+                    sc = rc.scale;
+                }
+                xo[k] = flow ? xt[k] / sc : xt[k] * sc;
+            }
+            store_any<VEC>(d.x_in, xindt, i, xo);
+        }
+    }
+}
+
+template <int VEC, bool PER_EL>
+static hipError_t launch(const lp_step_desc& d, hipStream_t stream) {
+    const int64_t groups = d.el_per_row / VEC;
+    // small problems: 64-thread blocks spread single waves over all 256 CUs (latency bound);
+    // large ones: 256-thread blocks, capped near 8 blocks/CU, grid-stride the rest.
+    const int64_t total_groups = groups * d.rows;
+    const int block = total_groups <= 64 * 1024 ? 64 : 256;
+    int64_t bx = (groups + block - 1) / block;
+    const int64_t cap = (2048 + d.rows - 1) / d.rows;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL((lp_step_kernel<VEC, PER_EL>), dim3(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows)),
+                       dim3(block), 0, stream, d);
+    return hipGetLastError();
+}
+
+static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int step_dispatch(const lp_step_desc* dp, hipStream_t stream) {
+    if (!dp) return LP_E_INVALID;
+    const lp_step_desc& d = *dp;
+    if (d.n_el <= 0 || d.rows <= 0 || d.el_per_row <= 0 || d.n_el != d.el_per_row * d.rows) return LP_E_INVALID;
+    if (d.rows > 65535) return LP_E_UNSUPPORTED;
+    if (!d.mask || !d.x_t) return LP_E_INVALID;
+    const uint32_t ph = d.phases;
+    if (ph == 0 || (ph & ~0x1fu)) return LP_E_INVALID;
+    if ((ph & LP_PH_POST_FIRST) && (ph & LP_PH_POST_STEADY)) return LP_E_INVALID;
+    if ((ph & LP_PH_REPLACE) && (ph & (LP_PH_POST_FIRST | LP_PH_POST_STEADY | LP_PH_PRE_HALF))) return LP_E_INVALID;
+    const bool per_el = d.flags & LP_FL_PER_ELEMENT;
+    if (!per_el && !d.coef) return LP_E_INVALID;
+    if (per_el && (!d.abt_el || (!(d.flags & LP_FL_FLOW) && !d.ve_el))) return LP_E_INVALID;
+    if (ph & LP_PH_REPLACE) {
+        if (!d.x) return LP_E_INVALID;
+        if (d.replace_kind == LP_REPLACE_KNOWN) {
+            if (!d.known) return LP_E_INVALID;
+        } else if (d.replace_kind == LP_REPLACE_VE || d.replace_kind == LP_REPLACE_FLOW) {
+            if (!d.noise || !d.y) return LP_E_INVALID;
+            if (per_el && !d.rsig_el) return LP_E_INVALID;
+        } else {
+            return LP_E_INVALID;
+        }
+    }
+    if (ph & (LP_PH_POST_FIRST | LP_PH_POST_STEADY)) {
+        const bool given = d.flags & LP_FL_X0S_GIVEN;
+        if (!d.x0 || !d.C || (!given && (!d.x0_big || !d.y))) return LP_E_INVALID;
+        if ((d.flags & LP_FL_WRITE_X0S) && !d.x0s) return LP_E_INVALID;
+    }
+    if ((ph & LP_PH_PRE_HALF) && !d.C) return LP_E_INVALID;
+    if ((ph & LP_PH_EMIT) && !d.x_in) return LP_E_INVALID;
+
+    const size_t half_al = 8, f_al = 16;
+    const bool x0_half = x0_dtype(d.flags) != DT_F32, xin_half = xin_dtype(d.flags) != DT_F32;
+    const bool vec4 = (d.el_per_row % 4 == 0) && aligned(d.coef, 4) && aligned(d.x, f_al) && aligned(d.known, f_al) &&
+                      aligned(d.noise, f_al) && aligned(d.y, f_al) &&
+                      aligned(d.mask, (d.flags & LP_FL_MASK_U8) ? 4 : f_al) && aligned(d.x_t, f_al) &&
+                      aligned(d.C, f_al) && aligned(d.x0s, f_al) && aligned(d.x0, x0_half ? half_al : f_al) &&
+                      aligned(d.x0_big, x0_half ? half_al : f_al) && aligned(d.x_in, xin_half ? half_al : f_al) &&
+                      aligned(d.xi_post, f_al) && aligned(d.xi_pre, f_al) && aligned(d.abt_el, f_al) &&
+                      aligned(d.ve_el, f_al) && aligned(d.rsig_el, f_al) && aligned(d.corr_el, f_al);
+    hipError_t err;
+    if (vec4) {
+        err = per_el ? launch<4, true>(d, stream) : launch<4, false>(d, stream);
+    } else {
+        err = per_el ? launch<1, true>(d, stream) : launch<1, false>(d, stream);
+    }
+    return err == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+}  // namespace lp

@@ -1,0 +1,569 @@
+"""LanPaint's Langevin "think" loop on MI355X: host side.
+
+Drop-in for the reference engine class (/root/reference/src/LanPaint/lanpaint.py:7-328):
+same constructor, same `__call__(x, latent_image, noise, sigma, latent_mask,
+current_times, model_options, seed, n_steps=None, ...)`, same in-place mutation of
+`x` (lanpaint.py:156), same tuple/list/single model-output handling (lanpaint.py:34-43),
+same public helper methods.  The arithmetic does NOT run here: every per-element
+operation of the loop is one launch of the fused HIP kernel behind the C ABI
+(include/lanpaint_hip.h), reached through ctypes with raw device pointers.
+
+Loop shape (the backbone call is the only cut):
+    lp_coeffs                         per-row table on the device (no host sync)
+    lp_step REPLACE|EMIT              replace step, VP rescale, first model input
+    for i in range(n):   model(x_in)  -> (x0, x0_BIG)
+        lp_step POST|PRE_HALF|EMIT    post-model half of iteration i fused with the
+                                      pre-model half of iteration i+1
+    model(x) ; lp_finalize            known-region reprojection + write-back of x
+
+There is no CPU / eager fallback: a missing extension or a non-HIP tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from functools import partial
+
+import torch
+
+from . import _cabi
+from ._cabi import (LP_FL_FLOW, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
+                    LP_PH_EMIT, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_REPLACE, LP_REPLACE_FLOW,
+                    LP_REPLACE_KNOWN, LP_REPLACE_VE)
+from .earlystop import LanPaintEarlyStopper
+from .types import LangevinState
+
+_VOID_NULL = None
+
+
+def _as_f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+def _noise_scaling_kind(model_sampling) -> str:
+    """Which closed form the replace step may fuse (lanpaint.py:84-94).  'callback'
+    keeps the reference behaviour for any model_sampling: call its noise_scaling."""
+    kind = getattr(model_sampling, "lanpaint_noise_scaling_kind", None)
+    if kind in ("ve", "flow"):
+        return kind
+    try:                                   # ComfyUI present: recognise its stock EPS / CONST forms
+        import comfy.model_sampling as cms  # type: ignore
+        fn = getattr(type(model_sampling), "noise_scaling", None)
+        if fn is getattr(getattr(cms, "CONST", None), "noise_scaling", object()):
+            return "flow"
+        if fn is getattr(getattr(cms, "EPS", None), "noise_scaling", object()):
+            return "ve"
+    except Exception:
+        pass
+    return "callback"
+
+
+class _Workspace:
+    """Device buffers reused across sigma calls of one engine (torch-owned)."""
+
+    def __init__(self, like: torch.Tensor):
+        self.shape, self.device = tuple(like.shape), like.device
+        self.x_t = torch.empty_like(like)
+        self.C = torch.empty_like(like)
+        self.coef = torch.empty((like.shape[0], _cabi.LP_COEF_STRIDE), dtype=torch.float32, device=like.device)
+        self.x0s = []            # lazily: rotating buffers for LangevinState.x0 (early stop only)
+
+    def matches(self, like):
+        return self.shape == tuple(like.shape) and self.device == like.device
+
+
+class LanPaint:
+    # ------------------------------------------------------------------ construction
+    def __init__(self, Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX=False, IS_FLOW=False,
+                 EarlyStopThreshold=0.0, EarlyStopPatience=1, EarlyStopHook=None, MinStepFrac=0.0,
+                 *, rng=None, philox_seed=None):
+        """Positional signature == reference lanpaint.py:8.  Keyword-only extras:
+        rng: "torch" (default; xi = torch.randn_like in the reference's draw order, so a
+             seeded run consumes the device generator exactly like the reference),
+             "philox" (xi generated inside the fused kernel, nothing read from HBM),
+             or a callable `rng(like) -> Tensor` (tests feed recorded streams).
+             Env LANPAINT_AMD_RNG overrides the default.
+        philox_seed: Philox key; defaults to the `seed` argument of each call."""
+        self.n_steps = NSteps
+        self.chara_lamb = Lambda
+        self.IS_FLUX = IS_FLUX
+        self.IS_FLOW = IS_FLOW
+        self.step_size = StepSize
+        self.inner_model = Model
+        self.friction = Friction
+        self.chara_beta = Beta
+        self.min_step_frac = MinStepFrac
+        self.img_dim_size = None
+        self.early_stop_threshold = EarlyStopThreshold
+        self.early_stop_patience = EarlyStopPatience
+        self.early_stop_hook = EarlyStopHook
+
+        self.rng = rng if rng is not None else os.environ.get("LANPAINT_AMD_RNG", "torch")
+        if not callable(self.rng) and self.rng not in ("torch", "philox"):
+            raise ValueError(f"rng must be 'torch', 'philox' or a callable, got {self.rng!r}")
+        self.philox_seed = philox_seed
+        self._philox_offset = 0
+        self._lib = _cabi.load()                 # raises if the HIP extension is not built
+        self._ws = None
+        self._desc = _cabi.LpStepDesc()
+        self._fdesc = _cabi.LpFinalDesc()
+        self._hyper = _cabi.LpHyper()
+        self._noise_check = None                 # (data_ptr, version, numel) -> bool cache
+        self.iterations_run = 0                  # think iterations executed (it/s accounting)
+        self.last_inner_steps = 0
+
+    # ------------------------------------------------------------------ reference helpers
+    def add_none_dims(self, array):
+        """lanpaint.py:23-29."""
+        while array.ndim < self.img_dim_size:
+            array = array.unsqueeze(array.ndim)
+        return array
+
+    def remove_none_dims(self, array):
+        """lanpaint.py:30-33."""
+        return array[(slice(None),) + (0,) * (self.img_dim_size - 1)]
+
+    def unpack_model_output(self, output):
+        """lanpaint.py:34-43."""
+        if isinstance(output, (tuple, list)):
+            if len(output) >= 2:
+                return output[0], output[1]
+            if len(output) == 1:
+                return output[0], output[0]
+            raise ValueError("Model output is empty")
+        return output, output
+
+    def sigma_x(self, abt):
+        """lanpaint.py:185-187."""
+        return abt ** 0
+
+    def sigma_y(self, abt):
+        """lanpaint.py:188-190."""
+        return self.chara_beta * abt ** 0
+
+    def prepare_step_size(self, current_times, step_size, sigma_x, sigma_y):
+        """lanpaint.py:295-328, host tensors; kept for API parity (the kernels take
+        the same quantities from the lp_coeffs table)."""
+        sigma, abt, _flow_t = current_times
+        sigma, abt = self.add_none_dims(sigma), self.add_none_dims(abt)
+        dtx, dty = 2 * step_size * sigma_x, 2 * step_size * sigma_y
+        gam_x = self.friction ** 2 * self.step_size * sigma_x / 0.1 * sigma ** 0 / 2.0
+        gam_y = self.friction ** 2 * self.step_size * sigma_y / 0.1 * sigma ** 0 / 2.0
+        a_t_x = 1 / (1 - abt) * dtx / 2
+        a_t_y = (1 + self.chara_lamb) / (1 - abt) * dty / 2
+        a_x, a_y = a_t_x / (dtx / 2), a_t_y / (dty / 2)
+        d = (2 * abt ** 0) ** 0.5
+        return sigma, abt, dtx / 2, dty / 2, gam_x / (dtx / 2), gam_y / (dty / 2), a_x, a_y, d, d
+
+    def score_model(self, x_t, y, mask, abt, sigma, tflow, model_options, seed):
+        """lanpaint.py:159-184 as host tensor ops: the public/compat entry.  The fused
+        loop never calls this; it exists so code written against the reference
+        (and overrides of it) keeps working."""
+        lamb = self.chara_lamb
+        if self.IS_FLUX or self.IS_FLOW:
+            x = x_t / (abt ** 0.5 + (1 - abt) ** 0.5)
+            t = self.remove_none_dims(tflow)
+        else:
+            x = x_t * (1 + sigma ** 2) ** 0.5
+            t = self.remove_none_dims(sigma)
+        x_0, x_0_big = self.unpack_model_output(self.inner_model(x, t, model_options=model_options, seed=seed))
+        corr = getattr(self, "audio_correction", None)
+        if corr is not None:
+            x_0 = x + corr * (x_0 - x)
+            x_0_big = x + corr * (x_0_big - x)
+        score_x = -(x_t - x_0)
+        score_y = -(1 + lamb) * (x_t - y) + lamb * (x_t - x_0_big)
+        return score_x * (1 - mask) + score_y * mask
+
+    # ------------------------------------------------------------------ plumbing
+    def _overridden(self, name):
+        return name in self.__dict__ or getattr(type(self), name) is not getattr(LanPaint, name)
+
+    def _stream(self, device):
+        return torch.cuda.current_stream(device).cuda_stream
+
+    def _noise_is_zero(self, noise):
+        """lanpaint.py:51: `mean|noise| < 1e-8` costs the reference one host sync per
+        sigma; the verdict is cached on (storage, version) so it is paid once."""
+        key = (noise.data_ptr(), noise._version, noise.numel())
+        if self._noise_check is None or self._noise_check[0] != key:
+            self._noise_check = (key, bool(torch.mean(torch.abs(noise)) < 1e-8))
+        return self._noise_check[1]
+
+    def _draw(self, like):
+        """One N(0,1) tensor in the reference's draw order (lanpaint.py:252), or None
+        when the kernel generates it (Philox)."""
+        if self.rng == "philox":
+            return None
+        xi = torch.randn_like(like) if self.rng == "torch" else self.rng(like)
+        return _as_f32c(xi)
+
+    def _fill_hyper(self, flow):
+        h = self._hyper
+        h.lambda_, h.beta, h.step_size = float(self.chara_lamb), float(self.chara_beta), float(self.step_size)
+        h.min_step_frac, h.is_flow = float(self.min_step_frac), int(bool(flow))
+        h.one_plus_lambda = 1.0 + float(self.chara_lamb)     # double sum, then fp32 (ctypes c_float)
+        return h
+
+    def _workspace(self, like):
+        if self._ws is None or not self._ws.matches(like):
+            self._ws = _Workspace(like)
+        return self._ws
+
+    def _launch_step(self, stream):
+        _cabi.check(self._lib.lp_step(ctypes.byref(self._desc), stream), "lp_step")
+
+    def _set_model_heads(self, d, x0, x0_big, base_flags, shape):
+        """Point the descriptor at the backbone outputs (fp32/bf16/fp16, made dense)."""
+        if x0.shape != shape:
+            x0 = x0.expand(shape)
+        if x0_big.shape != shape:
+            x0_big = x0_big.expand(shape)
+        same = x0_big is x0
+        if x0.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            x0 = x0.float()
+        if not x0.is_contiguous():
+            x0 = x0.contiguous()
+        if same:
+            x0_big = x0
+        else:
+            if x0_big.dtype != x0.dtype:
+                x0_big = x0_big.to(x0.dtype)
+            if not x0_big.is_contiguous():
+                x0_big = x0_big.contiguous()
+        fl = base_flags
+        if x0.dtype == torch.bfloat16:
+            fl |= LP_FL_X0_BF16
+        elif x0.dtype == torch.float16:
+            fl |= LP_FL_X0_F16
+        d.flags = fl
+        d.x0, d.x0_big = x0.data_ptr(), x0_big.data_ptr()
+        return x0, x0_big          # keep alive until the launch is enqueued
+
+    # ------------------------------------------------------------------ entry points
+    def __call__(self, x, latent_image, noise, sigma, latent_mask, current_times, model_options, seed, n_steps=None,
+                 current_times_audio=None, audio_indicator=None, audio_correction=None):
+        """lanpaint.py:44-55."""
+        if not x.is_cuda:
+            raise RuntimeError("lanpaint_amd.LanPaint runs on a HIP device only (got a %s tensor); "
+                               "there is no CPU fallback" % x.device.type)
+        self.img_dim_size = len(x.shape)
+        self.latent_image = latent_image
+        self.noise = noise
+        self.audio_indicator = audio_indicator
+        self.current_times_audio = current_times_audio
+        self.audio_correction = audio_correction
+        if self._noise_is_zero(noise):
+            self.noise = torch.randn_like(noise)
+        if n_steps is None:
+            n_steps = self.n_steps
+        if x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX,
+                                     self.IS_FLOW)
+        return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX,
+                             self.IS_FLOW)
+
+    def LanPaint(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
+        """lanpaint.py:56-157."""
+        lib, d = self._lib, self._desc
+        input_x = x
+        flow = bool(IS_FLUX or IS_FLOW)
+        xc = _as_f32c(x)
+        shape, n_el, rows = xc.shape, xc.numel(), xc.shape[0]
+        ws = self._workspace(xc)
+        stream = self._stream(xc.device)
+        y = _as_f32c(self.latent_image if self.latent_image.shape == shape else self.latent_image.expand(shape))
+        nz = _as_f32c(self.noise if self.noise.shape == shape else self.noise.expand(shape))
+        m = latent_mask if latent_mask.shape == shape else latent_mask.expand(shape)
+        m = _as_f32c(m)
+
+        VE_Sigma, abt, Flow_t = current_times
+        replace_sigma = sigma
+        per_el = False
+        if self.audio_indicator is not None and self.current_times_audio is not None:     # lanpaint.py:68-74
+            VE_a, abt_a, Flow_a = self.current_times_audio
+            ai = self.audio_indicator
+            VE_Sigma = VE_Sigma * (1 - ai) + VE_a * ai
+            abt = abt * (1 - ai) + abt_a * ai
+            replace_sigma = sigma * (1 - ai) + Flow_a * ai
+            current_times = (VE_Sigma, abt, Flow_t)
+        if abt.numel() not in (1, rows) or VE_Sigma.numel() not in (1, rows) or replace_sigma.numel() not in (1, rows):
+            per_el = True
+
+        # ---- per-call descriptor --------------------------------------------------
+        base_flags = LP_FL_FLOW if flow else 0
+        hyp = self._fill_hyper(flow)
+        d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
+        d.lambda_, d.one_plus_lambda, d.beta = hyp.lambda_, hyp.one_plus_lambda, hyp.beta
+        d.step_size, d.min_step_frac = hyp.step_size, hyp.min_step_frac
+        d.y, d.mask, d.x_t, d.C = y.data_ptr(), m.data_ptr(), ws.x_t.data_ptr(), ws.C.data_ptr()
+        d.x0s = None
+        d.abt_el = d.ve_el = d.rsig_el = d.corr_el = None
+        keep = []          # tensors that must outlive the enqueued launches of this call
+        corr = self.audio_correction
+        if per_el:
+            base_flags |= LP_FL_PER_ELEMENT
+            abt_el = _as_f32c(self.add_none_dims(abt).expand(shape))
+            ve_el = _as_f32c(self.add_none_dims(VE_Sigma).expand(shape))
+            rs_el = _as_f32c(self.add_none_dims(replace_sigma).expand(shape))
+            keep += [abt_el, ve_el, rs_el]
+            d.abt_el, d.ve_el, d.rsig_el = abt_el.data_ptr(), ve_el.data_ptr(), rs_el.data_ptr()
+            d.coef = None
+        else:
+            ve_r, abt_r, rs_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1)), _as_f32c(replace_sigma.reshape(-1))
+            keep += [ve_r, abt_r, rs_r]
+            _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), ve_r.data_ptr(), int(ve_r.numel() > 1), abt_r.data_ptr(),
+                                      int(abt_r.numel() > 1), rs_r.data_ptr(), int(rs_r.numel() > 1), None, 0, rows,
+                                      ws.coef.data_ptr(), stream), "lp_coeffs")
+            d.coef = ws.coef.data_ptr()
+        if corr is not None:
+            corr_el = _as_f32c(corr if corr.shape == shape else corr.expand(shape))
+            keep.append(corr_el)
+            d.corr_el = corr_el.data_ptr()
+
+        # ---- replace-step source (lanpaint.py:84-94) --------------------------------
+        ms = self.inner_model.inner_model.model_sampling
+        s_b = self.add_none_dims(replace_sigma)
+        d.noise_scale = 1.0
+        d.known = None
+        d.noise = nz.data_ptr()
+        if s_b.numel() == 1:
+            kind = _noise_scaling_kind(ms)
+            if kind == "callback":
+                known = _as_f32c(ms.noise_scaling(s_b, nz, y))
+                keep.append(known)
+                d.replace_kind, d.known = LP_REPLACE_KNOWN, known.data_ptr()
+            elif kind == "ve":
+                d.replace_kind = LP_REPLACE_VE
+            else:
+                d.replace_kind, d.noise_scale = LP_REPLACE_FLOW, float(getattr(ms, "noise_scale", 1.0))
+        else:        # per-row sigma: the reference emulates the FLOW form elementwise (lanpaint.py:89-92)
+            d.replace_kind, d.noise_scale = LP_REPLACE_FLOW, float(getattr(ms, "noise_scale", 1.0))
+
+        # model-space buffer handed to the backbone; fresh per call so the tensor the
+        # final model call saw stays valid after we return
+        x_in = torch.empty_like(xc)
+        d.x_in = x_in.data_ptr()
+        d.x = xc.data_ptr()
+        d.xi_post = d.xi_pre = None
+        d.rng_offset_ptr = None
+        d.rng_seed = int(self.philox_seed if self.philox_seed is not None else (seed or 0)) & 0xFFFFFFFFFFFFFFFF
+        d.flags, d.phases = base_flags, LP_PH_REPLACE | LP_PH_EMIT
+        self._launch_step(stream)
+
+        # ---- think loop ---------------------------------------------------------------
+        if flow:
+            t_model = self.remove_none_dims(self.add_none_dims(Flow_t))
+        else:
+            t_model = self.remove_none_dims(self.add_none_dims(current_times[0]))
+        stopper = LanPaintEarlyStopper.from_options(
+            model_options=model_options if isinstance(model_options, dict) else None, latent_mask=m, abt=abt,
+            default_threshold=self.early_stop_threshold, default_patience=self.early_stop_patience,
+            default_distance_fn=self.early_stop_hook)
+        compat = self._overridden("langevin_dynamics") or self._overridden("score_model") or \
+            self._overridden("prepare_step_size")
+        ran = 0
+        if n_steps > 0 and float(self.step_size) <= 0.0 and not compat:
+            n_steps = 0          # dtx <= 0: every iteration returns immediately (lanpaint.py:205)
+        if compat:
+            ran = self._loop_compat(ws, shape, m, y, abt, current_times, n_steps, model_options, seed, stopper)
+            d.phases = LP_PH_EMIT
+            d.flags = base_flags
+            self._launch_step(stream)
+        elif stopper is not None:
+            ran = self._loop_unfused(ws, shape, x_in, t_model, base_flags, n_steps, model_options, seed, stopper,
+                                     stream, m, y, current_times)
+        else:
+            for i in range(n_steps):
+                heads = self.unpack_model_output(self.inner_model(x_in, t_model, model_options=model_options, seed=seed))
+                alive = self._set_model_heads(d, heads[0], heads[1], base_flags, shape)
+                last = i == n_steps - 1
+                d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
+                self._set_xi(d, ws.x_t, want_pre=not last)
+                self._launch_step(stream)
+                del alive
+            ran = n_steps
+        self.iterations_run += ran
+        self.last_inner_steps = ran
+
+        # ---- final denoise + known-region reprojection + write-back (lanpaint.py:144-157) ----
+        out_model, _ = self.unpack_model_output(self.inner_model(x_in, sigma, model_options=model_options, seed=seed))
+        f = self._fdesc
+        if out_model.shape != shape:
+            out_model = out_model.expand(shape)
+        if out_model.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            out_model = out_model.float()
+        if not out_model.is_contiguous():
+            out_model = out_model.contiguous()
+        out = torch.empty_like(xc)
+        f.n_el = n_el
+        f.flags = (LP_FL_X0_BF16 if out_model.dtype == torch.bfloat16 else
+                   LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0)
+        f.model_out, f.y, f.mask = out_model.data_ptr(), y.data_ptr(), m.data_ptr()
+        f.x_src, f.x_dst, f.out = x_in.data_ptr(), xc.data_ptr(), out.data_ptr()
+        f.rng_bump_ptr, f.rng_bump = None, 0
+        _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
+        if xc is not input_x:
+            input_x.copy_(xc)
+        del keep
+        return out if out.dtype == input_x.dtype else out.to(input_x.dtype)
+
+    # ------------------------------------------------------------------ xi plumbing
+    def _set_xi(self, d, like, want_pre, want_post=True):
+        """Draw in the reference's order: the POST half-step of iteration i, then the
+        PRE half-step of iteration i+1 (lanpaint.py:277,280,283)."""
+        if self.rng == "philox":
+            d.xi_post = d.xi_pre = None
+            d.rng_offset = self._philox_offset
+            self._philox_offset += 1
+            self._xi_alive = None
+            return
+        xa = self._draw(like) if want_post else None
+        xb = self._draw(like) if want_pre else None
+        d.xi_post = xa.data_ptr() if xa is not None else None
+        d.xi_pre = xb.data_ptr() if xb is not None else None
+        self._xi_alive = (xa, xb)
+
+    # ------------------------------------------------------------------ loops off the fast path
+    def _x0s_buffer(self, ws, exclude):
+        """A rotating x0s buffer not aliased by any tensor in `exclude`."""
+        ptrs = {t.data_ptr() for t in exclude if t is not None}
+        for buf in ws.x0s:
+            if buf.data_ptr() not in ptrs:
+                return buf
+        buf = torch.empty_like(ws.x_t)
+        ws.x0s.append(buf)
+        return buf
+
+    def _loop_unfused(self, ws, shape, x_in, t_model, base_flags, n_steps, model_options, seed, stopper, stream, m, y,
+                      current_times):
+        """Early stop enabled: the stopper decides after every iteration, so the POST
+        half of iteration i cannot be fused with the PRE half of iteration i+1."""
+        d = self._desc
+        args = None
+        ran = 0
+        for i in range(n_steps):
+            x_t_before = ws.x_t.clone() if args is None or stopper.has_custom_distance_fn else None
+            if i > 0:
+                d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags
+                self._set_xi(d, ws.x_t, want_pre=True, want_post=False)
+                self._launch_step(stream)
+            heads = self.unpack_model_output(self.inner_model(x_in, t_model, model_options=model_options, seed=seed))
+            x0s = self._x0s_buffer(ws, [args.x0 if args else None, stopper.x0_anchor])
+            alive = self._set_model_heads(d, heads[0], heads[1], base_flags | LP_FL_WRITE_X0S, shape)
+            d.x0s = x0s.data_ptr()
+            d.phases = LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY
+            self._set_xi(d, ws.x_t, want_pre=False)
+            self._launch_step(stream)
+            del alive
+            prev_args, args = args, LangevinState(None, ws.C, x0s)
+            ran += 1
+            ctx = {"step": i, "steps_done": i + 1, "n_steps": n_steps, "mask": m, "latent_image": y,
+                   "current_times": current_times, "seed": seed}
+            if stopper.step(i=i, n_steps=n_steps, x_t_before=x_t_before, x_t_after=ws.x_t,
+                            x_t_prev_for_custom=x_t_before if stopper.has_custom_distance_fn else None,
+                            prev_args=prev_args, args=args, ctx=ctx):
+                break
+        d.x0s = None
+        d.phases, d.flags = LP_PH_EMIT, base_flags
+        self._launch_step(stream)
+        return ran
+
+    def _loop_compat(self, ws, shape, m, y, abt, current_times, n_steps, model_options, seed, stopper):
+        """A subclass / instance overrides langevin_dynamics, score_model or
+        prepare_step_size: run the reference's per-iteration call structure
+        (lanpaint.py:113-142) so the overrides see the calls they expect."""
+        abt_b = self.add_none_dims(abt)
+        step_size = self.add_none_dims(self.step_size * (1 - abt).clamp(min=self.min_step_frac))
+        x_t, args, ran = ws.x_t, None, 0
+        for i in range(n_steps):
+            score_func = partial(self.score_model, y=y, mask=m, abt=abt_b, sigma=self.add_none_dims(current_times[0]),
+                                 tflow=self.add_none_dims(current_times[2]), model_options=model_options, seed=seed)
+            prev_args = args
+            x_prev = x_t.detach().clone() if (stopper is not None and stopper.has_custom_distance_fn) else None
+            x_before = x_t.detach().clone() if stopper is not None else None
+            x_t, args = self.langevin_dynamics(x_t, score_func, m, step_size, current_times,
+                                               sigma_x=self.add_none_dims(self.sigma_x(abt)),
+                                               sigma_y=self.add_none_dims(self.sigma_y(abt)), args=args)
+            ran += 1
+            if stopper is not None:
+                ctx = {"step": i, "steps_done": i + 1, "n_steps": n_steps, "mask": m, "latent_image": y,
+                       "current_times": current_times, "seed": seed}
+                if stopper.step(i=i, n_steps=n_steps, x_t_before=x_before, x_t_after=x_t, x_t_prev_for_custom=x_prev,
+                                prev_args=prev_args, args=args, ctx=ctx):
+                    break
+        if x_t.data_ptr() != ws.x_t.data_ptr():
+            ws.x_t.copy_(x_t)
+        return ran
+
+    def langevin_dynamics(self, x_t, score, mask, step_size, current_times, sigma_x=1, sigma_y=0, args=None):
+        """Public single-iteration entry with the reference signature (lanpaint.py:192-293):
+        `score` is any callable x_t -> score tensor.  Returns (x_t_new, LangevinState)."""
+        if args is not None and not isinstance(args, LangevinState) and isinstance(args, tuple):
+            if len(args) == 2:
+                args = LangevinState(args[0], args[1], None)
+            elif len(args) >= 3:
+                args = LangevinState(args[0], args[1], args[2])
+        if not x_t.is_cuda:
+            raise RuntimeError("lanpaint_amd.LanPaint.langevin_dynamics runs on a HIP device only; no CPU fallback")
+        if self.img_dim_size is None:
+            self.img_dim_size = x_t.ndim
+        step_sizes = self.prepare_step_size(current_times, step_size, sigma_x, sigma_y)
+        _sig, abt_b, dtx = step_sizes[0], step_sizes[1], step_sizes[2]
+        if torch.mean(dtx) <= 0.0:                                   # lanpaint.py:205
+            return x_t, args
+        lib = self._lib
+        shape, rows = x_t.shape, x_t.shape[0]
+        xt = _as_f32c(x_t).clone()
+        mk = _as_f32c(mask if mask.shape == shape else mask.expand(shape))
+        stream = self._stream(xt.device)
+        flow = bool(self.IS_FLUX or self.IS_FLOW)
+        sx = torch.as_tensor(sigma_x, dtype=torch.float32, device=xt.device)
+        sy = torch.as_tensor(sigma_y, dtype=torch.float32, device=xt.device)
+        step_t = torch.as_tensor(step_size, dtype=torch.float32, device=xt.device)
+        if sx.numel() > 1 and bool((sx != sx.reshape(-1)[0]).any()) or sy.numel() > 1 and bool((sy != sy.reshape(-1)[0]).any()):
+            raise NotImplementedError("non-uniform sigma_x / sigma_y are not supported by the HIP path")
+        sx0, sy0 = float(sx.reshape(-1)[0]), float(sy.reshape(-1)[0])
+        VE_Sigma, abt, _ft = current_times
+        d = _cabi.LpStepDesc()
+        hyp = _cabi.LpHyper()
+        hyp.lambda_, hyp.step_size, hyp.min_step_frac = float(self.chara_lamb), float(self.step_size), 0.0
+        hyp.beta = (sy0 / sx0) if sx0 != 0.0 else 0.0
+        hyp.is_flow, hyp.one_plus_lambda = int(flow), 1.0 + float(self.chara_lamb)
+        if abt.numel() not in (1, rows) or step_t.numel() not in (1, rows):
+            raise NotImplementedError("per-element times in the public langevin_dynamics are not supported; "
+                                      "use LanPaint.__call__ (audio path) instead")
+        coef = torch.empty((rows, _cabi.LP_COEF_STRIDE), dtype=torch.float32, device=xt.device)
+        ve_r, abt_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1))
+        step_r = _as_f32c((step_t * sx0).reshape(-1))
+        _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), ve_r.data_ptr(), int(ve_r.numel() > 1), abt_r.data_ptr(),
+                                  int(abt_r.numel() > 1), None, 0, step_r.data_ptr(), int(step_r.numel() > 1), rows,
+                                  coef.data_ptr(), stream), "lp_coeffs")
+        d.n_el, d.el_per_row, d.rows = xt.numel(), xt.numel() // rows, rows
+        d.lambda_, d.one_plus_lambda, d.beta = hyp.lambda_, hyp.one_plus_lambda, hyp.beta
+        d.step_size, d.min_step_frac, d.noise_scale = hyp.step_size, 0.0, 1.0
+        d.coef, d.mask, d.x_t = coef.data_ptr(), mk.data_ptr(), xt.data_ptr()
+        base = (LP_FL_FLOW if flow else 0) | LP_FL_X0S_GIVEN | LP_FL_WRITE_X0S
+        d.rng_seed = int(self.philox_seed or 0)
+        if args is None:
+            c_buf = torch.empty_like(xt)
+            d.C = c_buf.data_ptr()
+        else:
+            c_buf = _as_f32c(args.C).clone()
+            d.C = c_buf.data_ptr()
+            d.phases, d.flags = LP_PH_PRE_HALF, base                # first half-step with the old C
+            self._set_xi(d, xt, want_pre=True, want_post=False)
+            self._launch_step_desc(d, stream)
+        x0s_in = _as_f32c(xt + score(xt))                            # Coef_C: x0 = x_t + score(x_t)
+        x0s_out = torch.empty_like(xt)
+        d.x0, d.x0_big, d.x0s = x0s_in.data_ptr(), x0s_in.data_ptr(), x0s_out.data_ptr()
+        d.phases, d.flags = (LP_PH_POST_FIRST if args is None else LP_PH_POST_STEADY), base
+        self._set_xi(d, xt, want_pre=False)
+        self._launch_step_desc(d, stream)
+        return xt.to(x_t.dtype), LangevinState(None, c_buf, x0s_out)
+
+    def _launch_step_desc(self, d, stream):
+        _cabi.check(self._lib.lp_step(ctypes.byref(d), stream), "lp_step")

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The in-tree HIP extension; built on demand here, prebuilt on the GPU box."""
+    from lanpaint_amd import _cabi, build
+    if not os.path.exists(_cabi.LIB_PATH):
+        build.build(verbose=False)
+    return _cabi.load()

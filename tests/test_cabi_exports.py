@@ -1,0 +1,96 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol
+include/lanpaint_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+from lanpaint_amd import _cabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lanpaint_hip.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_functions_are_exported_and_bound(hip_lib):
+    names = _declared_functions()
+    assert {"lp_coeffs", "lp_step", "lp_finalize", "lp_philox_normal", "lp_boundary_ring", "lp_wmse_pair",
+            "lp_reshape_mask", "lp_strerror", "lp_abi_version"} <= set(names)
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in the header but not exported"
+        assert n in _cabi.EXPORTS, f"{n} has no ctypes binding"
+
+
+def test_abi_version_and_strerror(hip_lib):
+    assert hip_lib.lp_abi_version() == _cabi.ABI_VERSION
+    assert hip_lib.lp_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4, -99):
+        assert len(hip_lib.lp_strerror(code)) > 0
+
+
+def _header_constants():
+    src = open(HEADER).read()
+    out = {}
+    for name, val in re.findall(r"#define\s+(LP_[A-Z0-9_]+)\s+(\(?[-0-9a-fx u<]+\)?)", src):
+        v = val.strip("() ").replace("u", "")
+        try:
+            out[name] = eval(v)       # "1 << 3" style literals only
+        except Exception:
+            pass
+    return out
+
+
+def test_python_constants_mirror_header():
+    consts = _header_constants()
+    checked = 0
+    for name, val in consts.items():
+        if hasattr(_cabi, name):
+            assert getattr(_cabi, name) == val, name
+            checked += 1
+    assert checked >= 40
+
+
+def test_struct_layout_matches_c(tmp_path):
+    """sizeof / offsetof of the two descriptors as gcc sees them == ctypes."""
+    import subprocess
+    fields_step = [f for f, _ in _cabi.LpStepDesc._fields_]
+    fields_final = [f for f, _ in _cabi.LpFinalDesc._fields_]
+    cname = lambda f: "lambda" if f == "lambda_" else f      # noqa: E731
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "lanpaint_hip.h"', 'int main(void){',
+            'printf("%zu %zu %zu\\n", sizeof(lp_step_desc), sizeof(lp_final_desc), sizeof(lp_hyper));']
+    for f in fields_step:
+        prog.append(f'printf("%zu ", offsetof(lp_step_desc, {cname(f)}));')
+    prog.append('printf("\\n");')
+    for f in fields_final:
+        prog.append(f'printf("%zu ", offsetof(lp_final_desc, {cname(f)}));')
+    prog.append('printf("\\n"); return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+    sizes = [int(v) for v in lines[0].split()]
+    assert sizes == [ctypes.sizeof(_cabi.LpStepDesc), ctypes.sizeof(_cabi.LpFinalDesc), ctypes.sizeof(_cabi.LpHyper)]
+    assert [int(v) for v in lines[1].split()] == [getattr(_cabi.LpStepDesc, f).offset for f in fields_step]
+    assert [int(v) for v in lines[2].split()] == [getattr(_cabi.LpFinalDesc, f).offset for f in fields_final]
+
+
+def test_engine_refuses_cpu_tensors(hip_lib):
+    import pytest
+    import torch
+    from lanpaint_amd import LanPaint
+    from tests.stubs import LinearTupleModel
+    eng = LanPaint(LinearTupleModel(), 5, 15.0, 5.0, 1.0, 0.2)
+    x = torch.zeros(1, 4, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng(x, x, x + 1, torch.tensor([1.0]), x, (torch.tensor([1.0]),) * 3, None, 0)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import pytest
+    with pytest.raises(ImportError, match="no CPU / PyTorch fallback"):
+        _cabi.load(str(tmp_path / "nope.so"))

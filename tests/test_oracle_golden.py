@@ -1,0 +1,66 @@
+"""The oracle is pinned to the reference: every golden trajectory (produced by the
+unmodified reference engine, tests/golden/make_golden.py) is reproduced by the numpy
+restatement when it is fed the same xi stream."""
+import numpy as np
+import pytest
+
+from oracle.lanpaint_oracle import OracleLanPaint
+from tests import golden_cases as gc
+from tests.helpers import assert_close, load_golden, run_oracle_case, xi_list
+from tests.stubs import MODELS
+
+
+@pytest.mark.parametrize("name", sorted(gc.CASES))
+def test_oracle_matches_reference_golden(name):
+    r = run_oracle_case(name)
+    g = r["golden"]
+    assert r["leftover"] == 0, "oracle consumed a different number of xi draws than the reference"
+    assert r["model"].calls == int(g["model_calls"])
+    assert_close(r["x"], g["x_out"], f"{name}: in-place x", rel=3e-6)
+    assert_close(r["out"], g["out"], f"{name}: out", rel=3e-6)
+    if "trace_dist" in g.files:
+        tr = r["engine"].last_stopper.trace
+        assert len(tr) == len(g["trace_dist"])
+        np.testing.assert_allclose([t["dist"] for t in tr], g["trace_dist"], rtol=2e-5)
+        assert [t["counter"] for t in tr] == list(g["trace_counter"])
+        assert [t["stopped"] for t in tr] == list(g["trace_stopped"])
+
+
+@pytest.mark.parametrize("name", sorted(gc.SCHEDULES))
+def test_oracle_matches_reference_schedule(name):
+    sc = gc.build_schedule(name)
+    g = load_golden(name)
+    it = iter(xi_list(g))
+    model = MODELS[sc["model"]](flow=sc["flow"])
+    h = sc["hyper"]
+    eng = OracleLanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], is_flow=sc["flow"],
+                         min_step_frac=h["MinStepFrac"], randn=lambda like: next(it))
+    x = sc["x"].copy()
+    sig = sc["sigmas"]
+    for i in range(len(sig) - 1):
+        s = np.full((sc["shape"][0],), sig[i], dtype=np.float32)
+        den = eng(x, sc["y"], sc["noise"], s, sc["mask"], gc.times_from_sigma(s, sc["flow"]), None, 0)
+        assert_close(den, g["denoised"][i], f"{name}: denoised[{i}]", rel=2e-5)
+        x = (x + (x - den) / sig[i] * (sig[i + 1] - sig[i])).astype(np.float32)
+    assert sum(1 for _ in it) == 0
+    assert_close(x, g["x_final"], f"{name}: final x", rel=2e-5)
+
+
+def test_oracle_on_torch_backend_matches_numpy():
+    """The cpu_baseline leg runs the same oracle on torch-CPU tensors."""
+    import torch
+    from oracle.lanpaint_oracle import TorchBackend
+    name = "ve_basic"
+    case = gc.build_case(name)
+    g = load_golden(name)
+    it = iter([torch.from_numpy(d) for d in xi_list(g)])
+    model = MODELS[case["model"]]()
+    h = case["hyper"]
+    eng = OracleLanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"],
+                         min_step_frac=h["MinStepFrac"], backend=TorchBackend(), randn=lambda like: next(it))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))   # noqa: E731
+    x = t(case["x"].copy())
+    out = eng(x, t(case["y"]), t(case["noise"]), t(case["sigma"]), t(case["mask"]),
+              tuple(t(v) for v in case["times"]), None, 0)
+    assert_close(x.numpy(), g["x_out"], "torch-backend x", rel=3e-6)
+    assert_close(out.numpy(), g["out"], "torch-backend out", rel=3e-6)
