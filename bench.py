@@ -149,7 +149,7 @@ def run_gpu(args):
 
     engine = LanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
                       HYPER["StepSize"], IS_FLOW=flow, MinStepFrac=HYPER["MinStepFrac"], rng=args.rng,
-                      philox_seed=args.seed + rank)
+                      philox_seed=args.seed + rank, graph=bool(args.graph))
 
     def barrier():
         if world > 1:
@@ -200,7 +200,8 @@ def run_gpu(args):
         "config": {"workload": f"{args.workload}: latent {'x'.join(map(str, shape))} per GPU, {n_sig} sigmas x "
                                f"{n_think} think iterations, 50% box mask, stub backbone x->(0.9x,0.8x), "
                                f"{'flow' if flow else 'VE/Karras'} schedule",
-                   "rng": args.rng, "replicas": args.gpus, "iterations_per_step": n_sig * n_think,
+                   "rng": args.rng, "launch": "hipGraph replay per sigma call" if args.graph else "eager launches",
+                   "replicas": args.gpus, "iterations_per_step": n_sig * n_think,
                    "latent_elements_per_gpu": n_el, "lambda": HYPER["Lambda"], "beta": HYPER["Beta"],
                    "step_size": HYPER["StepSize"]},
         "latent_rows_x_iterations_per_s": iters_total * b / tmax,
@@ -211,47 +212,65 @@ def run_gpu(args):
 
 
 def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args):
-    """Instrumented replay of the timed region: a HIP event pair on the launch stream
-    around every steady-state lp_step (POST_STEADY|PRE_HALF|EMIT) launch."""
+    """Instrumented replay of the timed region: every steady-state lp_step launch
+    (POST_STEADY|PRE_HALF|EMIT, the dominant kernel) goes through lp_step_timed, i.e.
+    hipExtLaunchKernelGGL with a HIP start/stop event pair bound to that dispatch on the
+    launch stream -- the kernel's own begin->end time, the quantity rocprofv3
+    --kernel-trace reports (profiles/ holds the matching summary)."""
+    import ctypes
+    lib = _cabi.load()
     steady = _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT
-    events = []
+    timers, used = [], []
     orig = engine._launch_step
 
     def timed_launch(stream):
         if engine._desc.phases == steady:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            orig(stream)
-            b.record()
-            events.append((a, b))
+            if timers:
+                t = timers.pop()
+            else:
+                t = ctypes.c_void_p()
+                _cabi.check(lib.lp_timer_create(ctypes.byref(t)), "lp_timer_create")
+            _cabi.check(lib.lp_step_timed(ctypes.byref(engine._desc), stream, t), "lp_step_timed")
+            used.append(t)
         else:
             orig(stream)
 
     engine._launch_step = timed_launch
+    graph_was, engine.graph = engine.graph, False      # per-dispatch timers need individual (eager) launches
     try:
         for _ in range(max(1, min(args.steps, 3))):
             schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
         torch.cuda.synchronize()
     finally:
         engine._launch_step = orig
-    if not events:
+        engine.graph = graph_was
+    if not used:
         return None
-    durs = np.asarray([a.elapsed_time(b) for a, b in events]) * 1e-3      # seconds
+    durs = []
+    for t in used:
+        ns = ctypes.c_double()
+        _cabi.check(lib.lp_timer_elapsed_ns(t, ctypes.byref(ns)), "lp_timer_elapsed_ns")
+        durs.append(ns.value * 1e-9)
+        lib.lp_timer_destroy(t)
+    durs = np.asarray(durs)
     n_el = x0.numel()
     bytes_per_launch = BYTES_PER_EL_STEADY * n_el
     mean_s = float(durs.mean())
     achieved = bytes_per_launch / mean_s / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "lp_step_kernel<4,false> phases=POST_STEADY|PRE_HALF|EMIT",
+            "kernel": "lp::lp_step_kernel<4,false> phases=POST_STEADY|PRE_HALF|EMIT (steady-state think step)",
             "algorithmic_bytes_per_launch": bytes_per_launch, "mean_launch_us": mean_s * 1e6,
-            "median_launch_us": float(np.median(durs)) * 1e6, "launches_timed": len(events),
-            "timer": "hipEvent pair per launch on the launch stream"}
+            "median_launch_us": float(np.median(durs)) * 1e6, "min_launch_us": float(durs.min()) * 1e6,
+            "launches_timed": len(durs),
+            "timer": "hipExtLaunchKernelGGL start/stop events per dispatch (kernel begin->end) on the launch stream"}
 
 
 def cpu_baseline(workload, budget_s):
-    """The CPU oracle (port of the reference engine, same op chain on torch-CPU tensors,
-    all host threads) on the same workload, bounded to ~budget_s seconds."""
+    """The CPU oracle (port of the reference engine: the same eager op chain on torch-CPU
+    fp32 tensors) on the same workload, bounded to ~budget_s seconds.  Timed at 1 thread
+    and at min(8, host CPUs) threads (the reference's tensors are tiny: more threads only
+    add fork/join cost); the faster of the two is reported, with its thread count."""
     from oracle.lanpaint_oracle import OracleLanPaint, TorchBackend
     shape, flow, n_sig, n_think = WORKLOADS[workload]
     sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
@@ -263,18 +282,25 @@ def cpu_baseline(workload, budget_s):
     ratios = euler_ratios(sig_list, len(shape))
     eng = OracleLanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
                          HYPER["StepSize"], is_flow=flow, min_step_frac=HYPER["MinStepFrac"], backend=TorchBackend())
-    threads = torch.get_num_threads()
-    schedule_pass(eng, x0, y, noise, mask, sig_list[:3], times_list[:3], ratios[:2], n_think)      # warm-up, discarded
-    it0, t0, passes = eng.iterations_run, time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:
-        schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
-        passes += 1
-    dt = time.perf_counter() - t0
-    return {"value": (eng.iterations_run - it0) / dt, "unit": "think-iterations/s", "cores": threads,
-            "kind": "port",
-            "sample": f"{passes} full passes of the {workload} schedule ({n_sig} sigmas x {n_think}) in {dt:.1f} s; "
-                      f"oracle/lanpaint_oracle.py on torch-CPU fp32 tensors ({threads} threads of "
-                      f"{os.cpu_count()} host CPUs)"}
+    saved = torch.get_num_threads()
+    results = []
+    try:
+        for threads in sorted({1, min(8, os.cpu_count() or 1)}):
+            torch.set_num_threads(threads)
+            schedule_pass(eng, x0, y, noise, mask, sig_list[:3], times_list[:3], ratios[:2], n_think)   # warm-up
+            it0, t0, passes = eng.iterations_run, time.perf_counter(), 0
+            while time.perf_counter() - t0 < budget_s / 2:
+                schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+                passes += 1
+            dt = time.perf_counter() - t0
+            results.append(((eng.iterations_run - it0) / dt, threads, passes, dt))
+    finally:
+        torch.set_num_threads(saved)
+    best = max(results)
+    detail = "; ".join(f"{t} thread(s): {v:.1f} it/s over {p} passes in {d:.1f} s" for v, t, p, d in results)
+    return {"value": best[0], "unit": "think-iterations/s", "cores": best[1], "kind": "port",
+            "sample": f"full passes of the {workload} schedule ({n_sig} sigmas x {n_think}) with "
+                      f"oracle/lanpaint_oracle.py on torch-CPU fp32 tensors, {os.cpu_count()} host CPUs; {detail}"}
 
 
 def main():
@@ -284,6 +310,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2_sdxl", choices=sorted(WORKLOADS))
     ap.add_argument("--rng", default="philox", choices=["philox", "torch"])
+    ap.add_argument("--graph", type=int, default=1, help="1: replay each sigma call as one hipGraph (default); 0: eager launches")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

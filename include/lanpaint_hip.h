@@ -180,6 +180,16 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
  *           :144-147 / :163 / :168 (EMIT).                                     */
 int lp_step(const lp_step_desc* desc, void* stream);
 
+/* Measurement hooks (bench.py roofline leg): lp_step_timed launches exactly like
+ * lp_step but through hipExtLaunchKernelGGL with a start/stop event pair bound to the
+ * dispatch itself, so lp_timer_elapsed_ns returns the kernel's own begin->end time
+ * (what rocprofv3 --kernel-trace reports), not a host-side interval.  The timer is a
+ * caller-owned handle; lp_timer_elapsed_ns blocks until that launch has finished.     */
+int lp_timer_create(void** timer);
+int lp_timer_destroy(void* timer);
+int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);
+int lp_timer_elapsed_ns(void* timer, double* ns);
+
 /* K3  finalise: known-region reprojection + in-place write-back.
  * Replaces: lanpaint.py:154,156.                                               */
 int lp_finalize(const lp_final_desc* desc, void* stream);

@@ -4,7 +4,10 @@
 #include "lp_common.h"
 
 namespace lp {
-int step_dispatch(const lp_step_desc* d, hipStream_t stream);
+int step_dispatch(const lp_step_desc* d, hipStream_t stream, void* timer);
+int timer_create(void** out);
+int timer_destroy(void* h);
+int timer_elapsed_ns(void* h, double* ns);
 int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const float* abt, int abt_stride,
                     const float* rs, int rs_stride, const float* step_ov, int step_stride, int rows, float* table,
                     hipStream_t stream);
@@ -41,7 +44,15 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
                                step_stride, rows, coef_table, as_stream(stream));
 }
 
-int lp_step(const lp_step_desc* desc, void* stream) { return lp::step_dispatch(desc, as_stream(stream)); }
+int lp_step(const lp_step_desc* desc, void* stream) { return lp::step_dispatch(desc, as_stream(stream), nullptr); }
+
+int lp_timer_create(void** timer) { return lp::timer_create(timer); }
+int lp_timer_destroy(void* timer) { return lp::timer_destroy(timer); }
+int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer) {
+    if (!timer) return LP_E_INVALID;
+    return lp::step_dispatch(desc, as_stream(stream), timer);
+}
+int lp_timer_elapsed_ns(void* timer, double* ns) { return lp::timer_elapsed_ns(timer, ns); }
 
 int lp_finalize(const lp_final_desc* desc, void* stream) { return lp::finalize_dispatch(desc, as_stream(stream)); }
 

@@ -1,6 +1,7 @@
 // lp_common.h -- device helpers shared by the gfx950 kernels (wave64, CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "lanpaint_hip.h"

@@ -320,8 +320,12 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     }
 }
 
+struct Timer {
+    hipEvent_t start, stop;
+};
+
 template <int VEC, bool PER_EL>
-static hipError_t launch(const lp_step_desc& d, hipStream_t stream) {
+static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer = nullptr) {
     const int64_t groups = d.el_per_row / VEC;
     // small problems: 64-thread blocks spread single waves over all 256 CUs (latency bound);
     // large ones: 256-thread blocks, capped near 8 blocks/CU, grid-stride the rest.
@@ -331,14 +335,20 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream) {
     const int64_t cap = (2048 + d.rows - 1) / d.rows;
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL((lp_step_kernel<VEC, PER_EL>), dim3(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows)),
-                       dim3(block), 0, stream, d);
+    const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
+    if (timer) {
+        hipExtLaunchKernelGGL((lp_step_kernel<VEC, PER_EL>), grid, dim3(block), 0, stream, timer->start, timer->stop,
+                              0, d);
+    } else {
+        hipLaunchKernelGGL((lp_step_kernel<VEC, PER_EL>), grid, dim3(block), 0, stream, d);
+    }
     return hipGetLastError();
 }
 
 static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-int step_dispatch(const lp_step_desc* dp, hipStream_t stream) {
+int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle) {
+    Timer* timer = static_cast<Timer*>(timer_handle);
     if (!dp) return LP_E_INVALID;
     const lp_step_desc& d = *dp;
     if (d.n_el <= 0 || d.rows <= 0 || d.el_per_row <= 0 || d.n_el != d.el_per_row * d.rows) return LP_E_INVALID;
@@ -381,11 +391,41 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream) {
                       aligned(d.ve_el, f_al) && aligned(d.rsig_el, f_al) && aligned(d.corr_el, f_al);
     hipError_t err;
     if (vec4) {
-        err = per_el ? launch<4, true>(d, stream) : launch<4, false>(d, stream);
+        err = per_el ? launch<4, true>(d, stream, timer) : launch<4, false>(d, stream, timer);
     } else {
-        err = per_el ? launch<1, true>(d, stream) : launch<1, false>(d, stream);
+        err = per_el ? launch<1, true>(d, stream, timer) : launch<1, false>(d, stream, timer);
     }
     return err == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+int timer_create(void** out) {
+    if (!out) return LP_E_INVALID;
+    Timer* t = new Timer();
+    if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) {
+        delete t;
+        return LP_E_LAUNCH;
+    }
+    *out = t;
+    return LP_OK;
+}
+
+int timer_destroy(void* h) {
+    if (!h) return LP_E_INVALID;
+    Timer* t = static_cast<Timer*>(h);
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+    return LP_OK;
+}
+
+int timer_elapsed_ns(void* h, double* ns) {
+    if (!h || !ns) return LP_E_INVALID;
+    Timer* t = static_cast<Timer*>(h);
+    if (hipEventSynchronize(t->stop) != hipSuccess) return LP_E_LAUNCH;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t->start, t->stop) != hipSuccess) return LP_E_LAUNCH;
+    *ns = static_cast<double>(ms) * 1e6;
+    return LP_OK;
 }
 
 }  // namespace lp

@@ -74,18 +74,37 @@ class _Workspace:
         return self.shape == tuple(like.shape) and self.device == like.device
 
 
+class _CapturedCall:
+    """One sigma call captured as a hipGraph: static inputs [x, sigma, VE, abt, flow_t],
+    static output, the device-side Philox counter the captured launches read."""
+
+    def __init__(self, static_in, counter):
+        self.graph = torch.cuda.CUDAGraph()
+        self.static_in = static_in
+        self.counter = counter
+        self.out = None
+        self.ran = 0
+        self.keep = None
+
+
 class LanPaint:
     # ------------------------------------------------------------------ construction
     def __init__(self, Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX=False, IS_FLOW=False,
                  EarlyStopThreshold=0.0, EarlyStopPatience=1, EarlyStopHook=None, MinStepFrac=0.0,
-                 *, rng=None, philox_seed=None):
+                 *, rng=None, philox_seed=None, graph=None):
         """Positional signature == reference lanpaint.py:8.  Keyword-only extras:
         rng: "torch" (default; xi = torch.randn_like in the reference's draw order, so a
              seeded run consumes the device generator exactly like the reference),
              "philox" (xi generated inside the fused kernel, nothing read from HBM),
              or a callable `rng(like) -> Tensor` (tests feed recorded streams).
              Env LANPAINT_AMD_RNG overrides the default.
-        philox_seed: Philox key; defaults to the `seed` argument of each call."""
+        philox_seed: Philox key; defaults to the `seed` argument of each call.
+        graph: capture each sigma call (coeffs, replace, N x [backbone, fused step], final
+             backbone call, finalise) into ONE hipGraph and replay it (the loop is launch
+             bound at image-latent sizes).  Needs a capturable backbone (static shapes, no
+             host sync); rng "torch"/"philox" only; ignored (eager launches) when the inner
+             early stop, per-element times or method overrides are in play.
+             Env LANPAINT_AMD_GRAPH=1 turns it on by default."""
         self.n_steps = NSteps
         self.chara_lamb = Lambda
         self.IS_FLUX = IS_FLUX
@@ -105,6 +124,11 @@ class LanPaint:
             raise ValueError(f"rng must be 'torch', 'philox' or a callable, got {self.rng!r}")
         self.philox_seed = philox_seed
         self._philox_offset = 0
+        self.graph = bool(int(os.environ.get("LANPAINT_AMD_GRAPH", "0"))) if graph is None else bool(graph)
+        self._graphs = {}                        # key -> _CapturedCall
+        self._rng_counters = {}                  # device -> u64 counter read by captured Philox launches
+        self._capturing = None                   # device u64 Philox counter while capturing
+        self._cap_offset = 0
         self._lib = _cabi.load()                 # raises if the HIP extension is not built
         self._ws = None
         self._desc = _cabi.LpStepDesc()
@@ -255,16 +279,78 @@ class LanPaint:
         self.audio_indicator = audio_indicator
         self.current_times_audio = current_times_audio
         self.audio_correction = audio_correction
-        if self._noise_is_zero(noise):
-            self.noise = torch.randn_like(noise)
+        if self._noise_is_zero(noise):           # lanpaint.py:51-52: the first draw of the call
+            self.noise = self.rng(noise) if callable(self.rng) else torch.randn_like(noise)
         if n_steps is None:
             n_steps = self.n_steps
+        run = self._call_graphed if self._graph_eligible(x, model_options) else self.LanPaint
         if x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):
-                return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX,
-                                     self.IS_FLOW)
-        return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX,
-                             self.IS_FLOW)
+                return run(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX,
+                           self.IS_FLOW)
+        return run(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX, self.IS_FLOW)
+
+    # ------------------------------------------------------------------ hipGraph replay of one sigma call
+    def _graph_eligible(self, x, model_options):
+        if not self.graph or callable(self.rng):
+            return False
+        if self.audio_indicator is not None or self.audio_correction is not None:
+            return False
+        if self.early_stop_threshold > 0.0 and self.early_stop_patience > 0:
+            return False
+        if isinstance(model_options, dict) and isinstance(model_options.get("lanpaint_semantic_stop"), dict):
+            return False
+        if self._overridden("langevin_dynamics") or self._overridden("score_model") or \
+                self._overridden("prepare_step_size"):
+            return False
+        return x.dtype == torch.float32
+
+    def _call_graphed(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
+        """Stage the per-call inputs into the captured call's static buffers, replay, hand
+        back a fresh `out` and the in-place-updated x (same contract as the eager path)."""
+        key = (tuple(x.shape), x.device.index, int(n_steps), bool(IS_FLUX), bool(IS_FLOW), self.latent_image.data_ptr(),
+               self.noise.data_ptr(), latent_mask.data_ptr(), tuple(sigma.shape), tuple(tuple(t.shape) for t in current_times),
+               id(model_options), seed, self.rng)
+        cap = self._graphs.get(key)
+        srcs = [x, sigma, current_times[0], current_times[1], current_times[2]]
+        if cap is None:
+            cap = self._capture(key, srcs, latent_mask, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+        torch._foreach_copy_(cap.static_in, srcs)
+        cap.graph.replay()
+        x.copy_(cap.static_in[0])
+        self.iterations_run += cap.ran
+        self.last_inner_steps = cap.ran
+        return cap.out.clone()
+
+    def _capture(self, key, srcs, latent_mask, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
+        dev = srcs[0].device
+        static_in = [t.detach().clone().contiguous() for t in srcs]
+        counter = self._rng_counters.get(dev)      # ONE Philox launch-sequence base per device, shared by
+        if counter is None:                        # every captured call so their streams never overlap
+            counter = self._rng_counters[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+        cap = _CapturedCall(static_in, counter)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        it0 = self.iterations_run
+        rng_state = torch.cuda.get_rng_state(dev)   # warm-up + capture must not consume the user's torch stream
+        with torch.cuda.stream(side):              # one eager run on the side stream: lazy inits, workspace
+            x_s, sig_s, t_s = static_in[0], static_in[1], tuple(static_in[2:5])
+            self.LanPaint(x_s.clone(), sig_s, latent_mask, t_s, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.iterations_run = it0
+        self._capturing, self._cap_offset = counter, 0
+        try:
+            with torch.cuda.graph(cap.graph, stream=side):
+                cap.out = self.LanPaint(x_s, sig_s, latent_mask, t_s, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+        finally:
+            self._capturing = None
+        torch.cuda.set_rng_state(rng_state, dev)
+        cap.ran = self.iterations_run - it0
+        self.iterations_run = it0
+        cap.keep, self._ws = self._ws, None      # the captured call owns that workspace (pointers are baked in)
+        self._graphs[key] = cap
+        return cap
 
     def LanPaint(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
         """lanpaint.py:56-157."""
@@ -404,7 +490,10 @@ class LanPaint:
                    LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0)
         f.model_out, f.y, f.mask = out_model.data_ptr(), y.data_ptr(), m.data_ptr()
         f.x_src, f.x_dst, f.out = x_in.data_ptr(), xc.data_ptr(), out.data_ptr()
-        f.rng_bump_ptr, f.rng_bump = None, 0
+        if self._capturing is not None and self.rng == "philox":
+            f.rng_bump_ptr, f.rng_bump = self._capturing.data_ptr(), self._cap_offset
+        else:
+            f.rng_bump_ptr, f.rng_bump = None, 0
         _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
         if xc is not input_x:
             input_x.copy_(xc)
@@ -417,8 +506,12 @@ class LanPaint:
         PRE half-step of iteration i+1 (lanpaint.py:277,280,283)."""
         if self.rng == "philox":
             d.xi_post = d.xi_pre = None
-            d.rng_offset = self._philox_offset
-            self._philox_offset += 1
+            if self._capturing is not None:      # replayed launches: base comes from the device counter
+                d.rng_offset, d.rng_offset_ptr = self._cap_offset, self._capturing.data_ptr()
+                self._cap_offset += 1
+            else:
+                d.rng_offset, d.rng_offset_ptr = (1 << 48) + self._philox_offset, None   # disjoint from replayed ones
+                self._philox_offset += 1
             self._xi_alive = None
             return
         xa = self._draw(like) if want_post else None
@@ -533,20 +626,28 @@ class LanPaint:
         hyp.lambda_, hyp.step_size, hyp.min_step_frac = float(self.chara_lamb), float(self.step_size), 0.0
         hyp.beta = (sy0 / sx0) if sx0 != 0.0 else 0.0
         hyp.is_flow, hyp.one_plus_lambda = int(flow), 1.0 + float(self.chara_lamb)
-        if abt.numel() not in (1, rows) or step_t.numel() not in (1, rows):
-            raise NotImplementedError("per-element times in the public langevin_dynamics are not supported; "
-                                      "use LanPaint.__call__ (audio path) instead")
-        coef = torch.empty((rows, _cabi.LP_COEF_STRIDE), dtype=torch.float32, device=xt.device)
-        ve_r, abt_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1))
-        step_r = _as_f32c((step_t * sx0).reshape(-1))
-        _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), ve_r.data_ptr(), int(ve_r.numel() > 1), abt_r.data_ptr(),
-                                  int(abt_r.numel() > 1), None, 0, step_r.data_ptr(), int(step_r.numel() > 1), rows,
-                                  coef.data_ptr(), stream), "lp_coeffs")
+        base = (LP_FL_FLOW if flow else 0) | LP_FL_X0S_GIVEN | LP_FL_WRITE_X0S
         d.n_el, d.el_per_row, d.rows = xt.numel(), xt.numel() // rows, rows
         d.lambda_, d.one_plus_lambda, d.beta = hyp.lambda_, hyp.one_plus_lambda, hyp.beta
-        d.step_size, d.min_step_frac, d.noise_scale = hyp.step_size, 0.0, 1.0
-        d.coef, d.mask, d.x_t = coef.data_ptr(), mk.data_ptr(), xt.data_ptr()
-        base = (LP_FL_FLOW if flow else 0) | LP_FL_X0S_GIVEN | LP_FL_WRITE_X0S
+        d.noise_scale = 1.0
+        d.mask, d.x_t = mk.data_ptr(), xt.data_ptr()
+        if abt.numel() not in (1, rows) or step_t.numel() not in (1, rows):
+            # per-element times (AV packs): the kernel derives the step from abt itself,
+            # StepSize*max(1-abt, MinStepFrac) -- what the engine passes as `step_size` here
+            base |= LP_FL_PER_ELEMENT
+            abt_el = _as_f32c(self.add_none_dims(abt).expand(shape))
+            ve_el = _as_f32c(self.add_none_dims(VE_Sigma).expand(shape))
+            d.abt_el, d.ve_el, d.coef = abt_el.data_ptr(), ve_el.data_ptr(), None
+            d.step_size, d.min_step_frac = float(self.step_size) * sx0, float(self.min_step_frac)
+        else:
+            coef = torch.empty((rows, _cabi.LP_COEF_STRIDE), dtype=torch.float32, device=xt.device)
+            ve_r, abt_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1))
+            step_r = _as_f32c((step_t * sx0).reshape(-1))
+            _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), ve_r.data_ptr(), int(ve_r.numel() > 1), abt_r.data_ptr(),
+                                      int(abt_r.numel() > 1), None, 0, step_r.data_ptr(), int(step_r.numel() > 1), rows,
+                                      coef.data_ptr(), stream), "lp_coeffs")
+            d.step_size, d.min_step_frac = hyp.step_size, 0.0
+            d.coef = coef.data_ptr()
         d.rng_seed = int(self.philox_seed or 0)
         if args is None:
             c_buf = torch.empty_like(xt)

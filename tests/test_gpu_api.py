@@ -1,0 +1,361 @@
+"""The reference's own unit tests, re-run against lanpaint_amd on the GPU (same stubs, same
+assertions): tests/test_sho_regression.py, test_lanpaint_semantic_stop.py, test_av_schedule.py,
+test_reshape_mask.py, test_videomask.py:475-713 -- plus the KSamplerX0Inpaint sampler callable."""
+import types
+
+import numpy as np
+import pytest
+
+from oracle import lanpaint_oracle as orc
+from tests import golden_cases as gc
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    import torch
+    assert torch.cuda.is_available()
+
+
+class _DummySampling:
+    noise_scale = 1.0
+
+    def noise_scaling(self, sigma, noise, latent_image, max_denoise=False):
+        return latent_image + noise * sigma
+
+
+class _FlowSampling:
+    noise_scale = 1.0
+
+    def noise_scaling(self, sigma, noise, latent_image, max_denoise=False):
+        assert sigma.numel() == 1, "noise_scaling requires a scalar sigma"
+        return sigma * (self.noise_scale * noise) + (1.0 - sigma) * latent_image
+
+
+class _DummyModel:
+    def __init__(self, sampling=None):
+        self.inner_model = self
+        self.model_sampling = sampling or _DummySampling()
+        self.last_input = None
+        self.model_type = "EPS"
+        self.calls = 0
+
+    def __call__(self, x, sigma, model_options=None, seed=None):
+        self.last_input = x
+        self.calls += 1
+        return x, x
+
+
+def _engine(model=None, n_steps=1, **kw):
+    from lanpaint_amd import LanPaint
+    return LanPaint(model or _DummyModel(), NSteps=n_steps, Friction=15.0, Lambda=1.0, Beta=1.0, StepSize=0.2, **kw)
+
+
+def T(*a, **k):
+    import torch
+    return torch.tensor(*a, device=DEV, **k)
+
+
+# ---- reference tests/test_sho_regression.py:6-33 -------------------------------------------
+def test_langevin_dynamics_uses_first_order_scheme():
+    import torch
+    from unittest.mock import MagicMock
+    from lanpaint_amd import LanPaint
+    torch.manual_seed(0)
+    lp = LanPaint(Model=MagicMock(), NSteps=10, Friction=1.0, Lambda=1.0, Beta=1.0, StepSize=0.1)
+    x_t = torch.randn(1, 4, 8, 8, device=DEV)
+    lp.img_dim_size = 4
+    mask = torch.zeros_like(x_t)
+    score = lambda x: torch.zeros_like(x)   # noqa: E731
+    current_times = (T([0.5]), T([0.5]), T([0.5]))
+    x_out, args_out = lp.langevin_dynamics(x_t, score, mask, T([0.1]), current_times, sigma_y=1.0)
+    assert hasattr(args_out, "v") and hasattr(args_out, "C") and hasattr(args_out, "x0")
+    assert args_out.v is None
+    assert args_out[1] is args_out.C and args_out[2] is args_out.x0
+    assert torch.isfinite(x_out).all()
+    # second call consumes the state (steady scheme) and legacy 2-/3-tuples are accepted
+    x2, st2 = lp.langevin_dynamics(x_out, score, mask, T([0.1]), current_times, sigma_y=1.0, args=args_out)
+    x3, st3 = lp.langevin_dynamics(x_out, score, mask, T([0.1]), current_times, sigma_y=1.0, args=(None, args_out.C))
+    assert torch.isfinite(x2).all() and torch.isfinite(x3).all() and st3.v is None
+
+
+def test_langevin_dynamics_matches_oracle_iteration():
+    """Public per-iteration entry vs the oracle's think_iteration with an arbitrary score."""
+    import torch
+    rng = np.random.default_rng(0)
+    shape = (2, 4, 6, 6)
+    xt = rng.standard_normal(shape, dtype=np.float32)
+    mask = gc.box_mask(shape)
+    abt = np.float32([0.3, 0.7])
+    ve = np.sqrt((1 - abt) / abt).astype(np.float32)
+    step = (0.2 * (1 - abt)).astype(np.float32)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(3)]
+    score_np = lambda x: (0.5 - x) * 0.7   # noqa: E731
+
+    it = iter(draws)
+    o = orc.OracleLanPaint(None, 1, 15.0, 5.0, 1.0, 0.2, randn=lambda like: next(it))
+    o.ndim = 4
+    b = lambda a: a.reshape(-1, 1, 1, 1)   # noqa: E731
+    one = np.ones_like(b(abt))
+    x1, s1 = o.think_iteration(xt, score_np, mask, b(step), (ve, abt, ve), one, one, None)
+    x2, s2 = o.think_iteration(x1, score_np, mask, b(step), (ve, abt, ve), one, one, s1)
+
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)   # noqa: E731
+    it2 = iter([tt(d) for d in draws])
+    from lanpaint_amd import LanPaint
+    eng = LanPaint(None, 1, 15.0, 5.0, 1.0, 0.2, rng=lambda like: next(it2))
+    eng.img_dim_size = 4
+    times = (tt(ve), tt(abt), tt(ve))
+    g1, st1 = eng.langevin_dynamics(tt(xt), lambda x: (0.5 - x) * 0.7, tt(mask), tt(b(step)), times,
+                                    sigma_x=tt(one), sigma_y=tt(one), args=None)
+    g2, st2 = eng.langevin_dynamics(g1, lambda x: (0.5 - x) * 0.7, tt(mask), tt(b(step)), times,
+                                    sigma_x=tt(one), sigma_y=tt(one), args=st1)
+    assert_close(g1.cpu().numpy(), x1, "iteration 0 x_t")
+    assert_close(st1.C.cpu().numpy(), s1.C, "iteration 0 C", rel=5e-5)
+    assert_close(g2.cpu().numpy(), x2, "iteration 1 x_t")
+    assert_close(st2.x0.cpu().numpy(), s2.x0, "iteration 1 x0")
+
+
+# ---- reference tests/test_lanpaint_semantic_stop.py:31-104 ---------------------------------
+def _stop_inputs():
+    import torch
+    x = torch.zeros((1, 4, 8, 8), device=DEV)
+    sigma = T([1.0])
+    return x, torch.zeros_like(x), torch.ones_like(x), sigma, torch.zeros_like(x), (sigma, T([0.5]), T([0.0]))
+
+
+@pytest.mark.parametrize("mask_all_known,patience,expected", [(False, 2, 3), (True, 1, 10)])
+def test_semantic_stop_with_overridden_langevin(mask_all_known, patience, expected):
+    import torch
+    engine = _engine(n_steps=10)
+    calls = {"langevin": 0, "with_score": 0}
+
+    def fake_langevin(x_t, score, mask, step_size, current_times, sigma_x=1, sigma_y=0, args=None):
+        calls["langevin"] += 1
+        calls["with_score"] += score is not None
+        return x_t, args
+
+    engine.langevin_dynamics = fake_langevin
+    mo = {"lanpaint_semantic_stop": {"threshold": 1e-6, "patience": patience}}
+    x, latent, noise, sigma, mask, times = _stop_inputs()
+    if mask_all_known:
+        mask = torch.ones_like(mask)
+    engine(x, latent, noise, sigma, mask, times, model_options=mo, seed=0, n_steps=10)
+    assert calls["langevin"] == expected and calls["with_score"] == expected
+
+
+# ---- reference tests/test_av_schedule.py:157-324 ---------------------------------------------
+def _flat_pack():
+    import torch
+    x = torch.zeros(1, 1, 8, device=DEV)
+    ai = torch.zeros(1, 1, 8, device=DEV)
+    ai[..., 5:] = 1.0
+    return (x, torch.zeros_like(x), torch.ones_like(x), T([0.5]), torch.zeros_like(x), (T([1.0]), T([0.5]), T([0.5])),
+            (T([0.25]), T([0.9]), T([0.2])), ai)
+
+
+def test_audio_rows_get_audio_schedule_parameters():
+    import torch
+    engine = _engine(_DummyModel(_FlowSampling()))
+    cap = {}
+
+    def fake_prepare_step_size(current_times, step_size, sigma_x, sigma_y):
+        cap["abt"], cap["step_size"] = current_times[1], step_size
+        abt = current_times[1]
+        ones, z = torch.ones_like(abt), torch.zeros_like(abt)
+        return (current_times[0], abt, ones, ones, ones, ones, z, z, z, z)
+
+    engine.prepare_step_size = fake_prepare_step_size
+    x, latent, noise, sigma, mask, times, times_a, ai = _flat_pack()
+    engine(x, latent, noise, sigma, mask, times, model_options=None, seed=0, n_steps=1, current_times_audio=times_a,
+           audio_indicator=ai)
+    abt, step = cap["abt"].flatten(), cap["step_size"].flatten()
+    assert float(abt[0]) == 0.5 and float(abt[-1]) == pytest.approx(0.9)
+    assert float(step[0]) == pytest.approx(0.2 * 0.5) and float(step[-1]) == pytest.approx(0.2 * 0.1)
+    cap.clear()
+    engine(x, latent, noise, sigma, mask, times, model_options=None, seed=0, n_steps=1)
+    assert float(cap["abt"].flatten()[0]) == 0.5 and float(cap["abt"].flatten()[-1]) == 0.5
+
+
+def test_replace_step_uses_audio_sigma_for_audio_rows():
+    import torch
+    engine = _engine(_DummyModel(_FlowSampling()), n_steps=0)
+    x, latent, noise, sigma, _, times, times_a, ai = _flat_pack()
+    engine(x, latent, noise, sigma, torch.ones_like(x), times, model_options=None, seed=0, n_steps=0,
+           current_times_audio=times_a, audio_indicator=ai)
+    inp = engine.inner_model.last_input.flatten()
+    assert float(inp[0]) == pytest.approx(0.5) and float(inp[-1]) == pytest.approx(0.2)
+
+
+def test_score_model_audio_correction_and_flat_target():
+    import torch
+    from lanpaint_amd import LanPaint
+
+    class Offset(_DummyModel):
+        def __call__(self, x, sigma, model_options=None, seed=None):
+            return x + 2.0, x + 2.0
+
+    engine = LanPaint(Offset(_FlowSampling()), NSteps=1, Friction=15.0, Lambda=1.0, Beta=1.0, StepSize=0.2, IS_FLOW=True)
+    engine.img_dim_size = 3
+    ai = torch.zeros(1, 1, 8, device=DEV)
+    ai[..., 5:] = 1.0
+    z = torch.zeros(1, 1, 8, device=DEV)
+    abt, sig = torch.full((1, 1, 8), 0.5, device=DEV), torch.ones(1, 1, 8, device=DEV)
+    tflow = engine.add_none_dims(T([0.5]))
+    s = engine.score_model(z, z, z, abt, sig, tflow, model_options=None, seed=0).flatten()
+    assert float(s[0]) == pytest.approx(2.0) and float(s[-1]) == pytest.approx(2.0)
+    engine.audio_indicator, engine.audio_correction = ai, (1.0 - ai) + 0.625 * ai
+    s = engine.score_model(z, z, z, abt, sig, tflow, model_options=None, seed=0).flatten()
+    assert float(s[0]) == pytest.approx(2.0) and float(s[-1]) == pytest.approx(1.25)
+
+
+def test_add_none_dims_and_prepare_step_size_per_row():
+    import torch
+    engine = _engine()
+    for nd in (3, 4, 5):
+        engine.img_dim_size = nd
+        assert tuple(engine.add_none_dims(torch.zeros(1)).shape) == (1,) + (1,) * (nd - 1)
+        assert tuple(engine.add_none_dims(torch.zeros(())).shape) == (1,) * nd
+    engine.img_dim_size = 3
+    assert tuple(engine.add_none_dims(torch.zeros(1, 1, 8)).shape) == (1, 1, 8)
+    abt = torch.full((1, 1, 8), 0.5)
+    abt[..., 5:] = 0.9
+    step = torch.full((1, 1, 8), 0.1)
+    step[..., 5:] = 0.02
+    one = torch.ones(1, 1, 8)
+    out = engine.prepare_step_size((one, abt, one), step, one, one)
+    assert all(t.ndim == 3 for t in out) and len(out) == 10
+    adt = (out[6] * out[2]).flatten()
+    assert float(adt[0]) == pytest.approx(0.2) and float(adt[-1]) == pytest.approx(0.2)
+
+
+def test_model_output_forms_and_empty_output_error():
+    engine = _engine()
+    a, b = object(), object()
+    assert engine.unpack_model_output((a, b, 3)) == (a, b)
+    assert engine.unpack_model_output([a]) == (a, a)
+    assert engine.unpack_model_output(a) == (a, a)
+    with pytest.raises(ValueError, match="Model output is empty"):
+        engine.unpack_model_output(())
+
+
+# ---- reference tests/test_reshape_mask.py + tests/test_videomask.py:475-713, on the HIP kernel --------
+def test_reshape_mask_reference_kats():
+    import torch
+    from lanpaint_amd.nodes import prepare_mask, reshape_mask
+    z = lambda *s: torch.zeros(*s)   # noqa: E731   (CPU inputs, like ComfyUI hands them over)
+    assert tuple(reshape_mask(z(1, 4, 4), (1, 16, 1, 8, 8)).shape) == (1, 16, 1, 8, 8)
+    out = prepare_mask(z(4, 4), (2, 3, 8, 8), device=torch.device("cuda"))
+    assert tuple(out.shape) == (2, 3, 8, 8) and out.device.type == "cuda"
+    m = z(8, 8, 8)
+    m[2, 5, 5], m[6, 7, 7] = 1.0, 1.0
+    out = reshape_mask(m, (1, 16, 2, 4, 4), video_inpainting=True)
+    assert tuple(out.shape) == (1, 16, 2, 4, 4)
+    assert out[0, 0, 0].max() == 1.0 and out[0, 0, 1].max() == 1.0
+    assert out[0, 0, 0, 2, 2] == 1.0 and out[0, 0, 1, 3, 3] == 1.0
+    m = z(8, 8, 8)
+    m[3, 5, 5] = 1.0
+    assert reshape_mask(m, (1, 16, 2, 4, 4), video_inpainting=True).max() == 0.0
+    m = z(3, 8, 8)
+    m[1, 5, 5] = 1.0
+    assert reshape_mask(m, (1, 16, 1, 4, 4), video_inpainting=True).max() == 1.0
+    m = z(16, 4, 4)
+    m[6, 1, 1] = 1.0
+    out = reshape_mask(m, (1, 24, 4, 4, 4), video_inpainting=True)
+    assert out[0, 0, 0].max() == 1.0 and out[0, 0, 3].max() == 1.0
+    m = z(124, 864, 480)
+    m[62, 100:140, 100:140] = 1.0
+    out = reshape_mask(m, (1, 24, 37, 30, 54), video_inpainting=True)
+    assert tuple(out.shape) == (1, 24, 37, 30, 54) and out.max() == 1.0 and (out == 0.0).float().mean() > 0.8
+    m4 = z(124, 1, 864, 480)
+    m4[62, 0, 100:140, 100:140] = 1.0
+    assert torch.equal(reshape_mask(m4, (1, 24, 37, 30, 54), video_inpainting=True), out)
+    assert reshape_mask(torch.ones(1, 6, 8), (1, 24, 37, 3, 4), video_inpainting=True).min() == 1.0
+    assert reshape_mask(torch.ones(4, 6, 8), (1, 4, 6, 8)).max() == 1.0
+    a = z(100)
+    a[50:60] = 1.0
+    out = reshape_mask(a, (1, 32, 2, 40))
+    assert tuple(out.shape) == (1, 32, 2, 40) and (out == 0.0).float().mean() > 0.7
+    assert out[0, 0, 0, 20] == 1.0 and out[0, 0, 1, 20] == 1.0
+    out = reshape_mask(a.reshape(1, 1, 100, 1), (1, 32, 2, 40))
+    assert out[0, 0, 0, 20] == 1.0 and out[0, 0, 1, 20] == 1.0
+    m = z(8, 1, 6, 8)
+    m[2, 0, 2, 3], m[6, 0, 4, 5] = 1.0, 1.0
+    out = reshape_mask(m, (1, 24, 2, 6, 8), video_inpainting=True)
+    assert out[0, 0, 0, 2, 3] == 1.0 and out[0, 0, 1, 4, 5] == 1.0
+
+
+def test_reshape_mask_equals_torch_interpolate_pipeline():
+    """Property check vs the exact torch ops the reference calls, on random sizes."""
+    import torch
+    from lanpaint_amd.nodes import reshape_mask
+    rng = np.random.default_rng(5)
+    for _ in range(12):
+        f, h, w = (int(v) for v in rng.integers(1, 40, 3))
+        tf, th, tw = (int(v) for v in rng.integers(1, 24, 3))
+        m = torch.from_numpy((rng.random((f, h, w)) > 0.6).astype(np.float32))
+        got = reshape_mask(m, (2, 3, tf, th, tw), video_inpainting=True).cpu()
+        t = torch.nn.functional.interpolate(m[None, None], size=(tf, th, tw), mode="nearest-exact")
+        t = torch.nn.functional.max_pool3d(t, kernel_size=(5, 1, 1), stride=(1, 1, 1), padding=(2, 0, 0))
+        assert torch.equal(got, t.repeat(2, 3, 1, 1, 1)), (f, h, w, tf, th, tw)
+        got2 = reshape_mask(m, (1, 2, th, tw)).cpu()                     # 3-D mask = batch of images
+        t2 = torch.nn.functional.interpolate(m[:, None], size=(th, tw), mode="nearest-exact").repeat(1, 2, 1, 1)[:1]
+        assert torch.equal(got2, t2)
+
+
+# ---- KSamplerX0Inpaint: the sampler-facing callable ----------------------------------------------
+@pytest.mark.parametrize("flow", [False, True])
+def test_ksampler_x0_inpaint_matches_oracle(flow):
+    import torch
+    from lanpaint_amd import LanPaint
+    from lanpaint_amd import nodes
+    shape = (1, 4, 8, 8)
+    sig = gc.flow_sigmas(5) if flow else gc.karras_sigmas(5, 0.1, 10.0)
+    rng = np.random.default_rng(9)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    denoise_mask = (rng.random(shape) > 0.5).astype(np.float32) * 0.9      # non-binary input, thresholded at 0.5
+    latent_mask = orc.binarize_and_invert(denoise_mask)
+    x0 = (sig[0] * noise + (1 - sig[0]) * y) if flow else (y + noise * sig[0])
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(64)]
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+
+    class M(_DummyModel):
+        def __call__(self, x, sigma, model_options=None, seed=None):
+            self.calls += 1
+            return 0.9 * x, 0.8 * x
+
+    model = M(_FlowSampling() if flow else _DummySampling())
+    model.model_type = nodes.ModelType.FLOW if flow else "EPS"
+    it = iter([tt(d) for d in draws])
+    k = nodes.KSamplerX0Inpaint(model, tt(sig))
+    k.latent_image, k.noise = tt(y), tt(noise)
+    k.PaintMethod = LanPaint(model, 4, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, MinStepFrac=0.5, rng=lambda like: next(it))
+    k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 0.5
+
+    it_o = iter(draws)
+    omodel = M()
+    o = orc.OracleLanPaint(omodel, 4, 15.0, 5.0, 1.0, 0.2, is_flow=flow, min_step_frac=0.5, randn=lambda like: next(it_o))
+    x, xo = tt(x0), x0.astype(np.float32).copy()
+    n_effs = []
+    for i in range(len(sig) - 1):
+        s = np.float32([sig[i]])
+        den = k(x, tt(s), tt(denoise_mask), model_options={}, seed=0)
+        times = orc.times_from_sigma(s, flow)
+        n_eff = orc.effective_inner_steps(4, sig, float(s[0]), float(times[1].mean()), 1, 0.5)
+        n_effs.append(n_eff)
+        assert k.PaintMethod.last_inner_steps == n_eff
+        den_o = o(xo, y, noise, s, latent_mask, times, None, 0, n_steps=n_eff)
+        assert_close(den.cpu().numpy(), den_o, f"sigma[{i}] denoised", rel=5e-5)
+        r = float((sig[i + 1] - sig[i]) / sig[i])
+        x = x + (x - den) * r
+        xo = (xo + (xo - den_o) * np.float32(r)).astype(np.float32)
+    assert n_effs[-1] == 0 and max(n_effs) == 4          # EarlyStop=1 tail and the un-ramped head both exercised
+    assert_close(x.cpu().numpy(), xo, "final x", rel=5e-5)
+    assert model.calls == omodel.calls
+    # no-mask path: plain model call (nodes.py:302)
+    out = k(x, tt(np.float32([sig[0]])), None, model_options={}, seed=0)
+    assert torch.equal(out, 0.9 * x)

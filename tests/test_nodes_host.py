@@ -1,0 +1,138 @@
+"""Host-side logic of the ComfyUI-facing layer, with ComfyUI stubbed the way the reference's
+own tests stub it (tests/test_reshape_mask.py:18-54).  Mirrors reference tests
+test_min_step_frac.py, test_node_params.py and the override restore semantics."""
+import importlib
+import sys
+import types
+
+import pytest
+
+RETIRED = ["LanPaint_Beta", "LanPaint_Friction", "LanPaint_EarlyStop", "LanPaint_InnerThreshold",
+           "LanPaint_InnerPatience", "LanPaint_MinStepFrac"]
+
+
+@pytest.fixture()
+def nodes(monkeypatch, hip_lib):
+    comfy_mod = types.ModuleType("comfy")
+    comfy_mod.__path__ = []
+    samplers = types.ModuleType("comfy.samplers")
+
+    class _KSAMPLER:
+        def sample(self, *a, **k):
+            return "orig_sample"
+
+    class _CFGGuider:
+        def outer_sample(self, *a, **k):
+            return "orig_outer"
+
+        def predict_noise(self, *a, **k):
+            return "orig_predict"
+
+    class _KSampler:
+        SCHEDULERS = ["normal", "karras"]
+
+    samplers.KSAMPLER, samplers.CFGGuider, samplers.KSampler = _KSAMPLER, _CFGGuider, _KSampler
+    model_base = types.ModuleType("comfy.model_base")
+    model_base.ModelType = types.SimpleNamespace(FLUX="FLUX", FLOW="FLOW")
+    model_base.WAN22 = type("WAN22", (), {})
+    helpers = types.ModuleType("comfy.sampler_helpers")
+    helpers.prepare_mask = lambda noise_mask, shape, device: "orig_prepare_mask"
+    ver = types.ModuleType("comfyui_version")
+    ver.__version__ = "0.6.0"
+    comfy_mod.samplers, comfy_mod.model_base, comfy_mod.sampler_helpers = samplers, model_base, helpers
+    for name, mod in (("comfy", comfy_mod), ("comfy.samplers", samplers), ("comfy.model_base", model_base),
+                      ("comfy.sampler_helpers", helpers), ("comfyui_version", ver)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    sys.modules.pop("lanpaint_amd.nodes", None)
+    mod = importlib.import_module("lanpaint_amd.nodes")
+    yield mod
+    sys.modules.pop("lanpaint_amd.nodes", None)
+
+
+def test_min_step_frac_effective_steps(nodes):
+    f = nodes.min_step_frac_effective_steps
+    assert f(5, 0.1, 0.0) == 5 and f(5, 0.01, 0.0) == 5
+    assert f(5, 0.2, 0.05) == 5 and f(5, 0.05, 0.05) == 5
+    assert f(5, 0.04, 0.05) == 4 and f(5, 0.025, 0.05) == 2 and f(5, 0.005, 0.05) == 0 and f(5, 0.0, 0.05) == 0
+    assert f(0, 0.01, 0.05) == 0
+
+
+def test_retired_params_hidden_and_widgets_kept(nodes):
+    for cls in (nodes.LanPaint_KSampler, nodes.LanPaint_KSamplerAdvanced, nodes.LanPaint_SamplerCustom,
+                nodes.LanPaint_SamplerCustomAdvanced):
+        req = cls.INPUT_TYPES().get("required", {})
+        for name in RETIRED:
+            assert name not in req
+        assert cls.FUNCTION == "sample" and "LATENT" in cls.RETURN_TYPES
+    assert set(nodes.LanPaint_KSamplerAdvanced.INPUT_TYPES()["hidden"]) >= set(RETIRED)
+    assert set(nodes.LanPaint_SamplerCustomAdvanced.INPUT_TYPES()["hidden"]) >= set(RETIRED)
+    assert "LanPaint_MinStepFrac" in nodes.LanPaint_KSampler.INPUT_TYPES()["hidden"]
+    req = nodes.LanPaint_KSamplerAdvanced.INPUT_TYPES()["required"]
+    for name in ("LanPaint_NumSteps", "LanPaint_Lambda", "LanPaint_StepSize", "LanPaint_PromptMode", "LanPaint_Info",
+                 "Inpainting_mode"):
+        assert name in req
+    assert set(nodes.NODE_CLASS_MAPPINGS) == {"LanPaint_KSampler", "LanPaint_KSamplerAdvanced", "LanPaint_SamplerCustom",
+                                              "LanPaint_SamplerCustomAdvanced"}
+    assert nodes.LanPaint_KSampler.INPUT_TYPES()["required"]["LanPaint_NumSteps"][1]["default"] == 5
+
+
+def test_sanitize_param(nodes):
+    s = nodes._sanitize_param
+    allowed = ("Image First", "Prompt First")
+    assert s("Image First", "Image First", allowed=allowed) == "Image First"
+    assert s("Prompt First", "Image First", allowed=allowed) == "Prompt First"
+    assert s(1.0, "Image First", allowed=allowed) == "Image First"
+    assert s("bogus", "Image First", allowed=allowed) == "Image First"
+    assert s(None, "Image First", allowed=allowed) == "Image First"
+    assert s(5, 5) == 5 and s(3.7, 0.2) == 3.7 and s("abc", 0.2) == 0.2 and s(None, 0.2) == 0.2 and s(True, 5) == 5
+
+
+def test_pinned_hyperparams_match_reference_defaults(nodes):
+    m = types.SimpleNamespace()
+    nodes._pin_hyperparams(m, 7.5, 5, "Image First")
+    assert (m.LanPaint_StepSize, m.LanPaint_Lambda, m.LanPaint_Beta, m.LanPaint_NumSteps) == (0.2, 5.0, 1.0, 5)
+    assert (m.LanPaint_MinStepFrac, m.LanPaint_Friction, m.LanPaint_EarlyStop) == (1.0, 15.0, 1)
+    assert (m.LanPaint_InnerThreshold, m.LanPaint_InnerPatience, m.LanPaint_cfg_BIG) == (0.0, 1, 7.5)
+    nodes._pin_hyperparams(m, 7.5, 3, "Prompt First", lamb=8.0, step_size=0.15)
+    assert m.LanPaint_cfg_BIG == -0.5 and m.LanPaint_Lambda == 8.0 and m.LanPaint_StepSize == 0.15
+
+
+def test_override_sample_function_patches_and_restores(nodes):
+    import comfy
+    g, k, h = comfy.samplers.CFGGuider, comfy.samplers.KSAMPLER, comfy.sampler_helpers
+    orig = (g.outer_sample, g.predict_noise, k.sample, h.prepare_mask)
+    with nodes.override_sample_function():
+        assert g.outer_sample is nodes.CFGGuider_LanPaint.outer_sample
+        assert g.predict_noise is nodes.CFGGuider_LanPaint.predict_noise
+        assert k.sample is nodes.KSAMPLER.sample
+        assert h.prepare_mask is not orig[3]
+        with nodes.override_sample_function():           # nested entry must not capture the patches as originals
+            assert k.sample is nodes.KSAMPLER.sample
+        assert k.sample is nodes.KSAMPLER.sample
+    assert (g.outer_sample, g.predict_noise, k.sample, h.prepare_mask) == orig
+    with pytest.raises(ValueError):
+        with nodes.override_sample_function():
+            raise ValueError("boom")
+    assert (g.outer_sample, g.predict_noise, k.sample, h.prepare_mask) == orig     # restored in `finally`
+
+
+def test_detect_minimax_h3_audio(nodes):
+    class DM:
+        sigma_shift_video, sigma_shift_audio = 12.0, 3.0
+    patcher = types.SimpleNamespace(model=types.SimpleNamespace(diffusion_model=DM()))
+    shapes = [(1, 24, 37, 30, 54), (1, 32, 2, 207)]
+    assert nodes._detect_minimax_h3_audio(patcher, {}, shapes[:1]) is None
+    assert nodes._detect_minimax_h3_audio(patcher, {}, None) is None
+    assert nodes._detect_minimax_h3_audio(types.SimpleNamespace(model=object()), {}, shapes) is None
+    assert nodes._detect_minimax_h3_audio(patcher, {}, shapes) == (shapes, 12.0, 3.0)
+    opts = {"transformer_options": {"minimax_h3_sigma_shift_video": 10.0, "minimax_h3_sigma_shift_audio": 2.5}}
+    assert nodes._detect_minimax_h3_audio(patcher, opts, shapes) == (shapes, 10.0, 2.5)
+    assert nodes.time_shift_sigma is None
+
+
+def test_reshape_mask_refuses_without_hip(nodes):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("HIP device present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nodes.reshape_mask(torch.zeros(4, 4), (1, 4, 8, 8))
