@@ -121,26 +121,24 @@ def schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_th
 def run_gpu(args):
     import torch.distributed as dist
     from lanpaint_amd import LanPaint, _cabi
+    from lanpaint_amd import distributed as lpd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = lpd.env_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # backend "nccl" IS RCCL on ROCm
+    lpd.init("nccl", dev)                               # backend "nccl" IS RCCL on ROCm; no-op at world size 1
 
     shape, flow, n_sig, n_think = WORKLOADS[args.workload]
     sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
-    x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed + rank, dev, tt)
-    if world > 1:      # all replicas inpaint the same image with the same mask: one RCCL broadcast at setup
-        dist.broadcast(mask, src=0)
-        dist.broadcast(y, src=0)
+    x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), lpd.replica_seed(args.seed, rank), dev, tt)
+    if world > 1:      # all replicas inpaint the same image with the same mask: ONE packed RCCL broadcast at setup
+        job = lpd.broadcast_job({"mask": mask, "y": y} if rank == 0 else None, src=0, device=dev)
+        mask, y = job["mask"], job["y"]
         x0 = (float(sig_np[0]) * noise + (1 - float(sig_np[0])) * y) if flow else (y + noise * float(sig_np[0]))
     b = shape[0]
     sig_list = [torch.full((b,), float(s), dtype=torch.float32, device=dev) for s in sig_np]
@@ -149,7 +147,7 @@ def run_gpu(args):
 
     engine = LanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
                       HYPER["StepSize"], IS_FLOW=flow, MinStepFrac=HYPER["MinStepFrac"], rng=args.rng,
-                      philox_seed=args.seed + rank, graph=bool(args.graph))
+                      philox_seed=lpd.replica_seed(args.seed, rank), graph=bool(args.graph))
 
     def barrier():
         if world > 1:
@@ -168,17 +166,14 @@ def run_gpu(args):
     iters_local = engine.iterations_run - it0
     assert torch.isfinite(x_last).all(), "bench produced non-finite latents"
 
-    tmax, iters_total = elapsed, iters_local
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        n = torch.tensor([iters_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        tmax, iters_total = float(t.item()), int(n.item())
+    tmax, iters_total = lpd.reduce_throughput(elapsed, iters_local, dev)
 
     roofline = None
     if rank == 0:
         roofline = measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args)
+    large = None
+    if rank == 0 and world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
+        large = measure_hbm_bound_shape(_cabi, dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_seconds)
@@ -206,9 +201,26 @@ def run_gpu(args):
                    "step_size": HYPER["StepSize"]},
         "latent_rows_x_iterations_per_s": iters_total * b / tmax,
         "roofline": roofline,
+        "roofline_hbm_bound_shape": large,
         "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
+
+
+def pmc_traffic(workload):
+    """HBM-side bytes per steady-state launch measured with rocprofv3 PMC counters (FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 x2 read correction) -- a committed measurement
+    (profiles/r*_pmc_traffic.json, produced by scripts/gpu_profile.sh), not something bench.py can
+    collect on itself.  None when no profile covers this workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        entry = json.load(open(files[-1])).get(workload)
+        return int(entry["traffic_bytes_per_launch"]) if entry else None
+    except Exception:
+        return None
 
 
 def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args):
@@ -258,12 +270,85 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
     mean_s = float(durs.mean())
     achieved = bytes_per_launch / mean_s / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "lp::lp_step_kernel<4,false> phases=POST_STEADY|PRE_HALF|EMIT (steady-state think step)",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
+            "kernel": "lp::lp_step_kernel<VEC,false,POST_STEADY|PRE_HALF|EMIT> (steady-state think step; "
+                      "VEC=1 up to 512K elements, VEC=4 above)",
             "algorithmic_bytes_per_launch": bytes_per_launch, "mean_launch_us": mean_s * 1e6,
             "median_launch_us": float(np.median(durs)) * 1e6, "min_launch_us": float(durs.min()) * 1e6,
             "launches_timed": len(durs),
             "timer": "hipExtLaunchKernelGGL start/stop events per dispatch (kernel begin->end) on the launch stream"}
+
+
+def standalone_step(_cabi, workload, dev, phase=None):
+    """A self-contained steady-state lp_step launch on synthetic buffers of `workload`'s shape
+    (used for the HBM-bound supplementary roofline and by scripts/microbench_step.py)."""
+    import ctypes
+    lib = _cabi.load()
+    shape, flow, _, _ = WORKLOADS[workload]
+    n_el, rows = int(np.prod(shape)), shape[0]
+    g = torch.Generator(device=dev).manual_seed(0)
+    bufs = {k: torch.randn(shape, device=dev, generator=g) for k in ("x", "y", "noise", "x_t", "C", "x0", "x0b", "x_in")}
+    mask = torch.zeros(shape, device=dev)
+    mask[..., : shape[-1] // 2] = 1.0
+    h = _cabi.LpHyper()
+    h.lambda_, h.beta, h.step_size, h.min_step_frac = HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"], 0.0
+    h.is_flow, h.one_plus_lambda = int(flow), 1.0 + HYPER["Lambda"]
+    sig = torch.full((rows,), 0.7 if flow else 1.5, device=dev)
+    ve, abt, _ = times_from_sigma(sig, flow)
+    coef = torch.empty((rows, _cabi.LP_COEF_STRIDE), device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _cabi.check(lib.lp_coeffs(ctypes.byref(h), ve.data_ptr(), 1, abt.data_ptr(), 1, sig.data_ptr(), 1, None, 0, rows,
+                              coef.data_ptr(), st))
+    d = _cabi.LpStepDesc()
+    d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
+    d.phases = phase or (_cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT)
+    d.flags = _cabi.LP_FL_FLOW if flow else 0
+    d.replace_kind, d.lambda_, d.one_plus_lambda, d.beta = _cabi.LP_REPLACE_VE, h.lambda_, h.one_plus_lambda, h.beta
+    d.step_size, d.noise_scale = h.step_size, 1.0
+    d.coef, d.x, d.noise, d.y, d.mask = (coef.data_ptr(), bufs["x"].data_ptr(), bufs["noise"].data_ptr(),
+                                         bufs["y"].data_ptr(), mask.data_ptr())
+    d.x_t, d.C, d.x0, d.x0_big, d.x_in = (bufs[k].data_ptr() for k in ("x_t", "C", "x0", "x0b", "x_in"))
+    d.rng_seed = 1
+    keep = (bufs, mask, coef, sig, ve, abt)
+    return d, keep, n_el
+
+
+def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
+    """Supplementary evidence: the same steady-state kernel on the video-latent shape (75 MB of
+    algorithmic traffic per launch -- the regime where the kernel is bandwidth bound, not launch
+    bound), launched back to back through lp_step_timed."""
+    import ctypes
+    lib = _cabi.load()
+    d, keep, n_el = standalone_step(_cabi, workload, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for k in range(10):
+        d.rng_offset = k
+        _cabi.check(lib.lp_step(ctypes.byref(d), st))
+    timers = []
+    for k in range(launches):
+        t = ctypes.c_void_p()
+        _cabi.check(lib.lp_timer_create(ctypes.byref(t)))
+        d.rng_offset = 100 + k
+        _cabi.check(lib.lp_step_timed(ctypes.byref(d), st, t))
+        timers.append(t)
+    torch.cuda.synchronize(dev)
+    durs = []
+    for t in timers:
+        ns = ctypes.c_double()
+        _cabi.check(lib.lp_timer_elapsed_ns(t, ctypes.byref(ns)))
+        durs.append(ns.value * 1e-9)
+        lib.lp_timer_destroy(t)
+    durs = np.asarray(durs)
+    bytes_per_launch = BYTES_PER_EL_STEADY * n_el
+    achieved = bytes_per_launch / float(durs.mean()) / 1e9
+    shape = WORKLOADS[workload][0]
+    del keep
+    return {"workload": f"{workload}: latent {'x'.join(map(str, shape))}, steady-state lp_step back to back",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "frac_of_measured_copy_peak_6290": achieved / 6290.0, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "traffic": pmc_traffic(workload),
+            "mean_launch_us": float(durs.mean()) * 1e6, "min_launch_us": float(durs.min()) * 1e6,
+            "launches_timed": int(durs.size)}
 
 
 def cpu_baseline(workload, budget_s):
@@ -314,6 +399,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")
     args = ap.parse_args()
     run_gpu(args)
 

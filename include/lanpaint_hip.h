@@ -190,13 +190,28 @@ int lp_timer_destroy(void* timer);
 int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);
 int lp_timer_elapsed_ns(void* timer, double* ns);
 
+/* Staging for hipGraph replay: up to LP_COPY_MAX independent fp32 copies in ONE launch
+ * (the sampler's x, sigma and the three time tensors into a captured call's static
+ * buffers; its x / out back out).  src_stride 0 broadcasts element 0.                  */
+#define LP_COPY_MAX 6
+typedef struct lp_copy_desc {
+    int32_t      n;                       /* number of copies                    */
+    int32_t      reserved0;
+    int64_t      count[LP_COPY_MAX];      /* elements written per copy           */
+    int32_t      src_stride[LP_COPY_MAX]; /* 1 = dense, 0 = broadcast element 0  */
+    const float* src[LP_COPY_MAX];
+    float*       dst[LP_COPY_MAX];
+} lp_copy_desc;
+int lp_copy_batch(const lp_copy_desc* desc, void* stream);
+
 /* K3  finalise: known-region reprojection + in-place write-back.
  * Replaces: lanpaint.py:154,156.                                               */
 int lp_finalize(const lp_final_desc* desc, void* stream);
 
-/* Standalone N(0,1) fill with the same Philox4x32-10 + Box-Muller the fused
- * kernel uses (slot 0 = POST stream, 1 = PRE stream) -- lets tests reproduce
- * the in-kernel noise exactly.  Replaces torch.randn_like (lanpaint.py:252).  */
+/* Standalone N(0,1) fill with the generator the fused kernel uses: Philox2x32-10, one
+ * block per latent element keyed on (seed, element, launch offset), Box-Muller; slot 0 =
+ * cosine branch (POST stream), 1 = sine branch (PRE stream).  Lets tests reproduce the
+ * in-kernel noise exactly.  Replaces torch.randn_like (lanpaint.py:252).               */
 int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream);
 
 /* K4  inner early-stop metric (earlystop.py:32-55).

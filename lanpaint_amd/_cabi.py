@@ -58,6 +58,15 @@ class LpFinalDesc(C.Structure):
     ]
 
 
+LP_COPY_MAX = 6
+
+
+class LpCopyDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved0", C.c_int32), ("count", C.c_int64 * LP_COPY_MAX),
+                ("src_stride", C.c_int32 * LP_COPY_MAX), ("src", C.c_void_p * LP_COPY_MAX),
+                ("dst", C.c_void_p * LP_COPY_MAX)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "lp_abi_version": (C.c_int, []),
@@ -66,6 +75,7 @@ EXPORTS = {
                             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lp_step": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p]),
     "lp_finalize": (C.c_int, [C.POINTER(LpFinalDesc), C.c_void_p]),
+    "lp_copy_batch": (C.c_int, [C.POINTER(LpCopyDesc), C.c_void_p]),
     "lp_timer_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "lp_timer_destroy": (C.c_int, [C.c_void_p]),
     "lp_step_timed": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.c_void_p]),

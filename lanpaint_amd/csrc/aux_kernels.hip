@@ -88,6 +88,44 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
 }
 
 // ---------------------------------------------------------------------------------
+// batched staging copy (graph replay): blockIdx.y selects the copy
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lp_copy_batch_kernel(const lp_copy_desc d) {
+    const int a = blockIdx.y;
+    const int64_t n = d.count[a];
+    const float* __restrict__ src = d.src[a];
+    float* __restrict__ dst = d.dst[a];
+    const int64_t stride = d.src_stride[a];
+    const bool vec = stride == 1 && (n % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    if (vec) {
+        for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n / 4;
+             q += static_cast<int64_t>(gridDim.x) * blockDim.x)
+            reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(src)[q];
+    } else {
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+             i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+            dst[i] = src[i * stride];
+    }
+}
+
+int copy_batch_dispatch(const lp_copy_desc* dp, hipStream_t stream) {
+    if (!dp || dp->n <= 0 || dp->n > LP_COPY_MAX) return LP_E_INVALID;
+    int64_t max_n = 0;
+    for (int a = 0; a < dp->n; ++a) {
+        if (!dp->src[a] || !dp->dst[a] || dp->count[a] <= 0) return LP_E_INVALID;
+        if (dp->src_stride[a] != 0 && dp->src_stride[a] != 1) return LP_E_INVALID;
+        if (dp->count[a] > max_n) max_n = dp->count[a];
+    }
+    int64_t bx = (max_n / 4 + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(lp_copy_batch_kernel, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(dp->n)), dim3(256), 0,
+                       stream, *dp);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------
 // K3: out = model_out*(1-m) + y*m ; x_dst <- x_src      (lanpaint.py:154,156)
 // ---------------------------------------------------------------------------------
 template <int VEC>
@@ -137,25 +175,24 @@ int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------
-// standalone Philox fill: element e <- normal4(e >> 2)[e & 3]
+// standalone fill with the fused kernel's generator: element e of launch `offset` gets the
+// cosine (slot 0, POST stream) or sine (slot 1, PRE stream) branch of its Box-Muller pair
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lp_philox_kernel(float* __restrict__ out, int64_t n_el, uint64_t seed,
                                                         uint64_t offset, uint32_t slot) {
-    const int64_t quads = (n_el + 3) / 4;
-    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < quads;
-         q += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        float z[4];
-        normal4(static_cast<uint64_t>(q), offset, slot, seed, z);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (q * 4 + k < n_el) out[q * 4 + k] = z[k];
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n_el;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float za, zb;
+        normal_pair(static_cast<uint64_t>(e), offset, seed, za, zb);
+        out[e] = slot ? zb : za;
     }
 }
 
 int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream) {
     if (!out || n_el <= 0) return LP_E_INVALID;
-    int64_t bx = ((n_el + 3) / 4 + 255) / 256;
-    if (bx > 2048) bx = 2048;
+    if (slot > 1) return LP_E_INVALID;
+    int64_t bx = (n_el + 255) / 256;
+    if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(lp_philox_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, out, n_el, seed,
                        offset, slot);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;

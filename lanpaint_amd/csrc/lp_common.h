@@ -10,23 +10,26 @@ namespace lp {
 
 constexpr int kWave = 64;   // CDNA wavefront width; hard-coded per the gfx950 programming guide
 
-// ---- Philox4x32-10 (Salmon et al. 2011) -------------------------------------
-// Counter-based: one call -> 4 x u32, keyed on (seed), indexed by
-// (element quad, launch sequence number, draw slot).  No state is carried, so the
-// stream is independent of grid shape, vector width and block size.
-struct u32x4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
-    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+// ---- Philox2x32-10 (Salmon et al. 2011, Random123) ---------------------------------
+// Counter-based, ONE block per latent element: counter = (element index, launch sequence
+// number), key = seed folded with the high words.  The two 32-bit outputs make one
+// Box-Muller pair whose cosine branch feeds the POST half-step and whose sine branch feeds
+// the PRE half-step of the same launch.  No state is carried and the mapping is per
+// element, so the stream is independent of grid shape, vector width and block size.
+__device__ __forceinline__ void philox2x32_10(uint32_t& c0, uint32_t& c1, uint32_t key) {
+    constexpr uint32_t M = 0xD256D193u, W = 0x9E3779B9u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-        c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-        k0 += W0;
-        k1 += W1;
+        const uint32_t hi = __umulhi(M, c0), lo = M * c0;
+        c0 = hi ^ key ^ c1;
+        c1 = lo;
+        key += W;
     }
-    return c;
+}
+
+__host__ __device__ __forceinline__ uint32_t philox_key(uint64_t seed, uint64_t seq, uint64_t elem) {
+    return static_cast<uint32_t>(seed) ^ (static_cast<uint32_t>(seed >> 32) * 0x85EBCA6Bu) ^
+           (static_cast<uint32_t>(seq >> 32) * 0xC2B2AE35u) ^ (static_cast<uint32_t>(elem >> 32) * 0x27D4EB2Fu);
 }
 
 // u32 -> uniform in (0, 1]: (x + 0.5) * 2^-32 (never 0, so log is finite).
@@ -34,21 +37,15 @@ __device__ __forceinline__ float u01(uint32_t x) {
     return fmaf(static_cast<float>(x), 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
-// 4 standard normals from one Philox block (two Box-Muller pairs).  v_sin_f32 /
+// Two independent standard normals for element `elem` of launch `seq`.  v_sin_f32 /
 // v_cos_f32 take their argument in revolutions, which is exactly 2*pi*u.
-__device__ __forceinline__ void normal4(uint64_t quad, uint64_t seq, uint32_t slot, uint64_t seed, float (&z)[4]) {
-    // 44 bits of quad index (2^46 elements) and 52 bits of launch sequence share the
-    // 128-bit counter with the slot, so distinct (quad, seq, slot) never collide.
-    const u32x4 ctr{static_cast<uint32_t>(quad), static_cast<uint32_t>(seq),
-                    static_cast<uint32_t>(seq >> 32) | (static_cast<uint32_t>(quad >> 32) << 20), slot};
-    const u32x4 r = philox4x32_10(ctr, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
-    const float r1 = sqrtf(-2.0f * __logf(u01(r.x)));
-    const float r2 = sqrtf(-2.0f * __logf(u01(r.z)));
-    const float t1 = u01(r.y), t2 = u01(r.w);
-    z[0] = r1 * __builtin_amdgcn_cosf(t1);
-    z[1] = r1 * __builtin_amdgcn_sinf(t1);
-    z[2] = r2 * __builtin_amdgcn_cosf(t2);
-    z[3] = r2 * __builtin_amdgcn_sinf(t2);
+__device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_t seed, float& z_post, float& z_pre) {
+    uint32_t c0 = static_cast<uint32_t>(elem), c1 = static_cast<uint32_t>(seq);
+    philox2x32_10(c0, c1, philox_key(seed, seq, elem));
+    const float r = sqrtf(-2.0f * __logf(u01(c0)));
+    const float t = u01(c1);
+    z_post = r * __builtin_amdgcn_cosf(t);
+    z_pre = r * __builtin_amdgcn_sinf(t);
 }
 
 // ---- 16/32-bit float conversions ----------------------------------------------

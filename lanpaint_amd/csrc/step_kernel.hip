@@ -1,11 +1,16 @@
 // step_kernel.hip -- the fused Langevin "think" step for gfx950 (CDNA4, wave64).
 //
 // One launch = [everything after backbone call i] + [everything before call i+1],
-// one pass over the latent: 16 B/lane coalesced loads straight HBM -> VGPR -> HBM
-// (no element is reused inside the pass, so an LDS stage would only add latency;
-// LDS is used where there IS reuse: the mask-edge stencil in aux_kernels.hip).
-// blockIdx.y = batch row, so the per-row coefficient table lands in SGPRs via
-// scalar loads and the binary-mask path needs no transcendental per element.
+// one pass over the latent, straight HBM -> VGPR -> HBM with coalesced loads (no element
+// is reused inside the pass, so an LDS stage would only add latency; LDS is used where
+// there IS reuse: the mask-edge stencil in aux_kernels.hip).
+//   - blockIdx.y = batch row: the per-row coefficient table lands in SGPRs via scalar
+//     loads, and with a binary mask no transcendental is evaluated per element.
+//   - the hot phase combinations are compile-time specialisations (PH), so every load of
+//     the launch is issued up front and the Philox / Box-Muller arithmetic runs while they
+//     are in flight; PH = 0 is the generic kernel that reads the phases at run time.
+//   - VEC = 4 (16 B/lane) streams large latents; VEC = 1 spreads a small latent over 4x
+//     more waves so that all four SIMDs of every CU work on the (latency-bound) launch.
 //
 // Math restated from the reference (file:line = /root/reference/src/LanPaint/):
 //   replace + VP rescale        lanpaint.py:94-99
@@ -13,6 +18,8 @@
 //   exact OU step + noise       lanpaint.py:232-254
 //   overdamped scheme           lanpaint.py:274-286 (second half-step uses the OLD C)
 //   back to model space         lanpaint.py:144-147, 163, 168
+#include <cstdlib>
+
 #include "lp_common.h"
 
 namespace lp {
@@ -67,7 +74,7 @@ __device__ __forceinline__ ElemCoef elem_from_times(float abt, float ve, float m
     const float step = step_size * fmaxf(oma, min_step_frac);        // lanpaint.py:81
     const float dtx2 = 2.0f * step * 1.0f, dty2 = 2.0f * step * beta;  // :300-301 (sigma_x = 1, sigma_y = beta)
     const float atx = (1.0f / oma) * dtx2 / 2.0f;                     // :315
-    const float aty = (opl / oma) * dty2 / 2.0f;                // :316
+    const float aty = (opl / oma) * dty2 / 2.0f;                      // :316
     const float ax = atx / (dtx2 / 2.0f), ay = aty / (dty2 / 2.0f);   // :319-320
     const float dxy = sqrtf(2.0f);                                    // :326-327
     const float om = 1.0f - m;
@@ -99,11 +106,18 @@ __device__ __forceinline__ float ou_general(float x, float tau, float a, float c
     return mean + xi * sqrtf(fmaxf(var, 0.0f));
 }
 
-template <int VEC, bool PER_EL>
+constexpr uint32_t kPost = LP_PH_POST_FIRST | LP_PH_POST_STEADY;
+constexpr uint32_t kTouchXt = LP_PH_REPLACE | kPost | LP_PH_PRE_HALF;
+
+template <int VEC, bool PER_EL, uint32_t PH>
 __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     const int row = blockIdx.y;
-    const uint32_t ph = d.phases, fl = d.flags;
+    const uint32_t ph = PH ? PH : d.phases;          // compile-time for the hot combinations
+    const uint32_t fl = d.flags;
     const bool flow = fl & LP_FL_FLOW;
+    const bool post = ph & kPost;
+    const bool given = fl & LP_FL_X0S_GIVEN;
+    const bool has_corr = d.corr_el != nullptr && !given;
     const int x0dt = x0_dtype(fl), xindt = xin_dtype(fl);
     const int64_t groups = d.el_per_row / VEC;
     const int64_t row_base = static_cast<int64_t>(row) * d.el_per_row;
@@ -114,40 +128,63 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 
     uint64_t seq = d.rng_offset;
     if (d.rng_offset_ptr) seq += *d.rng_offset_ptr;
+    const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
+    const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
 
     for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < groups;
          g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int64_t i = row_base + g * VEC;
 
-        float m[VEC], xt[VEC], yv[VEC];
+        // ---- issue every load of this launch before any arithmetic ---------------------
+        float m[VEC], xt[VEC], yv[VEC], cv[VEC], x0[VEC], x0b[VEC], xi_a[VEC], xi_b[VEC], corr[VEC];
+        float xv[VEC], kn[VEC], nv[VEC], rs[VEC], abt_e[VEC], ve_e[VEC];
         load_mask<VEC>(d.mask, fl, i, m);
-
-        float abt_e[VEC], ve_e[VEC];
         if constexpr (PER_EL) {
             load_f32<VEC>(d.abt_el, i, abt_e);
             if (!flow) load_f32<VEC>(d.ve_el, i, ve_e);
         }
-
-        // ---- REPLACE: x = x(1-m) + known*m ; x_t = VP(x) ------------------------
         if (ph & LP_PH_REPLACE) {
-            float xv[VEC], kn[VEC];
             load_f32<VEC>(d.x, i, xv);
             if (d.replace_kind == LP_REPLACE_KNOWN) {
                 load_f32<VEC>(d.known, i, kn);
             } else {
-                float nv[VEC], rs[VEC];
                 load_f32<VEC>(d.noise, i, nv);
                 load_f32<VEC>(d.y, i, yv);
-                if constexpr (PER_EL) {
-                    load_f32<VEC>(d.rsig_el, i, rs);
-                } else {
+                if constexpr (PER_EL) load_f32<VEC>(d.rsig_el, i, rs);
+            }
+        } else {
+            load_f32<VEC>(d.x_t, i, xt);
+        }
+        if ((ph & LP_PH_POST_STEADY) || ((ph & LP_PH_PRE_HALF) && !post)) load_f32<VEC>(d.C, i, cv);
+        if (post) {
+            load_any<VEC>(d.x0, x0dt, i, x0);
+            if (!(d.x0_big == d.x0 || given)) load_any<VEC>(d.x0_big, x0dt, i, x0b);
+            if (!given) load_f32<VEC>(d.y, i, yv);
+            if (host_post) load_f32<VEC>(d.xi_post, i, xi_a);
+            if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
+        }
+        if ((ph & LP_PH_PRE_HALF) && host_pre) load_f32<VEC>(d.xi_pre, i, xi_b);
+
+        // ---- Philox + Box-Muller while the loads are in flight ----------------------------
+        if (need_rng) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) rs[k] = rc.rsigma;
+            for (int k = 0; k < VEC; ++k) {
+                float za, zb;
+                normal_pair(static_cast<uint64_t>(i + k), seq, d.rng_seed, za, zb);
+                if (!host_post) xi_a[k] = za;
+                if (!host_pre) xi_b[k] = zb;
+            }
+        }
+
+        // ---- REPLACE: x = x(1-m) + known*m ; x_t = VP(x) -----------------------------------
+        if (ph & LP_PH_REPLACE) {
+            if (d.replace_kind != LP_REPLACE_KNOWN) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float r = PER_EL ? rs[k] : rc.rsigma;
+                    kn[k] = (d.replace_kind == LP_REPLACE_VE) ? (yv[k] + nv[k] * r)
+                                                              : (r * (d.noise_scale * nv[k]) + (1.0f - r) * yv[k]);
                 }
-#pragma unroll
-                for (int k = 0; k < VEC; ++k)
-                    kn[k] = (d.replace_kind == LP_REPLACE_VE) ? (yv[k] + nv[k] * rs[k])
-                                                              : (rs[k] * (d.noise_scale * nv[k]) + (1.0f - rs[k]) * yv[k]);
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
@@ -160,61 +197,23 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                 }
                 xt[k] = flow ? xr * sc : xr / sc;
             }
-        } else {
-            load_f32<VEC>(d.x_t, i, xt);
         }
 
-        const bool post = ph & (LP_PH_POST_FIRST | LP_PH_POST_STEADY);
-        float cv[VEC];
-        if (post || (ph & LP_PH_PRE_HALF)) {
+        // ---- POST: score split -> x0s, C' ; drift correction ; OU ----------------------------
+        if (post) {
+            float x0s[VEC];
+            if (d.x0_big == d.x0 || given) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) x0b[k] = x0[k];
+            }
+            if (given) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) yv[k] = 0.0f;
+            }
             if (ph & LP_PH_POST_FIRST) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) cv[k] = 0.0f;
-            } else {
-                load_f32<VEC>(d.C, i, cv);
             }
-        }
-
-        // Philox quad index follows the FLAT element index so the stream does not
-        // depend on VEC or on the row split.
-        float xi_a[VEC], xi_b[VEC];
-        auto draw = [&](const float* host_xi, uint32_t slot, float (&z)[VEC]) {
-            if (host_xi) {
-                load_f32<VEC>(host_xi, i, z);
-            } else if constexpr (VEC == 4) {
-                normal4(static_cast<uint64_t>(i) >> 2, seq, slot, d.rng_seed, z);
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    float z4[4];
-                    normal4(static_cast<uint64_t>(i + k) >> 2, seq, slot, d.rng_seed, z4);
-                    z[k] = z4[(i + k) & 3];
-                }
-            }
-        };
-
-        // ---- POST: score split -> x0s, C' ; drift correction ; OU -----------------
-        if (post) {
-            float x0[VEC], x0b[VEC], x0s[VEC];
-            load_any<VEC>(d.x0, x0dt, i, x0);
-            if (d.x0_big == d.x0 || (fl & LP_FL_X0S_GIVEN)) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) x0b[k] = x0[k];
-            } else {
-                load_any<VEC>(d.x0_big, x0dt, i, x0b);
-            }
-            if (fl & LP_FL_X0S_GIVEN) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) yv[k] = 0.0f;
-            } else {
-                load_f32<VEC>(d.y, i, yv);
-            }
-            draw(d.xi_post, 0u, xi_a);
-            float corr[VEC];
-            const bool given = fl & LP_FL_X0S_GIVEN;
-            const bool has_corr = d.corr_el != nullptr && !given;
-            if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
-
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float mk = m[k];
@@ -274,9 +273,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             if (fl & LP_FL_WRITE_X0S) store_f32<VEC>(d.x0s, i, x0s);
         }
 
-        // ---- PRE_HALF: first half-step of the next iteration (uses the new C) ------
+        // ---- PRE_HALF: first half-step of the next iteration (uses the new C) ------------------
         if (ph & LP_PH_PRE_HALF) {
-            draw(d.xi_pre, 1u, xi_b);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float mk = m[k];
@@ -300,9 +298,9 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         }
 
         if (post) store_f32<VEC>(d.C, i, cv);
-        if (ph & (LP_PH_REPLACE | LP_PH_POST_FIRST | LP_PH_POST_STEADY | LP_PH_PRE_HALF)) store_f32<VEC>(d.x_t, i, xt);
+        if (ph & kTouchXt) store_f32<VEC>(d.x_t, i, xt);
 
-        // ---- EMIT: model-space latent for the next backbone call ---------------------
+        // ---- EMIT: model-space latent for the next backbone call --------------------------------
         if (ph & LP_PH_EMIT) {
             float xo[VEC];
 #pragma unroll
@@ -320,29 +318,64 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     }
 }
 
+// ---- launch geometry ------------------------------------------------------------------------
 struct Timer {
     hipEvent_t start, stop;
 };
 
-template <int VEC, bool PER_EL>
-static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer = nullptr) {
+struct Tune {
+    int vec = 0, block = 0, max_blocks = 0;   // 0 = automatic
+    int64_t small_elems = 0;
+    Tune() {
+        // developer knobs for the micro-benchmarks (scripts/microbench_step.py); not an API
+        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_VEC")) vec = std::atoi(e);
+        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_BLOCK")) block = std::atoi(e);
+        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_MAXBLOCKS")) max_blocks = std::atoi(e);
+        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_SMALL")) small_elems = std::atoll(e);
+    }
+};
+
+static const Tune& tune() {
+    static const Tune t;
+    return t;
+}
+
+template <int VEC, bool PER_EL, uint32_t PH>
+static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
+    const Tune& t = tune();
     const int64_t groups = d.el_per_row / VEC;
-    // small problems: 64-thread blocks spread single waves over all 256 CUs (latency bound);
-    // large ones: 256-thread blocks, capped near 8 blocks/CU, grid-stride the rest.
-    const int64_t total_groups = groups * d.rows;
-    const int block = total_groups <= 64 * 1024 ? 64 : 256;
+    const int block = t.block ? t.block : 256;
     int64_t bx = (groups + block - 1) / block;
-    const int64_t cap = (2048 + d.rows - 1) / d.rows;
+    // large latents: cap at the resident-block capacity of 256 CUs (5 blocks of 256 threads per CU at
+    // the steady kernel's 81 VGPRs; measured best on c5_wan: 1280 -> 14.35 us, 2048 -> 15.2 us) and
+    // grid-stride the rest, so no partially filled second wave of blocks trails the launch
+    const int64_t cap_total = t.max_blocks ? t.max_blocks : 1280;
+    const int64_t cap = (cap_total + d.rows - 1) / d.rows;
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
     if (timer) {
-        hipExtLaunchKernelGGL((lp_step_kernel<VEC, PER_EL>), grid, dim3(block), 0, stream, timer->start, timer->stop,
-                              0, d);
+        hipExtLaunchKernelGGL((lp_step_kernel<VEC, PER_EL, PH>), grid, dim3(block), 0, stream, timer->start,
+                              timer->stop, 0, d);
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, PER_EL>), grid, dim3(block), 0, stream, d);
+        hipLaunchKernelGGL((lp_step_kernel<VEC, PER_EL, PH>), grid, dim3(block), 0, stream, d);
     }
     return hipGetLastError();
+}
+
+template <int VEC>
+static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
+    if (d.flags & LP_FL_PER_ELEMENT) return launch<VEC, true, 0>(d, stream, timer);
+    constexpr uint32_t R = LP_PH_REPLACE, F = LP_PH_POST_FIRST, S = LP_PH_POST_STEADY, P = LP_PH_PRE_HALF,
+                       E = LP_PH_EMIT;
+    switch (d.phases) {
+        case S | P | E: return launch<VEC, false, S | P | E>(d, stream, timer);   // steady state
+        case F | P | E: return launch<VEC, false, F | P | E>(d, stream, timer);   // iteration 0
+        case S | E: return launch<VEC, false, S | E>(d, stream, timer);           // last iteration
+        case F | E: return launch<VEC, false, F | E>(d, stream, timer);           // n_steps == 1
+        case R | E: return launch<VEC, false, R | E>(d, stream, timer);           // replace step
+        default: return launch<VEC, false, 0>(d, stream, timer);                  // unfused (early stop) etc.
+    }
 }
 
 static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -357,7 +390,7 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     const uint32_t ph = d.phases;
     if (ph == 0 || (ph & ~0x1fu)) return LP_E_INVALID;
     if ((ph & LP_PH_POST_FIRST) && (ph & LP_PH_POST_STEADY)) return LP_E_INVALID;
-    if ((ph & LP_PH_REPLACE) && (ph & (LP_PH_POST_FIRST | LP_PH_POST_STEADY | LP_PH_PRE_HALF))) return LP_E_INVALID;
+    if ((ph & LP_PH_REPLACE) && (ph & (kPost | LP_PH_PRE_HALF))) return LP_E_INVALID;
     const bool per_el = d.flags & LP_FL_PER_ELEMENT;
     if (!per_el && !d.coef) return LP_E_INVALID;
     if (per_el && (!d.abt_el || (!(d.flags & LP_FL_FLOW) && !d.ve_el))) return LP_E_INVALID;
@@ -372,7 +405,7 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
             return LP_E_INVALID;
         }
     }
-    if (ph & (LP_PH_POST_FIRST | LP_PH_POST_STEADY)) {
+    if (ph & kPost) {
         const bool given = d.flags & LP_FL_X0S_GIVEN;
         if (!d.x0 || !d.C || (!given && (!d.x0_big || !d.y))) return LP_E_INVALID;
         if ((d.flags & LP_FL_WRITE_X0S) && !d.x0s) return LP_E_INVALID;
@@ -382,19 +415,20 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
 
     const size_t half_al = 8, f_al = 16;
     const bool x0_half = x0_dtype(d.flags) != DT_F32, xin_half = xin_dtype(d.flags) != DT_F32;
-    const bool vec4 = (d.el_per_row % 4 == 0) && aligned(d.coef, 4) && aligned(d.x, f_al) && aligned(d.known, f_al) &&
-                      aligned(d.noise, f_al) && aligned(d.y, f_al) &&
-                      aligned(d.mask, (d.flags & LP_FL_MASK_U8) ? 4 : f_al) && aligned(d.x_t, f_al) &&
-                      aligned(d.C, f_al) && aligned(d.x0s, f_al) && aligned(d.x0, x0_half ? half_al : f_al) &&
-                      aligned(d.x0_big, x0_half ? half_al : f_al) && aligned(d.x_in, xin_half ? half_al : f_al) &&
-                      aligned(d.xi_post, f_al) && aligned(d.xi_pre, f_al) && aligned(d.abt_el, f_al) &&
-                      aligned(d.ve_el, f_al) && aligned(d.rsig_el, f_al) && aligned(d.corr_el, f_al);
-    hipError_t err;
-    if (vec4) {
-        err = per_el ? launch<4, true>(d, stream, timer) : launch<4, false>(d, stream, timer);
-    } else {
-        err = per_el ? launch<1, true>(d, stream, timer) : launch<1, false>(d, stream, timer);
-    }
+    const bool can_vec4 = (d.el_per_row % 4 == 0) && aligned(d.x, f_al) && aligned(d.known, f_al) &&
+                          aligned(d.noise, f_al) && aligned(d.y, f_al) &&
+                          aligned(d.mask, (d.flags & LP_FL_MASK_U8) ? 4 : f_al) && aligned(d.x_t, f_al) &&
+                          aligned(d.C, f_al) && aligned(d.x0s, f_al) && aligned(d.x0, x0_half ? half_al : f_al) &&
+                          aligned(d.x0_big, x0_half ? half_al : f_al) && aligned(d.x_in, xin_half ? half_al : f_al) &&
+                          aligned(d.xi_post, f_al) && aligned(d.xi_pre, f_al) && aligned(d.abt_el, f_al) &&
+                          aligned(d.ve_el, f_al) && aligned(d.rsig_el, f_al) && aligned(d.corr_el, f_al);
+    // small latents are latency bound: one element per lane puts 4x more waves on the chip
+    const Tune& t = tune();
+    const int64_t small = t.small_elems ? t.small_elems : (512 * 1024);
+    bool vec4 = can_vec4 && d.n_el > small;
+    if (t.vec == 4) vec4 = can_vec4;
+    if (t.vec == 1) vec4 = false;
+    const hipError_t err = vec4 ? launch_phase<4>(d, stream, timer) : launch_phase<1>(d, stream, timer);
     return err == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 

@@ -1,0 +1,113 @@
+"""One-node multi-GPU use of the Langevin path: batch-of-images replicas, one process per GPU.
+
+The reference has no multi-device code at all; the path shards naturally
+because every operation of lanpaint.py:56-157 is elementwise per latent element with per-row
+scalars.  So the design is: shard the batch rows across ranks, broadcast what the ranks share
+(mask, known latent, conditioning) ONCE at setup in a single packed RCCL broadcast over xGMI,
+and run the think loop with NO collective in it.  The only optional exchange is the inner
+early stop on a sharded batch, whose metric is defined over the whole batch tensor
+(earlystop.py:52-55): the four partial sums are all-reduced so every rank takes the same
+decision as a single process would.
+
+`torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) as torchrun / torch.distributed.run export them."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Initialise the default process group from the environment (no-op for world size 1)."""
+    rank, world, local_rank = env_world()
+    if world <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            device = device or torch.device("cuda", local_rank)
+            torch.cuda.set_device(device)
+            kw["device_id"] = device
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, **kw)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def replica_seed(seed: int, rank: int) -> int:
+    """Per-rank RNG seed (xi stream and initial noise): seed + rank."""
+    return (int(seed) + int(rank)) & 0xFFFFFFFFFFFFFFFF
+
+
+def shard_rows(global_batch: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) slice of the batch rows owned by `rank`; sizes differ by at most 1."""
+    base, extra = divmod(int(global_batch), int(world))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def _pack_header(tensors: Dict[str, torch.Tensor]):
+    return [(k, tuple(t.shape), str(t.dtype).replace("torch.", "")) for k, t in tensors.items()]
+
+
+def broadcast_job(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0,
+                  device: Optional[torch.device] = None, group=None) -> Dict[str, torch.Tensor]:
+    """Broadcast the tensors every replica shares (prepared mask, known latent `y`, cond tensors)
+    from `src` to all ranks: one tiny object broadcast for the layout, then ONE collective over a
+    single packed byte buffer (xGMI is per-link bound: one large transfer, not many small ones).
+    Non-src ranks may pass None.  Returns {name: tensor} on `device` on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {k: (t.to(device) if device is not None else t) for k, t in (tensors or {}).items()}
+    rank = dist.get_rank(group)
+    header = [_pack_header(tensors) if rank == src else None]
+    dist.broadcast_object_list(header, src=src, group=group)
+    layout = header[0]
+    sizes = []
+    for _name, shape, dtype in layout:
+        n = 1
+        for s in shape:
+            n *= s
+        sizes.append(n * torch.empty((), dtype=getattr(torch, dtype)).element_size())
+    offsets, total = [], 0
+    for sz in sizes:
+        offsets.append(total)
+        total += (sz + 15) // 16 * 16                      # keep every tensor 16-byte aligned in the pack
+    buf_dev = device if device is not None else (next(iter(tensors.values())).device if tensors else torch.device("cpu"))
+    buf = torch.empty(max(total, 1), dtype=torch.uint8, device=buf_dev)
+    if rank == src:
+        for (name, _shape, _dtype), off, sz in zip(layout, offsets, sizes):
+            buf[off:off + sz] = tensors[name].contiguous().view(-1).view(torch.uint8).to(buf_dev)
+    dist.broadcast(buf, src=src, group=group)
+    out = {}
+    for (name, shape, dtype), off, sz in zip(layout, offsets, sizes):
+        out[name] = buf[off:off + sz].view(getattr(torch, dtype)).reshape(shape).clone()
+    return out
+
+
+def reduce_throughput(elapsed_s: float, units: int, device: Optional[torch.device] = None, group=None) -> Tuple[float, int]:
+    """(max elapsed over ranks, total units over ranks): whole-job throughput = units / elapsed."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(elapsed_s), int(units)
+    dev = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    n = torch.tensor([float(units)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()), int(round(n.item()))
+
+
+def all_reduce_stop_sums(acc: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum the early-stop partial sums {sum(w d^2), sum(w)} x {inpaint, ring} over the ranks that
+    share one (sharded) batch, in place; identity when no process group is up."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    return acc

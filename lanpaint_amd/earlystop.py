@@ -49,6 +49,9 @@ class _Metric:
             b, c, h, w = m.shape
             _cabi.check(self.lib.lp_boundary_ring(m.data_ptr(), self.ring.data_ptr(), b * c, h, w, self._stream()),
                         "lp_boundary_ring")
+        # False: single-process metric (default).  True / a ProcessGroup: the batch tensor is sharded
+        # over those ranks and the metric is taken over the whole batch, as the reference defines it.
+        self.reduce_group = False
         self.acc = torch.zeros((2, 4), dtype=torch.float64, device=dev)
         self.scratch = torch.empty((self.SCRATCH_BLOCKS * 4,), dtype=torch.float64, device=dev)
 
@@ -77,6 +80,9 @@ class _Metric:
         """pairs: list of up to 2 (a, b).  Returns [(d_inpaint, d_ring|None), ...] with ONE sync."""
         for slot, (a, b) in enumerate(pairs):
             self._launch(a, b, slot)
+        if self.reduce_group is not False:                  # batch sharded over ranks: sum the partial sums
+            from .distributed import all_reduce_stop_sums
+            all_reduce_stop_sums(self.acc, None if self.reduce_group is True else self.reduce_group)
         vals = self.acc.tolist()                            # the single host sync of this iteration
         out = []
         for slot in range(len(pairs)):

@@ -315,12 +315,26 @@ class LanPaint:
         srcs = [x, sigma, current_times[0], current_times[1], current_times[2]]
         if cap is None:
             cap = self._capture(key, srcs, latent_mask, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
-        torch._foreach_copy_(cap.static_in, srcs)
-        cap.graph.replay()
-        x.copy_(cap.static_in[0])
+        stream = self._stream(x.device)
+        if all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs):
+            # one staging launch in, one out (a foreach copy costs ~11 us on the device for these five)
+            cd = cap.copy_in
+            for k, t in enumerate(srcs):
+                cd.src[k] = t.data_ptr()
+            _cabi.check(self._lib.lp_copy_batch(ctypes.byref(cd), stream), "lp_copy_batch")
+            cap.graph.replay()
+            out = torch.empty_like(cap.out)
+            co = cap.copy_out
+            co.dst[0], co.dst[1] = x.data_ptr(), out.data_ptr()
+            _cabi.check(self._lib.lp_copy_batch(ctypes.byref(co), stream), "lp_copy_batch")
+        else:
+            torch._foreach_copy_(cap.static_in, srcs)
+            cap.graph.replay()
+            x.copy_(cap.static_in[0])
+            out = cap.out.clone()
         self.iterations_run += cap.ran
         self.last_inner_steps = cap.ran
-        return cap.out.clone()
+        return out
 
     def _capture(self, key, srcs, latent_mask, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
         dev = srcs[0].device
@@ -349,6 +363,14 @@ class LanPaint:
         cap.ran = self.iterations_run - it0
         self.iterations_run = it0
         cap.keep, self._ws = self._ws, None      # the captured call owns that workspace (pointers are baked in)
+        cd = cap.copy_in = _cabi.LpCopyDesc()
+        cd.n = len(static_in)
+        for k, t in enumerate(static_in):
+            cd.count[k], cd.src_stride[k], cd.dst[k] = t.numel(), 1, t.data_ptr()
+        co = cap.copy_out = _cabi.LpCopyDesc()
+        co.n = 2
+        co.count[0], co.src_stride[0], co.src[0] = static_in[0].numel(), 1, static_in[0].data_ptr()
+        co.count[1], co.src_stride[1], co.src[1] = cap.out.numel(), 1, cap.out.data_ptr()
         self._graphs[key] = cap
         return cap
 

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused lp_step kernel alone: R back-to-back launches of one phase
+combination captured in a hipGraph, replayed; reports us per launch (kernel + the dependent
+launch boundary) for the current LANPAINT_AMD_TUNE_* environment.
+
+    python scripts/microbench_step.py c2_sdxl [steady|first|last|replace] [reps]
+"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                    # noqa: E402
+from lanpaint_amd import _cabi                  # noqa: E402
+
+PH = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
+      "first": _cabi.LP_PH_POST_FIRST | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
+      "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT,
+      "replace": _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT}
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "c2_sdxl"
+    phase = sys.argv[2] if len(sys.argv) > 2 else "steady"
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    dev = torch.device("cuda", 0)
+    lib = _cabi.load()
+    d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase])
+    bufs = keep[0]
+
+    def launches(n):
+        s = torch.cuda.current_stream().cuda_stream
+        for k in range(n):
+            d.rng_offset = k
+            _cabi.check(lib.lp_step(ctypes.byref(d), s))
+
+    launches(5)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(graph, stream=side):
+        launches(reps)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_rep = 20
+    for _ in range(n_rep):
+        graph.replay()
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / (n_rep * reps) * 1e6
+    # reference point: a plain torch elementwise kernel of the same size, same harness
+    g2 = torch.cuda.CUDAGraph()
+    a = bufs["x"]
+    with torch.cuda.graph(g2, stream=side):
+        for _ in range(reps):
+            b = a * 0.9
+    for _ in range(3):
+        g2.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_rep):
+        g2.replay()
+    torch.cuda.synchronize()
+    us_mul = (time.perf_counter() - t0) / (n_rep * reps) * 1e6
+    bytes_ = {"steady": 36, "first": 32, "last": 36, "replace": 24}[phase] * n_el
+    env = {k: v for k, v in os.environ.items() if k.startswith("LANPAINT_AMD_TUNE")}
+    print(f"{wl} {phase} n_el={n_el} us/launch={us:.3f} ({bytes_ / us / 1e3:.0f} GB/s algorithmic) "
+          f"torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

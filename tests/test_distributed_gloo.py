@@ -1,0 +1,80 @@
+"""The N > 1 path on CPU: world_size-2 gloo process group (one process per "GPU"), covering the
+setup broadcast, row sharding, per-rank seeds, throughput reduction and the early-stop partial-sum
+all-reduce.  No collective runs inside the think loop, so this is the whole distributed surface."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from lanpaint_amd import distributed as D
+    r, w = D.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    shared = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(0)
+        shared = {"mask": (torch.rand(1, 4, 8, 8, generator=g) > 0.5).float(),
+                  "y": torch.randn(1, 4, 8, 8, generator=g),
+                  "cond": torch.randn(1, 77, 32, generator=g).to(torch.bfloat16),
+                  "pooled": torch.randn(1, 7, generator=g).to(torch.float16),
+                  "ids": torch.arange(5, dtype=torch.int64)}
+    got = D.broadcast_job(shared, src=0)
+    digest = {k: (tuple(v.shape), str(v.dtype), float(v.double().sum())) for k, v in got.items()}
+    t, n = D.reduce_throughput(1.0 + rank, 150)
+    acc = torch.tensor([[1.0 + rank, 2.0, 3.0, 4.0], [0.5, 0.5, 0.5, 0.5]], dtype=torch.float64)
+    D.all_reduce_stop_sums(acc)
+    q.put((rank, digest, t, n, acc.tolist(), D.replica_seed(7, rank), D.shard_rows(32, world, rank)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_setup_and_reductions():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, d0, t0, n0, a0, s0, sh0), (r1, d1, t1, n1, a1, s1, sh1) = res
+    assert d0 == d1 and set(d0) == {"mask", "y", "cond", "pooled", "ids"}      # every rank holds the same job
+    assert d0["cond"][1] == "torch.bfloat16" and d0["ids"][1] == "torch.int64"
+    assert t0 == t1 == 2.0 and n0 == n1 == 300                                 # max time, summed units
+    assert a0 == a1 == [[3.0, 4.0, 6.0, 8.0], [1.0, 1.0, 1.0, 1.0]]
+    assert (s0, s1) == (7, 8)
+    assert (sh0, sh1) == ((0, 16), (16, 32))
+
+
+def test_shard_rows_and_single_process_identities():
+    from lanpaint_amd import distributed as D
+    for batch, world in [(32, 8), (5, 4), (3, 8), (1, 1)]:
+        spans = [D.shard_rows(batch, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == batch
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    t = {"m": torch.ones(2, 2)}
+    assert D.broadcast_job(t)["m"] is t["m"]
+    assert D.reduce_throughput(1.5, 10) == (1.5, 10)
+    acc = torch.ones(2, 4, dtype=torch.float64)
+    assert D.all_reduce_stop_sums(acc) is acc
+    assert D.env_world()[1] >= 1

@@ -61,7 +61,7 @@ def test_coeffs_table_matches_closed_form(lib, flow, sigmas, msf, lam, beta):
             for tag, tau, off in (("full", dt, 0), ("half", dt / 2, 3)):
                 e, k = np.exp(-a * tau), -np.expm1(-a * tau) / a
                 sd = np.sqrt(2 * (-np.expm1(-2 * a * tau) / (2 * a)))
-                np.testing.assert_allclose(t[r, base + off: base + off + 3], [e, k, sd], rtol=3e-7)
+                np.testing.assert_allclose(t[r, base + off: base + off + 3], [e, k, sd], rtol=3e-7, atol=1e-37)
             assert t[r, base + _cabi.LP_R_A] == pytest.approx(a, rel=2e-7)
             assert want[g]["A"] == pytest.approx(a, rel=1e-6)
         assert t[r, _cabi.LP_C_ABT] == a32 and t[r, _cabi.LP_C_OMA] == oma
@@ -91,8 +91,11 @@ def test_philox_normal_statistics(lib):
     assert abs(np.mean(z ** 3)) < 4 * np.sqrt(15.0 / n)
     assert abs(np.mean(z ** 4) - 3.0) < 4 * np.sqrt(96.0 / n)
     assert np.abs(z).max() > 4.5                       # tails are populated
-    for lag in (1, 2, 3, 4, 64, 4096):                 # no serial correlation (incl. across Box-Muller pairs / quads)
+    for lag in (1, 2, 3, 4, 64, 4096):                 # no serial correlation between neighbouring elements
         assert abs(np.mean(z[:-lag] * z[lag:])) < 5 / np.sqrt(n)
+    w = _philox(lib, 1 << 22, 1234, 7, 1).double().cpu().numpy()      # sine branch of the same pairs
+    assert abs(w.var() - 1.0) < 4 * np.sqrt(2.0 / n) and abs(np.mean(z * w)) < 5 / np.sqrt(n)
+    assert abs(np.mean(z * z * w * w) - 1.0) < 0.01                    # independent, not merely uncorrelated
     from scipy import stats
     assert stats.kstest(z[: 1 << 18], "norm").pvalue > 1e-4
 

@@ -190,7 +190,7 @@ def test_graph_replay_equals_eager_with_torch_rng():
     exactly like eager launches, so the whole trajectory is identical."""
     xe, oe, eng_e, _ = _sched_run(False, "torch")
     xg, og, eng_g, _ = _sched_run(True, "torch")
-    assert len(eng_g._graphs) == 1 and eng_g.iterations_run == eng_e.iterations_run == 12
+    assert len(eng_g._graphs) == 1 and eng_g.iterations_run == eng_e.iterations_run == 15
     np.testing.assert_array_equal(xe, xg)
     for a, b in zip(oe, og):
         np.testing.assert_array_equal(a, b)
