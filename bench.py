@@ -174,6 +174,9 @@ def run_gpu(args):
     large = None
     if rank == 0 and world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
         large = measure_hbm_bound_shape(_cabi, dev)
+    extras = {}
+    if rank == 0 and world == 1 and args.extras:
+        extras = extra_lines(args, dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_seconds)
@@ -204,6 +207,7 @@ def run_gpu(args):
         "roofline_hbm_bound_shape": large,
         "cpu_baseline": cpu,
     }
+    line.update(extras)
     print(json.dumps(line), flush=True)
 
 
@@ -269,8 +273,11 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
     bytes_per_launch = BYTES_PER_EL_STEADY * n_el
     mean_s = float(durs.mean())
     achieved = bytes_per_launch / mean_s / 1e9
+    burst_us = graph_burst_us_per_launch(_cabi, args.workload, x0.device)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
+            "graph_burst_us_per_launch": burst_us,
+            "graph_burst_GBps": bytes_per_launch / burst_us / 1e3,
             "kernel": "lp::lp_step_kernel<VEC,false,POST_STEADY|PRE_HALF|EMIT> (steady-state think step; "
                       "VEC=1 up to 512K elements, VEC=4 above)",
             "algorithmic_bytes_per_launch": bytes_per_launch, "mean_launch_us": mean_s * 1e6,
@@ -313,6 +320,38 @@ def standalone_step(_cabi, workload, dev, phase=None):
     return d, keep, n_el
 
 
+def graph_burst_us_per_launch(_cabi, workload, dev, reps=200, replays=20):
+    """Un-profiled steady-state cost of one launch: `reps` launches of the steady kernel captured in a
+    hipGraph on synthetic buffers of the workload's shape, replayed; wall time / launches (kernel +
+    the dependent-launch boundary; a bare torch elementwise kernel costs ~1.66 us this way)."""
+    import ctypes
+    lib = _cabi.load()
+    d, keep, _n = standalone_step(_cabi, workload, dev)
+
+    def launches(n):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for k in range(n):
+            d.rng_offset = k
+            _cabi.check(lib.lp_step(ctypes.byref(d), st))
+
+    launches(5)
+    torch.cuda.synchronize(dev)
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.graph(graph, stream=side):
+        launches(reps)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    us = (time.perf_counter() - t0) / (replays * reps) * 1e6
+    del keep
+    return us
+
+
 def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
     """Supplementary evidence: the same steady-state kernel on the video-latent shape (75 MB of
     algorithmic traffic per launch -- the regime where the kernel is bandwidth bound, not launch
@@ -349,6 +388,83 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
             "traffic": pmc_traffic(workload),
             "mean_launch_us": float(durs.mean()) * 1e6, "min_launch_us": float(durs.min()) * 1e6,
             "launches_timed": int(durs.size)}
+
+
+def extra_lines(args, dev):
+    """Secondary numbers of the same build (N = 1 only; not the headline):
+    node_default_schedule -- C2 driven through KSamplerX0Inpaint with the node defaults
+        (MinStepFrac = 1.0 => n_eff = round(N (1 - abt)), last sigma skipped: SURVEY.md 8d second line);
+    with_backbone -- BASELINE configs[0] shape (1x4x64x64, 20 sigmas x 5) in front of a random-init
+        SD1.5-shaped dummy UNet in bf16 (tests/dummy_unet.py), the stand-in (ii) of SURVEY.md 8d."""
+    from lanpaint_amd import LanPaint
+    from lanpaint_amd import nodes as lpn
+    out = {}
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    # ---- node-default schedule through the sampler-facing callable
+    shape, flow, n_sig, n_think = WORKLOADS["c2_sdxl"]
+    sig_np = karras_sigmas(n_sig)
+    x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed, dev, tt)
+    sig_list = [torch.full((1,), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+    ratios = euler_ratios(sig_list, 4)
+    model = StubBackbone(flow)
+    model.model_type = "EPS"
+    k = lpn.KSamplerX0Inpaint(model, torch.cat([tt(sig_np), torch.zeros(1, device=dev)]))
+    k.latent_image, k.noise = y, noise
+    k.PaintMethod = LanPaint(model, n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
+                             MinStepFrac=1.0, rng=args.rng, philox_seed=args.seed, graph=bool(args.graph))
+    k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 1.0
+    denoise_mask = 1.0 - mask
+
+    def node_pass():
+        x = x0.clone()
+        for i in range(n_sig):
+            den = k(x, sig_list[i], denoise_mask, model_options={}, seed=args.seed)
+            if i + 1 < n_sig:
+                x = x + (x - den) * ratios[i]
+        return x
+
+    for _ in range(2):
+        node_pass()
+    torch.cuda.synchronize()
+    it0, t0, reps = k.PaintMethod.iterations_run, time.perf_counter(), 5
+    for _ in range(reps):
+        node_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    iters = k.PaintMethod.iterations_run - it0
+    out["node_default_schedule"] = {
+        "value": iters / dt, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
+        "iterations_per_step": iters // reps,
+        "note": "C2 through KSamplerX0Inpaint, MinStepFrac=1.0, EarlyStop=1 (n_eff = round(5(1-abt)), last sigma 0); "
+                "includes the one host read per sigma the n_eff rule needs"}
+    # ---- dummy UNet backbone on the SD1.5 shape
+    try:
+        from tests.dummy_unet import DummyUNetBackbone
+        shape, flow, n_sig, n_think = WORKLOADS["c1_sd15"]
+        sig_np = karras_sigmas(n_sig)
+        x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed, dev, tt)
+        sig_list = [torch.full((1,), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+        times_list = [times_from_sigma(s, flow) for s in sig_list]
+        ratios = euler_ratios(sig_list, 4)
+        net = DummyUNetBackbone(dev, flow=flow)
+        eng = LanPaint(net, n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
+                       rng=args.rng, philox_seed=args.seed, graph=bool(args.graph))
+        for _ in range(2):
+            schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        torch.cuda.synchronize()
+        it0, t0, reps = eng.iterations_run, time.perf_counter(), 3
+        for _ in range(reps):
+            xl = schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["with_backbone"] = {
+            "value": (eng.iterations_run - it0) / dt, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
+            "finite": bool(torch.isfinite(xl).all()),
+            "backbone": "random-init SD1.5-shaped dummy UNet (conv/GroupNorm/SiLU + 1 self-attention block, 1.3 M "
+                        "params, bf16, dual-head output), latent 1x4x64x64, 20 sigmas x 5 (BASELINE configs[0] shape)"}
+    except Exception as e:                       # the stand-in is not a deliverable; never fail the bench on it
+        out["with_backbone"] = {"error": repr(e)}
+    return out
 
 
 def cpu_baseline(workload, budget_s):
@@ -399,6 +515,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")
     ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")
     args = ap.parse_args()
     run_gpu(args)

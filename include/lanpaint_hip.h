@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 1
+#define LP_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -100,6 +100,10 @@ typedef struct lp_hyper {
 #define LP_FL_XIN_F16       (1u << 7)  /* x_in is written as fp16                              */
 #define LP_FL_PER_ELEMENT   (1u << 8)  /* abt_el/ve_el/... per-element times (AV packs,
                                           lanpaint.py:60-74): general path                     */
+#define LP_FL_CFG_FUSED     (1u << 10) /* `x0` = cond prediction, `x0_big` = uncond prediction of ONE batched
+                                          backbone pass; the kernel forms both CFG heads itself,
+                                          head = uncond + (cond - uncond) * scale  (nodes.py:161-175 +
+                                          ComfyUI cfg_function) instead of 2 x 3 eager elementwise passes */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 
@@ -121,6 +125,8 @@ typedef struct lp_step_desc {
     float     step_size;
     float     min_step_frac;
     float     noise_scale;     /* model_sampling.noise_scale (lanpaint.py:91)             */
+    float     cfg_scale;       /* LP_FL_CFG_FUSED: cond_scale      (head 0, x0)           */
+    float     cfg_scale_big;   /*                  cond_scale_BIG  (head 1, x0_BIG)       */
     const float* coef;         /* [rows][LP_COEF_STRIDE] from lp_coeffs()                 */
     const float* x;            /* REPLACE: sampler latent (model space)                   */
     const float* known;        /* REPLACE, LP_REPLACE_KNOWN                               */
@@ -146,9 +152,10 @@ typedef struct lp_step_desc {
 
 typedef struct lp_final_desc {
     int64_t   n_el;
-    uint32_t  flags;           /* LP_FL_MASK_*, LP_FL_X0_BF16/F16 (dtype of model_out)    */
-    int32_t   reserved0;
-    const void*  model_out;    /* final denoise, head 0 (lanpaint.py:151-153)             */
+    uint32_t  flags;           /* LP_FL_MASK_*, LP_FL_X0_BF16/F16 (dtype of model_out), LP_FL_CFG_FUSED */
+    float     cfg_scale;       /* LP_FL_CFG_FUSED: head 0 = uncond + (model_out - uncond)*cfg_scale */
+    const void*  model_out;    /* final denoise, head 0 (lanpaint.py:151-153); cond prediction when fused */
+    const void*  uncond;       /* LP_FL_CFG_FUSED: uncond prediction, else NULL           */
     const float* y;
     const void*  mask;
     const float* x_src;        /* final model-space x (the last EMIT)                     */

@@ -6,8 +6,8 @@ MI355X (gfx950), behind the reference's own Python API.
 
 Importing the engine loads liblanpaint_hip.so and fails loudly when it is missing.
 """
-from .types import LangevinState  # noqa: F401
+from .types import FusedCFGHeads, LangevinState  # noqa: F401
 from .lanpaint import LanPaint  # noqa: F401
 
-__all__ = ["LanPaint", "LangevinState"]
+__all__ = ["LanPaint", "LangevinState", "FusedCFGHeads"]
 __version__ = "0.1.0"

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -27,7 +27,7 @@ LP_C_REGION0, LP_C_REGION1 = 12, 22
 LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT = 1, 2, 4, 8, 16
 LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
-LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN = 256, 512
+LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED = 256, 512, 1024
 LP_REPLACE_KNOWN, LP_REPLACE_VE, LP_REPLACE_FLOW = 0, 1, 2
 
 
@@ -41,7 +41,7 @@ class LpStepDesc(C.Structure):
         ("n_el", C.c_int64), ("el_per_row", C.c_int64), ("rows", C.c_int32), ("phases", C.c_uint32),
         ("flags", C.c_uint32), ("replace_kind", C.c_int32),
         ("lambda_", C.c_float), ("one_plus_lambda", C.c_float), ("beta", C.c_float), ("step_size", C.c_float),
-        ("min_step_frac", C.c_float), ("noise_scale", C.c_float),
+        ("min_step_frac", C.c_float), ("noise_scale", C.c_float), ("cfg_scale", C.c_float), ("cfg_scale_big", C.c_float),
         ("coef", C.c_void_p), ("x", C.c_void_p), ("known", C.c_void_p), ("noise", C.c_void_p), ("y", C.c_void_p),
         ("mask", C.c_void_p), ("x_t", C.c_void_p), ("C", C.c_void_p), ("x0s", C.c_void_p), ("x0", C.c_void_p),
         ("x0_big", C.c_void_p), ("x_in", C.c_void_p), ("xi_post", C.c_void_p), ("xi_pre", C.c_void_p),
@@ -52,8 +52,8 @@ class LpStepDesc(C.Structure):
 
 class LpFinalDesc(C.Structure):
     _fields_ = [
-        ("n_el", C.c_int64), ("flags", C.c_uint32), ("reserved0", C.c_int32),
-        ("model_out", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p), ("x_src", C.c_void_p),
+        ("n_el", C.c_int64), ("flags", C.c_uint32), ("cfg_scale", C.c_float),
+        ("model_out", C.c_void_p), ("uncond", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p), ("x_src", C.c_void_p),
         ("x_dst", C.c_void_p), ("out", C.c_void_p), ("rng_bump_ptr", C.c_void_p), ("rng_bump", C.c_uint64),
     ]
 

@@ -138,6 +138,12 @@ __global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d)
         float m[VEC], mo[VEC], yv[VEC], o[VEC];
         load_mask<VEC>(d.mask, d.flags, i, m);
         load_any<VEC>(d.model_out, dt, i, mo);
+        if (d.flags & LP_FL_CFG_FUSED) {
+            float un[VEC];
+            load_any<VEC>(d.uncond, dt, i, un);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) mo[k] = un[k] + (mo[k] - un[k]) * d.cfg_scale;
+        }
         load_f32<VEC>(d.y, i, yv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o[k] = mo[k] * (1.0f - m[k]) + yv[k] * m[k];
@@ -158,8 +164,10 @@ int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
     const lp_final_desc& d = *dp;
     if (d.n_el <= 0 || !d.model_out || !d.y || !d.mask || !d.out) return LP_E_INVALID;
     if (d.x_dst && !d.x_src) return LP_E_INVALID;
+    if ((d.flags & LP_FL_CFG_FUSED) && !d.uncond) return LP_E_INVALID;
     const bool half = x0_dtype(d.flags) != DT_F32;
-    const bool vec4 = (d.n_el % 4 == 0) && aligned(d.model_out, half ? 8 : 16) && aligned(d.y, 16) &&
+    const bool vec4 = (d.n_el % 4 == 0) && aligned(d.model_out, half ? 8 : 16) && aligned(d.uncond, half ? 8 : 16) &&
+                      aligned(d.y, 16) &&
                       aligned(d.mask, (d.flags & LP_FL_MASK_U8) ? 4 : 16) && aligned(d.x_src, 16) &&
                       aligned(d.x_dst, 16) && aligned(d.out, 16);
     const int vec = vec4 ? 4 : 1;

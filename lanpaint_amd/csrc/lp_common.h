@@ -74,7 +74,8 @@ enum : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 template <int V>
 __device__ __forceinline__ void load_f32(const float* __restrict__ p, int64_t i, float (&o)[V]) {
     if constexpr (V == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p + i);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + i));
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
     } else {
 #pragma unroll
@@ -85,7 +86,11 @@ __device__ __forceinline__ void load_f32(const float* __restrict__ p, int64_t i,
 template <int V>
 __device__ __forceinline__ void store_f32(float* __restrict__ p, int64_t i, const float (&v)[V]) {
     if constexpr (V == 4) {
-        *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+        // the 16 B/lane path only runs on large latents (streaming, nothing is re-read inside a
+        // launch): non-temporal accesses measured +11 % on c5_wan (14.4 -> 12.8 us per launch)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p + i));
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k) p[i + k] = v[k];

@@ -205,6 +205,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             if (d.x0_big == d.x0 || given) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) x0b[k] = x0[k];
+            } else if (fl & LP_FL_CFG_FUSED) {      // x0 = cond, x0b = uncond -> both CFG heads
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float c = x0[k], u = x0b[k], diff = c - u;
+                    x0[k] = u + diff * d.cfg_scale;
+                    x0b[k] = u + diff * d.cfg_scale_big;
+                }
             }
             if (given) {
 #pragma unroll
@@ -346,10 +353,9 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     const int64_t groups = d.el_per_row / VEC;
     const int block = t.block ? t.block : 256;
     int64_t bx = (groups + block - 1) / block;
-    // large latents: cap at the resident-block capacity of 256 CUs (5 blocks of 256 threads per CU at
-    // the steady kernel's 81 VGPRs; measured best on c5_wan: 1280 -> 14.35 us, 2048 -> 15.2 us) and
-    // grid-stride the rest, so no partially filled second wave of blocks trails the launch
-    const int64_t cap_total = t.max_blocks ? t.max_blocks : 1280;
+    // large latents: cap near 8 blocks per CU and grid-stride the rest (c5_wan with non-temporal
+    // accesses: 2048 -> 12.8 us, 1280 -> 13.1 us; profiles/r01_microbench_kernel_variants.log)
+    const int64_t cap_total = t.max_blocks ? t.max_blocks : 2048;
     const int64_t cap = (cap_total + d.rows - 1) / d.rows;
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;

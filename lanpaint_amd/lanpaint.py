@@ -27,11 +27,11 @@ from functools import partial
 import torch
 
 from . import _cabi
-from ._cabi import (LP_FL_FLOW, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
+from ._cabi import (LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
                     LP_PH_EMIT, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_REPLACE, LP_REPLACE_FLOW,
                     LP_REPLACE_KNOWN, LP_REPLACE_VE)
 from .earlystop import LanPaintEarlyStopper
-from .types import LangevinState
+from .types import FusedCFGHeads, LangevinState
 
 _VOID_NULL = None
 
@@ -150,7 +150,9 @@ class LanPaint:
         return array[(slice(None),) + (0,) * (self.img_dim_size - 1)]
 
     def unpack_model_output(self, output):
-        """lanpaint.py:34-43."""
+        """lanpaint.py:34-43 (a FusedCFGHeads is a lazy (x0, x0_BIG) pair)."""
+        if isinstance(output, FusedCFGHeads):
+            return output.materialize()
         if isinstance(output, (tuple, list)):
             if len(output) >= 2:
                 return output[0], output[1]
@@ -238,6 +240,15 @@ class LanPaint:
 
     def _launch_step(self, stream):
         _cabi.check(self._lib.lp_step(ctypes.byref(self._desc), stream), "lp_step")
+
+    def _set_model_output(self, d, output, base_flags, shape):
+        """Backbone output -> descriptor: a FusedCFGHeads keeps the CFG combination inside the kernel."""
+        if isinstance(output, FusedCFGHeads) and output._heads is None and not (base_flags & LP_FL_PER_ELEMENT) \
+                and output.cond.dtype == output.uncond.dtype:
+            d.cfg_scale, d.cfg_scale_big = output.scale, output.scale_big
+            return self._set_model_heads(d, output.cond, output.uncond, base_flags | LP_FL_CFG_FUSED, shape)
+        heads = self.unpack_model_output(output)
+        return self._set_model_heads(d, heads[0], heads[1], base_flags, shape)
 
     def _set_model_heads(self, d, x0, x0_big, base_flags, shape):
         """Point the descriptor at the backbone outputs (fp32/bf16/fp16, made dense)."""
@@ -486,8 +497,8 @@ class LanPaint:
                                      stream, m, y, current_times)
         else:
             for i in range(n_steps):
-                heads = self.unpack_model_output(self.inner_model(x_in, t_model, model_options=model_options, seed=seed))
-                alive = self._set_model_heads(d, heads[0], heads[1], base_flags, shape)
+                alive = self._set_model_output(d, self.inner_model(x_in, t_model, model_options=model_options, seed=seed),
+                                               base_flags, shape)
                 last = i == n_steps - 1
                 d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
                 self._set_xi(d, ws.x_t, want_pre=not last)
@@ -498,18 +509,27 @@ class LanPaint:
         self.last_inner_steps = ran
 
         # ---- final denoise + known-region reprojection + write-back (lanpaint.py:144-157) ----
-        out_model, _ = self.unpack_model_output(self.inner_model(x_in, sigma, model_options=model_options, seed=seed))
+        final = self.inner_model(x_in, sigma, model_options=model_options, seed=seed)
         f = self._fdesc
-        if out_model.shape != shape:
-            out_model = out_model.expand(shape)
-        if out_model.dtype not in (torch.float32, torch.bfloat16, torch.float16):
-            out_model = out_model.float()
-        if not out_model.is_contiguous():
-            out_model = out_model.contiguous()
+
+        def dense(t):
+            if t.shape != shape:
+                t = t.expand(shape)
+            if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                t = t.float()
+            return t if t.is_contiguous() else t.contiguous()
+
+        uncond = None
+        if isinstance(final, FusedCFGHeads) and final._heads is None and final.cond.dtype == final.uncond.dtype:
+            out_model, uncond = dense(final.cond), dense(final.uncond)      # head 0 formed inside lp_finalize
+            f.cfg_scale = final.scale
+        else:
+            out_model = dense(self.unpack_model_output(final)[0])
         out = torch.empty_like(xc)
         f.n_el = n_el
         f.flags = (LP_FL_X0_BF16 if out_model.dtype == torch.bfloat16 else
-                   LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0)
+                   LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0) | (LP_FL_CFG_FUSED if uncond is not None else 0)
+        f.uncond = uncond.data_ptr() if uncond is not None else None
         f.model_out, f.y, f.mask = out_model.data_ptr(), y.data_ptr(), m.data_ptr()
         f.x_src, f.x_dst, f.out = x_in.data_ptr(), xc.data_ptr(), out.data_ptr()
         if self._capturing is not None and self.rng == "philox":
@@ -566,9 +586,9 @@ class LanPaint:
                 d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags
                 self._set_xi(d, ws.x_t, want_pre=True, want_post=False)
                 self._launch_step(stream)
-            heads = self.unpack_model_output(self.inner_model(x_in, t_model, model_options=model_options, seed=seed))
+            output = self.inner_model(x_in, t_model, model_options=model_options, seed=seed)
             x0s = self._x0s_buffer(ws, [args.x0 if args else None, stopper.x0_anchor])
-            alive = self._set_model_heads(d, heads[0], heads[1], base_flags | LP_FL_WRITE_X0S, shape)
+            alive = self._set_model_output(d, output, base_flags | LP_FL_WRITE_X0S, shape)
             d.x0s = x0s.data_ptr()
             d.phases = LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY
             self._set_xi(d, ws.x_t, want_pre=False)

@@ -26,6 +26,7 @@ import torch
 
 from . import _cabi
 from .lanpaint import LanPaint
+from .types import FusedCFGHeads
 
 try:                                    # ComfyUI present (or stubbed by tests)
     import comfy                        # type: ignore
@@ -55,6 +56,7 @@ except Exception:
     time_shift_slope = None
 
 FLOW_MODEL_TYPES = (getattr(ModelType, "FLOW", "FLOW"), getattr(ModelType, "FLOW_AV", None))
+FUSE_CFG = bool(int(__import__("os").environ.get("LANPAINT_AMD_FUSE_CFG", "1")))   # 0: always run cfg_function eagerly
 
 
 def _require_comfy(what):
@@ -202,6 +204,10 @@ def sampling_function_LanPaint(model, x, timestep, uncond, cond, cond_scale, con
     for fn in model_options.get("sampler_pre_cfg_function", []):
         out = fn({"conds": conds, "conds_out": out, "cond_scale": cond_scale, "timestep": timestep, "input": x,
                   "sigma": timestep, "model": model, "model_options": model_options})
+    if FUSE_CFG and "sampler_cfg_function" not in model_options and not model_options.get("sampler_post_cfg_function"):
+        # stock cfg_function is `uncond + (cond - uncond) * scale`: let the step kernel form both heads
+        # from the one batched pass instead of 2 x 3 eager elementwise launches
+        return FusedCFGHeads(out[0], out[1], cond_scale, cond_scale_BIG)
     cfg = comfy.samplers.cfg_function
     return (cfg(model, out[0], out[1], cond_scale, x, timestep, model_options=model_options, cond=cond, uncond=uncond_),
             cfg(model, out[0], out[1], cond_scale_BIG, x, timestep, model_options=model_options, cond=cond, uncond=uncond_))

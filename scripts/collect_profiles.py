@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Copy the summaries scripts/gpu_profile.sh left under gpurun_out/profiles/ into profiles/rNN_* and
+derive profiles/rNN_pmc_traffic.json (per-launch HBM-side bytes of the steady-state lp_step kernel).
+
+    python scripts/collect_profiles.py 01
+"""
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "profiles")
+DST = os.path.join(ROOT, "profiles")
+N_EL = {"c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c5": ("c5_wan", 2096640)}
+
+
+def steady_mean(path):
+    """mean-per-dispatch (KB) of the steady lp_step kernel (PH = 28) in a --pmc summary."""
+    for line in open(path):
+        m = re.match(r"\| `lp::lp_step_kernel<(\d), false, 28u>.*?` \| (\w+) \| (\d+) \| ([0-9.]+) \|", line)
+        if m:
+            return int(m.group(1)), float(m.group(4)), int(m.group(3))
+    return None
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "01"
+    os.makedirs(DST, exist_ok=True)
+    for f in sorted(os.listdir(SRC)):
+        if f.endswith(".md"):
+            shutil.copy(os.path.join(SRC, f), os.path.join(DST, f"r{rnd}_{f}"))
+        elif f.endswith("_under_rocprof.json.log"):
+            lines = [ln for ln in open(os.path.join(SRC, f)) if ln.startswith("{")]
+            if lines:
+                open(os.path.join(DST, f"r{rnd}_{f[:-4]}"), "w").write(lines[-1])
+    traffic = {"_doc": "HBM-side bytes per launch of the steady-state lp_step kernel from rocprofv3 PMC passes "
+                       "(FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, profiles/r%s_*_pmc_*.md; KB per dispatch). "
+                       "gfx950: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read "
+                       "(MI355X_MICROARCH.md, HBM section; re-checked in the same runs on torch's fp32 x*0.9 kernel, "
+                       "which reads N*4 B and writes N*4 B) -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024." % rnd}
+    for tag, (wl, n_el) in N_EL.items():
+        fe = steady_mean(os.path.join(SRC, f"{tag}_pmc_FETCH_SIZE.md")) if os.path.exists(os.path.join(SRC, f"{tag}_pmc_FETCH_SIZE.md")) else None
+        wr = steady_mean(os.path.join(SRC, f"{tag}_pmc_WRITE_SIZE.md")) if os.path.exists(os.path.join(SRC, f"{tag}_pmc_WRITE_SIZE.md")) else None
+        if not fe or not wr:
+            continue
+        tb = int(round((2 * fe[1] + wr[1]) * 1024))
+        traffic[wl] = {"kernel": f"lp::lp_step_kernel<{fe[0]},false,28>", "FETCH_SIZE_KB": fe[1], "WRITE_SIZE_KB": wr[1],
+                       "dispatches": fe[2], "traffic_bytes_per_launch": tb, "algorithmic_bytes_per_launch": 36 * n_el,
+                       "traffic_over_algorithmic": round(tb / (36 * n_el), 4)}
+    json.dump(traffic, open(os.path.join(DST, f"r{rnd}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps({k: v.get("traffic_over_algorithmic") for k, v in traffic.items() if isinstance(v, dict)}))
+
+
+if __name__ == "__main__":
+    main()

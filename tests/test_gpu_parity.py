@@ -220,3 +220,72 @@ def test_graph_replay_philox_draws_fresh_noise_each_replay():
     assert abs(np.std(res[0]) / np.std(res[1]) - 1.0) < 0.1
     # the trajectory statistics of graph and eager philox runs agree loosely (different streams)
     assert abs(np.std(xg) - np.std(xe)) < 0.25 * np.std(xe)
+
+
+# ------------------------------------------------------------------ CFG combination fused into the step kernel
+@pytest.mark.parametrize("name,dtype", [("ve_basic", "float32"), ("flow_batch", "float32"), ("ve_odd_numel", "float32"),
+                                        ("ve_basic", "bfloat16")])
+def test_fused_cfg_heads_equal_eager_cfg(name, dtype):
+    """A backbone handing back FusedCFGHeads(cond, uncond, s, s_BIG) gives the same trajectory as one
+    that forms `uncond + (cond - uncond) * scale` eagerly (reference nodes.py:161-175)."""
+    import torch
+    from lanpaint_amd import FusedCFGHeads
+    dt = getattr(torch, dtype)
+
+    class Eager(MODELS["linear_tuple"]):
+        def preds(self, x):
+            return (0.9 * x + 0.05).to(dt), (0.7 * x - 0.1).to(dt)
+
+        def __call__(self, x, t, model_options=None, seed=None):
+            self._note(x, t)
+            c, u = self.preds(x)
+            return u + (c - u) * 5.0, u + (c - u) * -0.5
+
+    class Fused(Eager):
+        def __call__(self, x, t, model_options=None, seed=None):
+            self._note(x, t)
+            c, u = self.preds(x)
+            return FusedCFGHeads(c, u, 5.0, -0.5)
+
+    a = run_product_case(name, model_cls=Eager)
+    b = run_product_case(name, model_cls=Fused)
+    assert a["model"].calls == b["model"].calls
+    rel = 2e-5 if dtype == "float32" else 3e-2            # bf16: eager rounds the heads to bf16, fused keeps fp32
+    assert_close(b["x"], a["x"], f"{name}: fused-CFG x", rel=rel, mse=1e-9 if dtype == "float32" else 1e-4)
+    assert_close(b["out"], a["out"], f"{name}: fused-CFG out", rel=rel, mse=1e-9 if dtype == "float32" else 1e-4)
+
+
+def test_engine_in_front_of_dummy_unet_matches_oracle():
+    """A real nn.Module backbone (random-init SD1.5-shaped UNet, fp32 here) with a dual-head output:
+    HIP engine vs CPU oracle driving the SAME network on the same xi stream."""
+    import torch
+    from lanpaint_amd import LanPaint
+    from oracle.lanpaint_oracle import OracleLanPaint, times_from_sigma
+    from tests.dummy_unet import DummyUNetBackbone
+    dev = "cuda"
+    net = DummyUNetBackbone(dev, dtype=torch.float32)
+    rng = np.random.default_rng(4)
+    shape = (1, 4, 16, 16)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    sigma = np.float32([1.2])
+    x = (y + noise * sigma[0]).astype(np.float32)
+    mask = gc.box_mask(shape)
+    times = times_from_sigma(sigma, False)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(5)]
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+
+    def np_model(xn, t, model_options=None, seed=None):      # the oracle calls the same GPU network
+        a, b = net(tt(xn.astype(np.float32)), tt(np.asarray(t, dtype=np.float32)))
+        return a.cpu().numpy(), b.cpu().numpy()
+
+    it = iter(draws)
+    o = OracleLanPaint(np_model, 3, 15.0, 5.0, 1.0, 0.2, randn=lambda like: next(it))
+    xo = x.copy()
+    out_o = o(xo, y, noise, sigma, mask, times, None, 0)
+    it2 = iter([tt(d) for d in draws])
+    eng = LanPaint(net, 3, 15.0, 5.0, 1.0, 0.2, rng=lambda like: next(it2))
+    xg = tt(x)
+    out_g = eng(xg, tt(y), tt(noise), tt(sigma), tt(mask), tuple(tt(t) for t in times), None, 0)
+    assert_close(xg.cpu().numpy(), xo, "dummy-UNet x", rel=1e-4, mse=1e-8)
+    assert_close(out_g.cpu().numpy(), out_o, "dummy-UNet out", rel=1e-4, mse=1e-8)

@@ -136,3 +136,40 @@ def test_reshape_mask_refuses_without_hip(nodes):
         pytest.skip("HIP device present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         nodes.reshape_mask(torch.zeros(4, 4), (1, 4, 8, 8))
+
+
+def test_sampling_function_returns_fused_heads_or_eager_tuple(nodes, monkeypatch):
+    import torch
+    import comfy
+    calls = {"cfg": 0}
+
+    def calc_cond_batch(model, conds, x, timestep, model_options):
+        return [x * 2.0, x * 0.5 if conds[1] is not None else torch.zeros_like(x)]
+
+    def cfg_function(model, cond_pred, uncond_pred, cond_scale, x, timestep, model_options={}, cond=None, uncond=None):
+        calls["cfg"] += 1
+        return uncond_pred + (cond_pred - uncond_pred) * cond_scale
+
+    monkeypatch.setattr(comfy.samplers, "calc_cond_batch", calc_cond_batch, raising=False)
+    monkeypatch.setattr(comfy.samplers, "cfg_function", cfg_function, raising=False)
+    x = torch.arange(6.0).reshape(1, 1, 2, 3)
+    out = nodes.sampling_function_LanPaint(None, x, torch.tensor([1.0]), "neg", "pos", 5.0, -0.5, model_options={})
+    assert isinstance(out, nodes.FusedCFGHeads) and calls["cfg"] == 0
+    x0, x0_big = out                                    # behaves like the reference's tuple
+    assert torch.allclose(x0, x * 0.5 + (x * 2.0 - x * 0.5) * 5.0)
+    assert torch.allclose(x0_big, x * 0.5 + (x * 2.0 - x * 0.5) * -0.5)
+    assert len(out) == 2 and out[0] is x0
+    # custom cfg hooks present -> the eager reference path
+    out2 = nodes.sampling_function_LanPaint(None, x, torch.tensor([1.0]), "neg", "pos", 5.0, -0.5,
+                                            model_options={"sampler_post_cfg_function": [lambda a: a["denoised"]]})
+    assert isinstance(out2, tuple) and calls["cfg"] == 2
+    # cond_scale == 1 drops the uncond pass exactly like the reference (nodes.py:162-165)
+    seen = {}
+    monkeypatch.setattr(comfy.samplers, "calc_cond_batch",
+                        lambda model, conds, x, t, mo: seen.setdefault("conds", conds) and [x, torch.zeros_like(x)], raising=False)
+    nodes.sampling_function_LanPaint(None, x, torch.tensor([1.0]), "neg", "pos", 1.0, 1.0, model_options={})
+    assert seen["conds"] == ["pos", None]
+    seen.clear()
+    nodes.sampling_function_LanPaint(None, x, torch.tensor([1.0]), "neg", "pos", 1.0, 1.0,
+                                     model_options={"disable_cfg1_optimization": True})
+    assert seen["conds"] == ["pos", "neg"]
