@@ -33,9 +33,6 @@ from ._cabi import (LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_PER_ELEMENT, LP_FL_WRITE_
 from .earlystop import LanPaintEarlyStopper
 from .types import FusedCFGHeads, LangevinState
 
-_VOID_NULL = None
-
-
 def _as_f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.to(torch.float32).contiguous()
@@ -366,7 +363,9 @@ class LanPaint:
         self.iterations_run = it0
         self._capturing, self._cap_offset = counter, 0
         try:
-            with torch.cuda.graph(cap.graph, stream=side):
+            # thread_local: a live RCCL communicator's watchdog thread issues HIP calls of its own;
+            # in the default "global" mode those would invalidate this thread's capture
+            with torch.cuda.graph(cap.graph, stream=side, capture_error_mode="thread_local"):
                 cap.out = self.LanPaint(x_s, sig_s, latent_mask, t_s, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
         finally:
             self._capturing = None
@@ -390,6 +389,11 @@ class LanPaint:
         lib, d = self._lib, self._desc
         input_x = x
         flow = bool(IS_FLUX or IS_FLOW)
+        if x.numel() == 0:               # empty batch: only the model-call structure of the reference remains
+            for _ in range(n_steps if float(self.step_size) > 0.0 else 0):
+                self.inner_model(x, sigma, model_options=model_options, seed=seed)
+            out, _ = self.unpack_model_output(self.inner_model(x, sigma, model_options=model_options, seed=seed))
+            return out
         xc = _as_f32c(x)
         shape, n_el, rows = xc.shape, xc.numel(), xc.shape[0]
         ws = self._workspace(xc)
