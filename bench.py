@@ -414,11 +414,12 @@ def extra_lines(args, dev):
                              MinStepFrac=1.0, rng=args.rng, philox_seed=args.seed, graph=bool(args.graph))
     k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 1.0
     denoise_mask = 1.0 - mask
+    model_options = {}                     # ComfyUI hands the SAME dict to every step
 
     def node_pass():
         x = x0.clone()
         for i in range(n_sig):
-            den = k(x, sig_list[i], denoise_mask, model_options={}, seed=args.seed)
+            den = k(x, sig_list[i], denoise_mask, model_options=model_options, seed=args.seed)
             if i + 1 < n_sig:
                 x = x + (x - den) * ratios[i]
         return x

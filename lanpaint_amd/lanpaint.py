@@ -22,12 +22,13 @@ from __future__ import annotations
 
 import ctypes
 import os
+from collections import OrderedDict
 from functools import partial
 
 import torch
 
 from . import _cabi
-from ._cabi import (LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
+from ._cabi import (LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
                     LP_PH_EMIT, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_REPLACE, LP_REPLACE_FLOW,
                     LP_REPLACE_KNOWN, LP_REPLACE_VE)
 from .earlystop import LanPaintEarlyStopper
@@ -85,10 +86,12 @@ class _CapturedCall:
 
 
 class LanPaint:
+    MAX_GRAPHS = 16          # captured sigma calls kept per engine (one per distinct n_steps / tensor set)
+
     # ------------------------------------------------------------------ construction
     def __init__(self, Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX=False, IS_FLOW=False,
                  EarlyStopThreshold=0.0, EarlyStopPatience=1, EarlyStopHook=None, MinStepFrac=0.0,
-                 *, rng=None, philox_seed=None, graph=None):
+                 *, rng=None, philox_seed=None, graph=None, model_dtype=None):
         """Positional signature == reference lanpaint.py:8.  Keyword-only extras:
         rng: "torch" (default; xi = torch.randn_like in the reference's draw order, so a
              seeded run consumes the device generator exactly like the reference),
@@ -101,7 +104,10 @@ class LanPaint:
              bound at image-latent sizes).  Needs a capturable backbone (static shapes, no
              host sync); rng "torch"/"philox" only; ignored (eager launches) when the inner
              early stop, per-element times or method overrides are in play.
-             Env LANPAINT_AMD_GRAPH=1 turns it on by default."""
+             Env LANPAINT_AMD_GRAPH=1 turns it on by default.
+        model_dtype: torch.bfloat16 / torch.float16 -> the latent handed to the backbone inside the
+             think loop is emitted in that dtype by the kernel (no separate cast pass); the state,
+             the written-back x and the arithmetic stay fp32."""
         self.n_steps = NSteps
         self.chara_lamb = Lambda
         self.IS_FLUX = IS_FLUX
@@ -122,7 +128,10 @@ class LanPaint:
         self.philox_seed = philox_seed
         self._philox_offset = 0
         self.graph = bool(int(os.environ.get("LANPAINT_AMD_GRAPH", "0"))) if graph is None else bool(graph)
-        self._graphs = {}                        # key -> _CapturedCall
+        if model_dtype not in (None, torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"model_dtype must be None, float32, bfloat16 or float16, got {model_dtype}")
+        self.model_dtype = None if model_dtype == torch.float32 else model_dtype
+        self._graphs = OrderedDict()             # key -> _CapturedCall, LRU-bounded (MAX_GRAPHS)
         self._rng_counters = {}                  # device -> u64 counter read by captured Philox launches
         self._capturing = None                   # device u64 Philox counter while capturing
         self._cap_offset = 0
@@ -323,6 +332,10 @@ class LanPaint:
         srcs = [x, sigma, current_times[0], current_times[1], current_times[2]]
         if cap is None:
             cap = self._capture(key, srcs, latent_mask, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+            while len(self._graphs) > self.MAX_GRAPHS:       # bound the static memory held by stale captures
+                self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
         stream = self._stream(x.device)
         if all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs):
             # one staging launch in, one out (a foreach copy costs ~11 us on the device for these five)
@@ -402,6 +415,12 @@ class LanPaint:
         nz = _as_f32c(self.noise if self.noise.shape == shape else self.noise.expand(shape))
         m = latent_mask if latent_mask.shape == shape else latent_mask.expand(shape)
         m = _as_f32c(m)
+        # a caller that KNOWS the mask is binary (KSamplerX0Inpaint builds it as 1 - (dm > 0.5)) may attach a
+        # uint8 copy: the kernels then read 1 byte instead of 4 per element for the mask stream
+        m_u8 = getattr(latent_mask, "_lp_u8", None)
+        if m_u8 is not None and not (m_u8.dtype == torch.uint8 and m_u8.shape == shape and m_u8.is_contiguous()
+                                     and m_u8.device == xc.device):
+            m_u8 = None
 
         VE_Sigma, abt, Flow_t = current_times
         replace_sigma = sigma
@@ -417,12 +436,13 @@ class LanPaint:
             per_el = True
 
         # ---- per-call descriptor --------------------------------------------------
-        base_flags = LP_FL_FLOW if flow else 0
+        base_flags = (LP_FL_FLOW if flow else 0) | (LP_FL_MASK_U8 if m_u8 is not None else 0)
         hyp = self._fill_hyper(flow)
         d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
         d.lambda_, d.one_plus_lambda, d.beta = hyp.lambda_, hyp.one_plus_lambda, hyp.beta
         d.step_size, d.min_step_frac = hyp.step_size, hyp.min_step_frac
-        d.y, d.mask, d.x_t, d.C = y.data_ptr(), m.data_ptr(), ws.x_t.data_ptr(), ws.C.data_ptr()
+        d.y, d.x_t, d.C = y.data_ptr(), ws.x_t.data_ptr(), ws.C.data_ptr()
+        d.mask = m_u8.data_ptr() if m_u8 is not None else m.data_ptr()
         d.x0s = None
         d.abt_el = d.ve_el = d.rsig_el = d.corr_el = None
         keep = []          # tensors that must outlive the enqueued launches of this call
@@ -466,15 +486,33 @@ class LanPaint:
         else:        # per-row sigma: the reference emulates the FLOW form elementwise (lanpaint.py:89-92)
             d.replace_kind, d.noise_scale = LP_REPLACE_FLOW, float(getattr(ms, "noise_scale", 1.0))
 
-        # model-space buffer handed to the backbone; fresh per call so the tensor the
-        # final model call saw stays valid after we return
-        x_in = torch.empty_like(xc)
-        d.x_in = x_in.data_ptr()
+        compat = self._overridden("langevin_dynamics") or self._overridden("score_model") or \
+            self._overridden("prepare_step_size")
+        if n_steps > 0 and float(self.step_size) <= 0.0 and not compat:
+            n_steps = 0          # dtx <= 0: every iteration returns immediately (lanpaint.py:205)
+
+        # model-space buffers handed to the backbone; fresh per call so the tensor the final model call
+        # saw stays valid after we return.  x_final (fp32) is the x that is written back in place; with
+        # a half-precision model_dtype the in-loop emits go to a separate buffer in that dtype.
+        x_final = torch.empty_like(xc)
+        if self.model_dtype is None:
+            x_in, xin_flag = x_final, 0
+        else:
+            x_in = torch.empty_like(xc, dtype=self.model_dtype)
+            xin_flag = LP_FL_XIN_BF16 if self.model_dtype == torch.bfloat16 else LP_FL_XIN_F16
+        self._emit_loop = (x_in.data_ptr(), xin_flag)
+        self._emit_final = (x_final.data_ptr(), 0)
+
+        def emit(final):
+            ptr, fl = self._emit_final if final else self._emit_loop
+            d.x_in = ptr
+            return fl
+
         d.x = xc.data_ptr()
         d.xi_post = d.xi_pre = None
         d.rng_offset_ptr = None
         d.rng_seed = int(self.philox_seed if self.philox_seed is not None else (seed or 0)) & 0xFFFFFFFFFFFFFFFF
-        d.flags, d.phases = base_flags, LP_PH_REPLACE | LP_PH_EMIT
+        d.flags, d.phases = base_flags | emit(n_steps == 0), LP_PH_REPLACE | LP_PH_EMIT
         self._launch_step(stream)
 
         # ---- think loop ---------------------------------------------------------------
@@ -486,24 +524,20 @@ class LanPaint:
             model_options=model_options if isinstance(model_options, dict) else None, latent_mask=m, abt=abt,
             default_threshold=self.early_stop_threshold, default_patience=self.early_stop_patience,
             default_distance_fn=self.early_stop_hook)
-        compat = self._overridden("langevin_dynamics") or self._overridden("score_model") or \
-            self._overridden("prepare_step_size")
         ran = 0
-        if n_steps > 0 and float(self.step_size) <= 0.0 and not compat:
-            n_steps = 0          # dtx <= 0: every iteration returns immediately (lanpaint.py:205)
         if compat:
             ran = self._loop_compat(ws, shape, m, y, abt, current_times, n_steps, model_options, seed, stopper)
             d.phases = LP_PH_EMIT
-            d.flags = base_flags
+            d.flags = base_flags | emit(True)
             self._launch_step(stream)
         elif stopper is not None:
             ran = self._loop_unfused(ws, shape, x_in, t_model, base_flags, n_steps, model_options, seed, stopper,
-                                     stream, m, y, current_times)
+                                     stream, m, y, current_times, emit)
         else:
             for i in range(n_steps):
-                alive = self._set_model_output(d, self.inner_model(x_in, t_model, model_options=model_options, seed=seed),
-                                               base_flags, shape)
                 last = i == n_steps - 1
+                alive = self._set_model_output(d, self.inner_model(x_in, t_model, model_options=model_options, seed=seed),
+                                               base_flags | emit(last), shape)
                 d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
                 self._set_xi(d, ws.x_t, want_pre=not last)
                 self._launch_step(stream)
@@ -513,7 +547,8 @@ class LanPaint:
         self.last_inner_steps = ran
 
         # ---- final denoise + known-region reprojection + write-back (lanpaint.py:144-157) ----
-        final = self.inner_model(x_in, sigma, model_options=model_options, seed=seed)
+        x_model = x_final if self.model_dtype is None else x_final.to(self.model_dtype)
+        final = self.inner_model(x_model, sigma, model_options=model_options, seed=seed)
         f = self._fdesc
 
         def dense(t):
@@ -532,10 +567,12 @@ class LanPaint:
         out = torch.empty_like(xc)
         f.n_el = n_el
         f.flags = (LP_FL_X0_BF16 if out_model.dtype == torch.bfloat16 else
-                   LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0) | (LP_FL_CFG_FUSED if uncond is not None else 0)
+                   LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0) | (LP_FL_CFG_FUSED if uncond is not None else 0) \
+            | (LP_FL_MASK_U8 if m_u8 is not None else 0)
         f.uncond = uncond.data_ptr() if uncond is not None else None
-        f.model_out, f.y, f.mask = out_model.data_ptr(), y.data_ptr(), m.data_ptr()
-        f.x_src, f.x_dst, f.out = x_in.data_ptr(), xc.data_ptr(), out.data_ptr()
+        f.model_out, f.y = out_model.data_ptr(), y.data_ptr()
+        f.mask = m_u8.data_ptr() if m_u8 is not None else m.data_ptr()
+        f.x_src, f.x_dst, f.out = x_final.data_ptr(), xc.data_ptr(), out.data_ptr()
         if self._capturing is not None and self.rng == "philox":
             f.rng_bump_ptr, f.rng_bump = self._capturing.data_ptr(), self._cap_offset
         else:
@@ -578,7 +615,7 @@ class LanPaint:
         return buf
 
     def _loop_unfused(self, ws, shape, x_in, t_model, base_flags, n_steps, model_options, seed, stopper, stream, m, y,
-                      current_times):
+                      current_times, emit):
         """Early stop enabled: the stopper decides after every iteration, so the POST
         half of iteration i cannot be fused with the PRE half of iteration i+1."""
         d = self._desc
@@ -587,7 +624,7 @@ class LanPaint:
         for i in range(n_steps):
             x_t_before = ws.x_t.clone() if args is None or stopper.has_custom_distance_fn else None
             if i > 0:
-                d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags
+                d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags | emit(False)
                 self._set_xi(d, ws.x_t, want_pre=True, want_post=False)
                 self._launch_step(stream)
             output = self.inner_model(x_in, t_model, model_options=model_options, seed=seed)
@@ -607,7 +644,7 @@ class LanPaint:
                             prev_args=prev_args, args=args, ctx=ctx):
                 break
         d.x0s = None
-        d.phases, d.flags = LP_PH_EMIT, base_flags
+        d.phases, d.flags = LP_PH_EMIT, base_flags | emit(True)
         self._launch_step(stream)
         return ran
 

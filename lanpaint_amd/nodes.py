@@ -266,7 +266,10 @@ class KSamplerX0Inpaint:
     def _latent_mask(self, denoise_mask):
         key = (denoise_mask.data_ptr(), denoise_mask._version, tuple(denoise_mask.shape))
         if self._mask_cache is None or self._mask_cache[0] != key:
-            self._mask_cache = (key, 1 - (denoise_mask > 0.5).float())          # nodes.py:281-283
+            keep = denoise_mask > 0.5
+            latent_mask = 1 - keep.float()                                      # nodes.py:281-283
+            latent_mask._lp_u8 = (~keep).to(torch.uint8).contiguous()          # binary by construction: 1 B/element stream
+            self._mask_cache = (key, latent_mask)
         return self._mask_cache[1]
 
     def __call__(self, x, sigma, denoise_mask, model_options={}, seed=None, **kwargs):

@@ -289,3 +289,47 @@ def test_engine_in_front_of_dummy_unet_matches_oracle():
     out_g = eng(xg, tt(y), tt(noise), tt(sigma), tt(mask), tuple(tt(t) for t in times), None, 0)
     assert_close(xg.cpu().numpy(), xo, "dummy-UNet x", rel=1e-4, mse=1e-8)
     assert_close(out_g.cpu().numpy(), out_o, "dummy-UNet out", rel=1e-4, mse=1e-8)
+
+
+def test_model_dtype_bf16_emits_half_precision_inputs():
+    """model_dtype=bfloat16: the kernel emits the backbone input in bf16 (no cast pass); state, the
+    written-back x and the arithmetic stay fp32."""
+    import torch
+    seen = []
+
+    class Spy(MODELS["linear_tuple"]):
+        def __call__(self, x, t, model_options=None, seed=None):
+            seen.append(x.dtype)
+            return super().__call__(x.float(), t)
+
+    a = run_product_case("ve_basic")
+    b = run_product_case("ve_basic", model_cls=Spy, model_dtype=torch.bfloat16)
+    assert seen and all(dt == torch.bfloat16 for dt in seen)
+    assert b["x"].dtype == np.float32
+    assert float(np.mean((b["out"] - a["out"]) ** 2)) < 1e-3 and float(np.abs(b["x"] - a["x"]).max()) < 0.15
+    c = run_product_case("ve_n0", model_cls=Spy, model_dtype=torch.float16)       # n_steps = 0: only the final emit
+    g = c["golden"]
+    assert_close(c["x"], g["x_out"], "fp16 model_dtype keeps the written-back x in fp32")
+
+
+def test_uint8_mask_attachment_is_bitwise_equivalent():
+    """A binary mask may travel as uint8 (KSamplerX0Inpaint attaches it): identical results, 1 B/element."""
+    import torch
+    from lanpaint_amd import LanPaint
+    for name in ("ve_basic", "ve_odd_numel", "flow_video5d"):
+        case = gc.build_case(name)
+        g = load_golden(name)
+        outs = []
+        for attach in (False, True):
+            it = iter([torch.from_numpy(d).cuda() for d in xi_list(g)])
+            model = MODELS[case["model"]](flow=case["flow"])
+            eng = LanPaint(model, 5, 15.0, 5.0, 1.0, 0.2, IS_FLOW=case["flow"], rng=lambda like: next(it))
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+            mask = tt(case["mask"])
+            if attach:
+                mask._lp_u8 = mask.to(torch.uint8)
+            x = tt(case["x"].copy())
+            out = eng(x, tt(case["y"]), tt(case["noise"]), tt(case["sigma"]), mask, tuple(tt(t) for t in case["times"]), None, 0)
+            outs.append((x.cpu().numpy(), out.cpu().numpy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert_close(outs[1][0], g["x_out"], f"{name}: u8-mask x")
