@@ -114,7 +114,7 @@ def schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_th
     for i in range(ns):
         den = engine(x, y, noise, sig_list[i], mask, times_list[i], None, 0, n_steps=n_think)
         if i + 1 < ns:
-            x = x + (x - den) * ratios[i]
+            x = torch.addcmul(x, x - den, ratios[i])      # x + (x - den) * r in two launches
     return x
 
 
@@ -421,7 +421,7 @@ def extra_lines(args, dev):
         for i in range(n_sig):
             den = k(x, sig_list[i], denoise_mask, model_options=model_options, seed=args.seed)
             if i + 1 < n_sig:
-                x = x + (x - den) * ratios[i]
+                x = torch.addcmul(x, x - den, ratios[i])
         return x
 
     for _ in range(2):

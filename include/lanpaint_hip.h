@@ -244,6 +244,27 @@ int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_
                     float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
                     int32_t temporal_taps, int32_t binarize, void* stream);
 
+/* Post-decode mask blend (pixel space, once per job):
+ *   m = conv2d(max_pool2d(mask, k, stride 1, pad k/2), gaussian_kernel_2d(k), pad k/2)
+ *   out = image1 * (1 - m) + image2 * m
+ * Replaces MaskBlend.blend_images (nodes.py:610-638) and merge_video_with_mask
+ * (nodes.py:1060-1088, incl. its nearest-exact resample of a lower-resolution mask).
+ * One fused launch: the mask tile (+ 2*(k/2) halo) is staged in LDS, dilated and blurred
+ * separably there (the 2-D Gaussian is the outer product of its normalised 1-D profile),
+ * then the NHWC images are blended.  k odd, 1..51.                                       */
+typedef struct lp_blend_desc {
+    int32_t batch, height, width, channels;   /* images are [batch, height, width, channels] fp32 */
+    int32_t k;                                /* blend_overlap                                  */
+    int32_t mask_batch;                       /* 1 = one mask frame for every image, else == batch */
+    int32_t mask_h, mask_w;                   /* mask resolution (resampled nearest-exact when != image) */
+    const float* mask;                        /* [mask_batch, mask_h, mask_w]                   */
+    const float* image1;
+    const float* image2;
+    float*       out;                         /* [batch, height, width, channels]               */
+    float*       smooth_out;                  /* optional [batch, height, width] smoothed mask  */
+} lp_blend_desc;
+int lp_mask_blend(const lp_blend_desc* desc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

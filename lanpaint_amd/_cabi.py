@@ -67,6 +67,13 @@ class LpCopyDesc(C.Structure):
                 ("dst", C.c_void_p * LP_COPY_MAX)]
 
 
+class LpBlendDesc(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
+                ("k", C.c_int32), ("mask_batch", C.c_int32), ("mask_h", C.c_int32), ("mask_w", C.c_int32),
+                ("mask", C.c_void_p), ("image1", C.c_void_p), ("image2", C.c_void_p), ("out", C.c_void_p),
+                ("smooth_out", C.c_void_p)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "lp_abi_version": (C.c_int, []),
@@ -76,6 +83,7 @@ EXPORTS = {
     "lp_step": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p]),
     "lp_finalize": (C.c_int, [C.POINTER(LpFinalDesc), C.c_void_p]),
     "lp_copy_batch": (C.c_int, [C.POINTER(LpCopyDesc), C.c_void_p]),
+    "lp_mask_blend": (C.c_int, [C.POINTER(LpBlendDesc), C.c_void_p]),
     "lp_timer_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "lp_timer_destroy": (C.c_int, [C.c_void_p]),
     "lp_step_timed": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.c_void_p]),

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["step_kernel.hip", "aux_kernels.hip", "cabi.hip"]
+SOURCES = ["step_kernel.hip", "aux_kernels.hip", "blend_kernel.hip", "cabi.hip"]
 HEADERS = [os.path.join(CSRC, "lp_common.h"), os.path.join(ROOT, "include", "lanpaint_hip.h")]
 OUT = os.path.join(HERE, "liblanpaint_hip.so")
 

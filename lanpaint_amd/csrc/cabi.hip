@@ -13,6 +13,7 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
                     hipStream_t stream);
 int finalize_dispatch(const lp_final_desc* d, hipStream_t stream);
 int copy_batch_dispatch(const lp_copy_desc* d, hipStream_t stream);
+int blend_dispatch(const lp_blend_desc* d, hipStream_t stream);
 int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream);
 int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream);
 int wmse_dispatch(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
@@ -54,6 +55,8 @@ int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer) {
     return lp::step_dispatch(desc, as_stream(stream), timer);
 }
 int lp_timer_elapsed_ns(void* timer, double* ns) { return lp::timer_elapsed_ns(timer, ns); }
+
+int lp_mask_blend(const lp_blend_desc* desc, void* stream) { return lp::blend_dispatch(desc, as_stream(stream)); }
 
 int lp_copy_batch(const lp_copy_desc* desc, void* stream) { return lp::copy_batch_dispatch(desc, as_stream(stream)); }
 

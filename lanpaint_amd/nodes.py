@@ -25,6 +25,7 @@ from contextlib import contextmanager
 import torch
 
 from . import _cabi
+from .blend import MaskBlend, gaussian_kernel_2d, merge_video_with_mask  # noqa: F401
 from .lanpaint import LanPaint
 from .types import FusedCFGHeads
 
@@ -666,8 +667,10 @@ NODE_CLASS_MAPPINGS = {
     "LanPaint_KSamplerAdvanced": LanPaint_KSamplerAdvanced,
     "LanPaint_SamplerCustom": LanPaint_SamplerCustom,
     "LanPaint_SamplerCustomAdvanced": LanPaint_SamplerCustomAdvanced,
+    "LanPaint_MaskBlend": MaskBlend,
 }
 NODE_DISPLAY_NAME_MAPPINGS = {
+    "LanPaint_MaskBlend": "LanPaint Mask Blend",
     "LanPaint_KSampler": "LanPaint KSampler",
     "LanPaint_KSamplerAdvanced": "LanPaint KSampler (Advanced)",
     "LanPaint_SamplerCustom": "LanPaint Sampler Custom",

@@ -23,7 +23,7 @@ the reference's operation order so fp32 rounding follows it closely.
 from __future__ import annotations
 
 import math
-from typing import Any, Callable, NamedTuple, Optional, Sequence, Tuple
+from typing import Any, Callable, NamedTuple, Optional, Sequence
 
 import numpy as np
 
@@ -579,3 +579,68 @@ def region_coefficients(abt: float, step: float, lamb: float, beta: float):
             ent["e_" + tag], ent["k_" + tag], ent["std_" + tag] = e, k, math.sqrt(max(2.0 * k2, 0.0))
         out[r] = ent
     return out
+
+
+# ----------------------------------------------------------------------------
+# post-decode mask blend: nodes.py:592-647, 1049-1088
+# ----------------------------------------------------------------------------
+def gaussian_kernel_2d(kernel_size: int) -> np.ndarray:
+    """nodes.py:1049-1057: sigma = (size-1)/4, normalised to sum 1; identity for size <= 1."""
+    if kernel_size <= 1:
+        return np.ones((1, 1), dtype=np.float32)
+    sigma = (kernel_size - 1) / 4
+    x = np.arange(kernel_size, dtype=np.float32) - (kernel_size // 2)
+    xg, yg = np.meshgrid(x, x, indexing="ij")
+    k = np.exp(-(xg ** 2 + yg ** 2) / np.float32(2 * sigma ** 2)).astype(np.float32)
+    return (k / k.sum(dtype=np.float32)).astype(np.float32)
+
+
+def smooth_mask(mask: np.ndarray, k: int) -> np.ndarray:
+    """max_pool2d(k, stride 1, pad k//2, -inf padding) then conv2d with the Gaussian (zero padding);
+    mask [B, H, W] (nodes.py:625-632, 1080-1087)."""
+    m = np.asarray(mask, dtype=np.float32)
+    b, h, w = m.shape
+    r = k // 2
+    pad = np.full((b, h + 2 * r, w + 2 * r), -np.inf, dtype=np.float32)
+    pad[:, r:r + h, r:r + w] = m
+    d = np.full((b, h, w), -np.inf, dtype=np.float32)
+    for dy in range(k):
+        for dx in range(k):
+            d = np.maximum(d, pad[:, dy:dy + h, dx:dx + w])
+    g = gaussian_kernel_2d(k)
+    zp = np.zeros((b, h + 2 * r, w + 2 * r), dtype=np.float32)
+    zp[:, r:r + h, r:r + w] = d
+    out = np.zeros((b, h, w), dtype=np.float32)
+    for dy in range(g.shape[0]):
+        for dx in range(g.shape[1]):
+            out += g[dy, dx] * zp[:, dy:dy + h, dx:dx + w]
+    return out
+
+
+def mask_blend(image1: np.ndarray, image2: np.ndarray, mask: np.ndarray, blend_overlap: int) -> np.ndarray:
+    """MaskBlend.blend_images, nodes.py:610-638; images [B, H, W, C]."""
+    if image1.shape[1] != image2.shape[1] or image1.shape[2] != image2.shape[2]:
+        raise ValueError("Image size mismatch")
+    m = smooth_mask(mask, blend_overlap)[..., None]
+    return (image1 * (1 - m) + image2 * m).astype(np.float32)
+
+
+def merge_video_with_mask(orig: np.ndarray, inpainted: np.ndarray, mask: np.ndarray, blend_overlap: int) -> np.ndarray:
+    """nodes.py:1060-1088."""
+    m = np.asarray(mask, dtype=np.float32)
+    if m.ndim == 4:
+        m = m[:, 0]
+    elif m.ndim == 2:
+        m = m[None]
+    count = min(orig.shape[0], inpainted.shape[0])
+    orig, inpainted = orig[:count], inpainted[:count]
+    if m.shape[0] == 1:
+        m = np.broadcast_to(m[:1], (count,) + m.shape[1:])
+    elif m.shape[0] < count:
+        raise ValueError("the mask has fewer frames than the image")
+    else:
+        m = m[:count]
+    if tuple(m.shape[1:]) != tuple(orig.shape[1:3]):
+        m = _interp_nearest_exact(m, orig.shape[1:3])
+    sm = smooth_mask(np.ascontiguousarray(m), blend_overlap)[..., None]
+    return (orig * (1 - sm) + inpainted * sm).astype(np.float32)

@@ -166,6 +166,61 @@ def boundary_kat():
                         mses=np.asarray(mses, dtype=np.float64), seed=np.int64(5))
 
 
+def _import_ref_nodes():
+    """The reference's nodes.py with ComfyUI stubbed the way its own tests do (tests/test_reshape_mask.py:18-54)."""
+    import importlib
+    import types
+    comfy_mod = types.ModuleType("comfy")
+    comfy_mod.__path__ = []
+    utils = types.ModuleType("comfy.utils")
+    utils.repeat_to_batch_size = lambda t, b: t
+    samplers = types.ModuleType("comfy.samplers")
+    samplers.KSAMPLER = type("KSAMPLER", (), {})
+    samplers.KSampler = type("KSampler", (), {"SCHEDULERS": ["karras"]})
+    mb = types.ModuleType("comfy.model_base")
+    mb.ModelType = types.SimpleNamespace(FLUX="FLUX", FLOW="FLOW")
+    mb.WAN22 = type("WAN22", (), {})
+    ver = types.ModuleType("comfyui_version")
+    ver.__version__ = "0.6.0"
+    comfy_mod.utils, comfy_mod.samplers, comfy_mod.model_base = utils, samplers, mb
+    for name, mod in (("comfy", comfy_mod), ("comfy.utils", utils), ("comfy.samplers", samplers),
+                      ("comfy.model_base", mb), ("nodes", types.ModuleType("nodes")),
+                      ("latent_preview", types.ModuleType("latent_preview")), ("comfyui_version", ver)):
+        sys.modules[name] = mod
+    return importlib.import_module("src.LanPaint.nodes")
+
+
+def blend_kat():
+    """MaskBlend.blend_images / merge_video_with_mask / gaussian_kernel_2d of the reference
+    (nodes.py:592-647, 1049-1088) on small random images."""
+    ref = _import_ref_nodes()
+    rng = np.random.default_rng(21)
+    rec = {}
+    for idx, (b, h, w, k) in enumerate([(2, 20, 24, 1), (1, 17, 23, 3), (2, 20, 24, 7), (1, 33, 40, 11), (1, 16, 16, 21)]):
+        i1 = rng.random((b, h, w, 3), dtype=np.float32)
+        i2 = rng.random((b, h, w, 3), dtype=np.float32)
+        m = (rng.random((b, h, w)) > 0.8).astype(np.float32)
+        out, = ref.MaskBlend().blend_images(_t(i1), _t(i2), _t(m), k)
+        rec[f"blend{idx}_i1"], rec[f"blend{idx}_i2"], rec[f"blend{idx}_mask"] = i1, i2, m
+        rec[f"blend{idx}_k"], rec[f"blend{idx}_out"] = np.int64(k), out.numpy()
+    for idx, (f, h, w, mh, mw, k, mdim) in enumerate([(3, 20, 24, 20, 24, 5, 3), (4, 24, 32, 12, 16, 7, 3),
+                                                    (2, 16, 16, 16, 16, 3, 4), (3, 18, 22, 9, 11, 9, 2)]):
+        o = rng.random((f, h, w, 3), dtype=np.float32)
+        p = rng.random((f + 1, h, w, 3), dtype=np.float32)
+        if mdim == 2:
+            m = (rng.random((mh, mw)) > 0.7).astype(np.float32)
+        elif mdim == 4:
+            m = (rng.random((f, 1, mh, mw)) > 0.7).astype(np.float32)
+        else:
+            m = (rng.random((f + 2, mh, mw)) > 0.7).astype(np.float32)
+        out = ref.merge_video_with_mask(_t(o), _t(p), _t(m), k)
+        rec[f"merge{idx}_orig"], rec[f"merge{idx}_inp"], rec[f"merge{idx}_mask"] = o, p, m
+        rec[f"merge{idx}_k"], rec[f"merge{idx}_out"] = np.int64(k), out.numpy()
+    for k in (1, 3, 7, 51):
+        rec[f"gauss{k}"] = ref.gaussian_kernel_2d(k).numpy()
+    np.savez_compressed(os.path.join(HERE, "kat_mask_blend.npz"), **rec)
+
+
 def main():
     for name in gc.CASES:
         nd, mc = run_case(name)
@@ -174,6 +229,7 @@ def main():
         print(f"{name:24s} draws={run_schedule(name)}")
     coefficient_kat()
     boundary_kat()
+    blend_kat()
 
 
 if __name__ == "__main__":

@@ -1,8 +1,6 @@
 """The reference's own unit tests, re-run against lanpaint_amd on the GPU (same stubs, same
 assertions): tests/test_sho_regression.py, test_lanpaint_semantic_stop.py, test_av_schedule.py,
 test_reshape_mask.py, test_videomask.py:475-713 -- plus the KSamplerX0Inpaint sampler callable."""
-import types
-
 import numpy as np
 import pytest
 

@@ -7,8 +7,7 @@ import pytest
 
 from oracle import lanpaint_oracle as orc
 from tests import golden_cases as gc
-from tests.helpers import assert_close, run_product_case
-from tests.stubs import MODELS
+from tests.helpers import run_product_case
 
 pytestmark = pytest.mark.gpu
 
@@ -127,7 +126,6 @@ def test_fused_in_kernel_noise_equals_host_supplied_philox(lib, name):
         calls.append((launch, slot))
         return _philox(lib, like.numel(), seed, (1 << 48) + launch, slot).reshape(like.shape)
 
-    import lanpaint_amd  # noqa: F401
     host = run_product_case(name, rng=host_xi, philox_seed=seed)
     assert len(calls) == max(0, 2 * n_steps - 1)
     assert np.array_equal(fused["x"], host["x"]) and np.array_equal(fused["out"], host["out"])
@@ -186,3 +184,52 @@ def test_reshape_mask_kernel_bit_exact(lib, src_shape, out_shape, video):
     got = reshape_mask(tt(m), out_shape, video_inpainting=video)
     assert tuple(got.shape) == tuple(out_shape)
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------- post-decode mask blend
+def test_mask_blend_matches_reference_golden(lib):
+    import torch
+    from lanpaint_amd import blend
+    from tests.helpers import load_golden
+    g = load_golden("kat_mask_blend")
+    for idx in range(5):
+        out = blend.mask_blend(tt(g[f"blend{idx}_i1"]), tt(g[f"blend{idx}_i2"]), tt(g[f"blend{idx}_mask"]), int(g[f"blend{idx}_k"]))
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"blend{idx}_out"], atol=3e-6)
+    for idx in range(4):
+        out = blend.merge_video_with_mask(tt(g[f"merge{idx}_orig"]), tt(g[f"merge{idx}_inp"]), tt(g[f"merge{idx}_mask"]),
+                                          int(g[f"merge{idx}_k"]))
+        assert tuple(out.shape) == g[f"merge{idx}_out"].shape
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"merge{idx}_out"], atol=3e-6)
+    for k in (1, 3, 7, 51):
+        np.testing.assert_allclose(blend.gaussian_kernel_2d(k).numpy(), g[f"gauss{k}"], rtol=1e-6)
+    node_out, = blend.MaskBlend().blend_images(torch.from_numpy(g["blend2_i1"]), torch.from_numpy(g["blend2_i2"]),
+                                               torch.from_numpy(g["blend2_mask"]), 7)       # CPU tensors in, like ComfyUI
+    assert node_out.device.type == "cpu"
+    np.testing.assert_allclose(node_out.numpy(), g["blend2_out"], atol=3e-6)
+    with pytest.raises(ValueError):
+        blend.mask_blend(tt(g["blend0_i1"]), tt(g["blend1_i1"]), tt(g["blend0_mask"]), 3)
+    with pytest.raises(ValueError):
+        blend.mask_blend(tt(g["blend0_i1"]), tt(g["blend0_i2"]), tt(g["blend0_mask"]), 4)
+
+
+@pytest.mark.parametrize("shape,k", [((1, 64, 64, 3), 51), ((2, 70, 130, 4), 9), ((1, 1, 1, 3), 3), ((1, 1080, 1920, 3), 15),
+                                     ((3, 37, 53, 1), 21)])
+def test_mask_blend_matches_oracle_across_tiles(lib, shape, k):
+    """Tile seams, halos wider than the image, both tile geometries, full-HD size."""
+    from lanpaint_amd import blend
+    rng = np.random.default_rng(k)
+    b, h, w, c = shape
+    i1, i2 = rng.random(shape, dtype=np.float32), rng.random(shape, dtype=np.float32)
+    m = (rng.random((b, h, w)) > 0.9).astype(np.float32)
+    got, smooth = blend._launch(tt(m), tt(i1), tt(i2), k, want_smooth=True)
+    if h * w <= 70 * 130:
+        want_smooth = orc.smooth_mask(m, k)
+        np.testing.assert_allclose(smooth.cpu().numpy(), want_smooth, atol=3e-6)
+        np.testing.assert_allclose(got.cpu().numpy(), orc.mask_blend(i1, i2, m, k), atol=3e-6)
+    else:       # full HD: the oracle's k^2 loops are too slow; check a crop that contains a tile seam and an image edge
+        crop = (slice(None), slice(0, 96), slice(1800, 1920))
+        want = orc.smooth_mask(m[:, :96 + k, 1800 - k:], k)[:, :96, k:]
+        np.testing.assert_allclose(smooth.cpu().numpy()[crop], want, atol=3e-6)
+        s = smooth.cpu().numpy()[..., None]
+        np.testing.assert_allclose(got.cpu().numpy(), i1 * (1 - s) + i2 * s, atol=1e-6)
+        assert 0.0 <= s.min() and s.max() <= 1.0 + 1e-5

@@ -72,7 +72,9 @@ def test_retired_params_hidden_and_widgets_kept(nodes):
                  "Inpainting_mode"):
         assert name in req
     assert set(nodes.NODE_CLASS_MAPPINGS) == {"LanPaint_KSampler", "LanPaint_KSamplerAdvanced", "LanPaint_SamplerCustom",
-                                              "LanPaint_SamplerCustomAdvanced"}
+                                              "LanPaint_SamplerCustomAdvanced", "LanPaint_MaskBlend"}
+    mb = nodes.NODE_CLASS_MAPPINGS["LanPaint_MaskBlend"]
+    assert mb.FUNCTION == "blend_images" and mb.INPUT_TYPES()["required"]["blend_overlap"][1]["max"] == 51
     assert nodes.LanPaint_KSampler.INPUT_TYPES()["required"]["LanPaint_NumSteps"][1]["default"] == 5
 
 

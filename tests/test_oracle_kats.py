@@ -186,3 +186,21 @@ def test_times_from_sigma_forms():
     assert float(ft[0]) == pytest.approx(math.sqrt(0.8) / (math.sqrt(0.8) + math.sqrt(0.2)))
     ve, abt, ft = orc.times_from_sigma(np.float32([0.5]), True)
     assert float(abt[0]) == pytest.approx(0.5) and float(ve[0]) == pytest.approx(1.0) and float(ft[0]) == 0.5
+
+
+# --- post-decode mask blend (reference nodes.py:592-647, 1049-1088) ------------------------
+def test_mask_blend_and_video_merge_match_reference():
+    g = load_golden("kat_mask_blend")
+    for k in (1, 3, 7, 51):
+        np.testing.assert_allclose(orc.gaussian_kernel_2d(k), g[f"gauss{k}"], rtol=2e-6, atol=1e-12)
+    for idx in range(5):
+        out = orc.mask_blend(g[f"blend{idx}_i1"], g[f"blend{idx}_i2"], g[f"blend{idx}_mask"], int(g[f"blend{idx}_k"]))
+        np.testing.assert_allclose(out, g[f"blend{idx}_out"], atol=2e-6)
+    for idx in range(4):
+        out = orc.merge_video_with_mask(g[f"merge{idx}_orig"], g[f"merge{idx}_inp"], g[f"merge{idx}_mask"],
+                                        int(g[f"merge{idx}_k"]))
+        assert out.shape == g[f"merge{idx}_out"].shape
+        np.testing.assert_allclose(out, g[f"merge{idx}_out"], atol=2e-6)
+    with pytest.raises(ValueError):
+        orc.merge_video_with_mask(np.zeros((4, 8, 8, 3), np.float32), np.zeros((4, 8, 8, 3), np.float32),
+                                  np.zeros((2, 8, 8), np.float32), 3)
