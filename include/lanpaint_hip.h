@@ -181,6 +181,15 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
               const float* replace_sigma, int rs_stride, const float* step_override, int step_stride,
               int rows, float* coef_table, void* stream);
 
+/* K1a  sigma -> (VE_sigma, abt, flow_t) per batch row plus the two scalars the inner-step rule needs,
+ * in ONE launch.  Replaces the ~15 eager scalar ops + 2 host syncs of KSamplerX0Inpaint.__call__
+ * (nodes.py:242-252 times, :286 argmin over the schedule, :299 mean(1 - abt)); every operation is a
+ * separately rounded fp32 op in the reference's order (no FMA contraction), so n_eff decisions match.
+ * times_out: [3][rows] = VE_sigma, abt, flow_t.  scalars_out: [2] = { index of the schedule entry
+ * closest to mean(sigma) (first minimum), mean(1 - abt) }.                                        */
+int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
+                   float* times_out, float* scalars_out, void* stream);
+
 /* K0 / K_first / K2  the fused step (phases select the work).
  * Replaces: lanpaint.py:94-99 (REPLACE), :159-184 + :212-220 (score split + Coef_C),
  *           :232-254 (exact OU + noise injection), :274-286 (the scheme),

@@ -80,6 +80,7 @@ EXPORTS = {
     "lp_strerror": (C.c_char_p, [C.c_int]),
     "lp_coeffs": (C.c_int, [C.POINTER(LpHyper), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "lp_sigma_times": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_step": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p]),
     "lp_finalize": (C.c_int, [C.POINTER(LpFinalDesc), C.c_void_p]),
     "lp_copy_batch": (C.c_int, [C.POINTER(LpCopyDesc), C.c_void_p]),

@@ -76,6 +76,71 @@ __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int v
     }
 }
 
+// ---------------------------------------------------------------------------------
+// K1a: per-sigma scalar algebra of KSamplerX0Inpaint.__call__ (nodes.py:242-252, 286-299).
+// One thread: B and the schedule are tiny.  __f*_rn keep every op separately rounded like the
+// reference's eager fp32 tensor ops (an FMA here could flip a round() in the n_eff rule).
+// ---------------------------------------------------------------------------------
+__global__ void lp_sigma_times_kernel(const float* __restrict__ sigma, int rows, const float* __restrict__ schedule,
+                                      int schedule_len, int is_flow, float* __restrict__ times,
+                                      float* __restrict__ scalars) {
+    // plain operators under `fp contract(off)`: every * + - / below is rounded on its own, like the
+    // reference's eager tensor ops (HIP's __fmul_rn/__fadd_rn are inline wrappers whose bodies keep the
+    // default contract(fast) flags and DO get fused into an FMA after inlining -- measured: 1 ulp off)
+#pragma clang fp contract(off)
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float sum_sigma = 0.0f, sum_oma = 0.0f;
+    for (int r = 0; r < rows; ++r) {
+        const float s = sigma[r];
+        float ve, abt, ft;
+        if (is_flow) {                                               // nodes.py:243-245
+            const float a = 1.0f - s;
+            const float a2 = a * a;
+            const float s2 = s * s;
+            const float den = a2 + s2;
+            abt = a2 / den;
+            ve = s / a;
+            ft = s;
+        } else {                                                     // nodes.py:250-252
+            ve = s;
+            const float s2 = s * s;
+            const float den = 1.0f + s2;
+            abt = 1.0f / den;
+            const float b = 1.0f - abt;
+            const float sb = sqrtf(b), sa = sqrtf(abt);
+            const float sden = sb + sa;
+            ft = sb / sden;
+        }
+        times[r] = ve;
+        times[rows + r] = abt;
+        times[2 * rows + r] = ft;
+        sum_sigma = sum_sigma + s;
+        const float oma = 1.0f - abt;
+        sum_oma = sum_oma + oma;
+    }
+    const float mean_sigma = sum_sigma / static_cast<float>(rows);
+    int best = 0;
+    float best_d = INFINITY;
+    for (int i = 0; i < schedule_len; ++i) {                         // first minimum, like torch.argmin
+        const float diff = schedule[i] - mean_sigma;
+        const float dd = fabsf(diff);
+        if (dd < best_d) {
+            best_d = dd;
+            best = i;
+        }
+    }
+    scalars[0] = static_cast<float>(best);
+    scalars[1] = sum_oma / static_cast<float>(rows);
+}
+
+int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow,
+                         float* times, float* scalars, hipStream_t stream) {
+    if (!sigma || !schedule || !times || !scalars || rows <= 0 || schedule_len <= 0) return LP_E_INVALID;
+    hipLaunchKernelGGL(lp_sigma_times_kernel, dim3(1), dim3(64), 0, stream, sigma, rows, schedule, schedule_len, is_flow,
+                       times, scalars);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
 int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const float* abt, int abt_stride,
                     const float* rs, int rs_stride, const float* step_ov, int step_stride, int rows, float* table,
                     hipStream_t stream) {

@@ -12,6 +12,8 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
                     const float* rs, int rs_stride, const float* step_ov, int step_stride, int rows, float* table,
                     hipStream_t stream);
 int finalize_dispatch(const lp_final_desc* d, hipStream_t stream);
+int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow, float* times,
+                         float* scalars, hipStream_t stream);
 int copy_batch_dispatch(const lp_copy_desc* d, hipStream_t stream);
 int blend_dispatch(const lp_blend_desc* d, hipStream_t stream);
 int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream);
@@ -44,6 +46,11 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
               float* coef_table, void* stream) {
     return lp::coeffs_dispatch(hyper, ve_sigma, ve_stride, abt, abt_stride, replace_sigma, rs_stride, step_override,
                                step_stride, rows, coef_table, as_stream(stream));
+}
+
+int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
+                   float* times_out, float* scalars_out, void* stream) {
+    return lp::sigma_times_dispatch(sigma, rows, schedule, schedule_len, is_flow, times_out, scalars_out, as_stream(stream));
 }
 
 int lp_step(const lp_step_desc* desc, void* stream) { return lp::step_dispatch(desc, as_stream(stream), nullptr); }

@@ -277,7 +277,20 @@ class KSamplerX0Inpaint:
         model_type = self.inner_model.inner_model.model_type
         IS_FLUX = model_type == ModelType.FLUX
         IS_FLOW = model_type in FLOW_MODEL_TYPES
-        if IS_FLUX or IS_FLOW:                                              # nodes.py:242-245
+        fused_scalars = None
+        if (sigma.is_cuda and sigma.dtype == torch.float32 and sigma.ndim == 1 and self.sigmas.is_cuda
+                and self.sigmas.dtype == torch.float32 and self.sigmas.device == sigma.device):
+            # one launch: the three time tensors AND the two scalars of the inner-step rule (lp_sigma_times)
+            sig_c, sched = sigma.contiguous(), self.sigmas.contiguous()
+            rows = sig_c.shape[0]
+            buf = torch.empty((3 * rows + 2,), dtype=torch.float32, device=sigma.device)
+            with torch.cuda.device(sigma.device):
+                _cabi.check(_cabi.load().lp_sigma_times(
+                    sig_c.data_ptr(), rows, sched.data_ptr(), sched.numel(), int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
+                    buf[3 * rows:].data_ptr(), torch.cuda.current_stream(sigma.device).cuda_stream), "lp_sigma_times")
+            VE_Sigma, abt, Flow_t = buf[:rows], buf[rows:2 * rows], buf[2 * rows:3 * rows]
+            fused_scalars = buf[3 * rows:]
+        elif IS_FLUX or IS_FLOW:                                            # nodes.py:242-245
             Flow_t = sigma
             abt = (1 - Flow_t) ** 2 / ((1 - Flow_t) ** 2 + Flow_t ** 2)
             VE_Sigma = Flow_t / (1 - Flow_t)
@@ -305,8 +318,11 @@ class KSamplerX0Inpaint:
             current_times = (VE_Sigma, abt, Flow_t)
             # nodes.py:286-299.  Same device arithmetic as the reference; its two host syncs
             # (argmin -> int compare, float(mean)) are fetched with ONE device->host read.
-            current_step = torch.argmin(torch.abs(self.sigmas - torch.mean(sigma)))
-            step_f, frac = torch.stack([current_step.to(torch.float32), (1.0 - abt).mean().to(torch.float32)]).tolist()
+            if fused_scalars is not None:
+                step_f, frac = fused_scalars.tolist()
+            else:
+                current_step = torch.argmin(torch.abs(self.sigmas - torch.mean(sigma)))
+                step_f, frac = torch.stack([current_step.to(torch.float32), (1.0 - abt).mean().to(torch.float32)]).tolist()
             total_steps = len(self.sigmas) - 1
             n_eff = self.PaintMethod.n_steps
             if total_steps - int(step_f) <= self.LanPaint_early_stop:

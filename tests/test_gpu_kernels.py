@@ -233,3 +233,45 @@ def test_mask_blend_matches_oracle_across_tiles(lib, shape, k):
         s = smooth.cpu().numpy()[..., None]
         np.testing.assert_allclose(got.cpu().numpy(), i1 * (1 - s) + i2 * s, atol=1e-6)
         assert 0.0 <= s.min() and s.max() <= 1.0 + 1e-5
+
+
+# ---------------------------------------------------------------- K1a sigma -> times + inner-step scalars
+@pytest.mark.parametrize("flow", [False, True])
+def test_sigma_times_bit_exact_vs_reference_cpu_ops(lib, flow):
+    """lp_sigma_times reproduces the reference's eager fp32 tensor ops (nodes.py:242-252, 286, 299) bit for
+    bit as the reference's CPU path evaluates them (IEEE-correct division / sqrt).  torch's own GPU kernels
+    use the hardware reciprocal for `1 / t`, so against them the match is to 2 ulp."""
+    import torch
+    from lanpaint_amd import _cabi
+    sched_cpu = torch.from_numpy(np.concatenate([gc.flow_sigmas(30)[:-1] if flow else gc.karras_sigmas(30)[:-1], [0.0]]).astype(np.float32))
+    sched = sched_cpu.cuda()
+    probes = list(sched_cpu[:-1].tolist()) + [0.37, 0.62, 0.05] + ([] if flow else [3.3, 11.0])
+
+    def ref_ops(sigma):
+        if flow:
+            ft = sigma
+            abt = (1 - ft) ** 2 / ((1 - ft) ** 2 + ft ** 2)
+            return ft / (1 - ft), abt, ft
+        abt = 1 / (1 + sigma ** 2)
+        return sigma, abt, (1 - abt) ** 0.5 / ((1 - abt) ** 0.5 + abt ** 0.5)
+
+    for rows in (1, 4):
+        for sv in probes:
+            sigma_cpu = torch.full((rows,), sv, dtype=torch.float32)
+            sigma = sigma_cpu.cuda()
+            buf = torch.empty(3 * rows + 2, dtype=torch.float32, device="cuda")
+            _cabi.check(lib.lp_sigma_times(sigma.data_ptr(), rows, sched.data_ptr(), sched.numel(), int(flow), buf.data_ptr(),
+                                           buf[3 * rows:].data_ptr(), _stream()))
+            got = buf.cpu()
+            ve, abt, ft = ref_ops(sigma_cpu)
+            assert torch.equal(got[:rows], ve) and torch.equal(got[rows:2 * rows], abt), sv     # what n_eff and the kernels consume
+            if flow:
+                assert torch.equal(got[2 * rows:3 * rows], ft), sv
+            else:   # VE: flow_t is informational (unused by a VE engine); torch's CPU pow(x, 0.5) is not always sqrt-exact
+                torch.testing.assert_close(got[2 * rows:3 * rows], ft, rtol=2.5e-7, atol=0)
+            assert int(got[3 * rows]) == int(torch.argmin(torch.abs(sched_cpu - torch.mean(sigma_cpu))))
+            assert float(got[3 * rows + 1]) == pytest.approx(float((1.0 - abt).mean()), rel=2e-7)
+            if rows == 1:
+                assert float(got[3 * rows + 1]) == float((1.0 - abt).mean())
+            for a, b in zip(ref_ops(sigma), (got[:rows], got[rows:2 * rows], got[2 * rows:3 * rows])):
+                torch.testing.assert_close(a.cpu(), b, rtol=2.5e-7, atol=0)
