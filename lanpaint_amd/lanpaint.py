@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from collections import OrderedDict
 from functools import partial
 
@@ -140,7 +141,8 @@ class LanPaint:
         self._desc = _cabi.LpStepDesc()
         self._fdesc = _cabi.LpFinalDesc()
         self._hyper = _cabi.LpHyper()
-        self._noise_check = None                 # (data_ptr, version, numel) -> bool cache
+        self._noise_check = None                 # (weakref(noise), version, verdict)
+        self._noise_regenerated = False
         self.iterations_run = 0                  # think iterations executed (it/s accounting)
         self.last_inner_steps = 0
 
@@ -217,12 +219,13 @@ class LanPaint:
         return torch.cuda.current_stream(device).cuda_stream
 
     def _noise_is_zero(self, noise):
-        """lanpaint.py:51: `mean|noise| < 1e-8` costs the reference one host sync per
-        sigma; the verdict is cached on (storage, version) so it is paid once."""
-        key = (noise.data_ptr(), noise._version, noise.numel())
-        if self._noise_check is None or self._noise_check[0] != key:
-            self._noise_check = (key, bool(torch.mean(torch.abs(noise)) < 1e-8))
-        return self._noise_check[1]
+        """lanpaint.py:51: `mean|noise| < 1e-8` costs the reference one host sync per sigma; the verdict is
+        cached per tensor OBJECT and version (a weak reference, not the address: the caching allocator
+        recycles addresses), so it is paid once per sampling run."""
+        c = self._noise_check
+        if c is None or c[0]() is not noise or c[1] != noise._version:
+            self._noise_check = c = (weakref.ref(noise), noise._version, bool(torch.mean(torch.abs(noise)) < 1e-8))
+        return c[2]
 
     def _draw(self, like):
         """One N(0,1) tensor in the reference's draw order (lanpaint.py:252), or None
@@ -296,7 +299,8 @@ class LanPaint:
         self.audio_indicator = audio_indicator
         self.current_times_audio = current_times_audio
         self.audio_correction = audio_correction
-        if self._noise_is_zero(noise):           # lanpaint.py:51-52: the first draw of the call
+        self._noise_regenerated = self._noise_is_zero(noise)
+        if self._noise_regenerated:              # lanpaint.py:51-52: the first draw of the call
             self.noise = self.rng(noise) if callable(self.rng) else torch.randn_like(noise)
         if n_steps is None:
             n_steps = self.n_steps
@@ -309,8 +313,8 @@ class LanPaint:
 
     # ------------------------------------------------------------------ hipGraph replay of one sigma call
     def _graph_eligible(self, x, model_options):
-        if not self.graph or callable(self.rng):
-            return False
+        if not self.graph or callable(self.rng) or self._noise_regenerated:
+            return False         # (regenerated noise is a fresh tensor per call: nothing stable to bake into a graph)
         if self.audio_indicator is not None or self.audio_correction is not None:
             return False
         if self.early_stop_threshold > 0.0 and self.early_stop_patience > 0:
@@ -325,9 +329,11 @@ class LanPaint:
     def _call_graphed(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
         """Stage the per-call inputs into the captured call's static buffers, replay, hand
         back a fresh `out` and the in-place-updated x (same contract as the eager path)."""
+        # every pointer the capture bakes in is part of the key (the tensors themselves are the caller's)
+        m_u8 = getattr(latent_mask, "_lp_u8", None)
         key = (tuple(x.shape), x.device.index, int(n_steps), bool(IS_FLUX), bool(IS_FLOW), self.latent_image.data_ptr(),
-               self.noise.data_ptr(), latent_mask.data_ptr(), tuple(sigma.shape), tuple(tuple(t.shape) for t in current_times),
-               id(model_options), seed, self.rng)
+               self.noise.data_ptr(), latent_mask.data_ptr(), m_u8.data_ptr() if m_u8 is not None else 0,
+               tuple(sigma.shape), tuple(tuple(t.shape) for t in current_times), id(model_options), seed, self.rng)
         cap = self._graphs.get(key)
         srcs = [x, sigma, current_times[0], current_times[1], current_times[2]]
         if cap is None:

@@ -20,6 +20,7 @@ Image/mask utility nodes, the AV encode/decode nodes and the video-mask editor a
 from __future__ import annotations
 
 import math
+import weakref
 from contextlib import contextmanager
 
 import torch
@@ -262,16 +263,18 @@ class KSamplerX0Inpaint:
         self.sigmas = sigmas
         self.audio_indicator = None
         self.audio_shifts = None
-        self._mask_cache = None          # (data_ptr, version, shape) -> latent_mask: binarised once per run
+        self._mask_cache = None          # (weakref(denoise_mask), version, latent_mask): binarised once per run
 
     def _latent_mask(self, denoise_mask):
-        key = (denoise_mask.data_ptr(), denoise_mask._version, tuple(denoise_mask.shape))
-        if self._mask_cache is None or self._mask_cache[0] != key:
+        """nodes.py:281-283, computed once per mask tensor OBJECT + version (weak reference: a
+        denoise_mask_function may hand back a fresh tensor at a recycled address every step)."""
+        c = self._mask_cache
+        if c is None or c[0]() is not denoise_mask or c[1] != denoise_mask._version:
             keep = denoise_mask > 0.5
-            latent_mask = 1 - keep.float()                                      # nodes.py:281-283
+            latent_mask = 1 - keep.float()
             latent_mask._lp_u8 = (~keep).to(torch.uint8).contiguous()          # binary by construction: 1 B/element stream
-            self._mask_cache = (key, latent_mask)
-        return self._mask_cache[1]
+            self._mask_cache = c = (weakref.ref(denoise_mask), denoise_mask._version, latent_mask)
+        return c[2]
 
     def __call__(self, x, sigma, denoise_mask, model_options={}, seed=None, **kwargs):
         model_type = self.inner_model.inner_model.model_type

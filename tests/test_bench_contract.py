@@ -1,0 +1,46 @@
+"""bench.py's contract pieces that do not need a GPU: workload table, schedules, the cpu_baseline leg
+(bounded sample, JSON-able dict), traffic lookup, and that bench/smoke are the only non-test users of oracle/."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_workloads_match_baseline_configs():
+    import bench
+    assert bench.WORKLOADS["c2_sdxl"] == ((1, 4, 128, 128), False, 30, 5)
+    assert bench.WORKLOADS["c1_sd15"] == ((1, 4, 64, 64), False, 20, 5)
+    assert bench.WORKLOADS["c3_sdxl_b4"][0] == (4, 4, 128, 128)
+    assert bench.WORKLOADS["c4_flux"] == ((1, 16, 64, 64), True, 28, 10)
+    assert bench.WORKLOADS["c5_wan"] == ((1, 16, 21, 60, 104), True, 30, 5)
+    s = bench.karras_sigmas(30)
+    assert len(s) == 30 and abs(s[0] - 14.6146) < 1e-3 and abs(s[-1] - 0.0292) < 1e-4 and all(a > b for a, b in zip(s, s[1:]))
+    f = bench.flow_sigmas(28)
+    assert len(f) == 28 and 0 < f[-1] < f[0] < 1.0
+    assert bench.BYTES_PER_EL_STEADY == 36 and bench.HBM_PEAK_GBPS == 8000.0
+
+
+def test_cpu_baseline_leg_is_bounded_and_json_serialisable():
+    import bench
+    out = bench.cpu_baseline("c1_sd15", 0.6)
+    json.dumps(out)
+    assert out["kind"] == "port" and out["unit"] == "think-iterations/s" and out["value"] > 0 and out["cores"] >= 1
+    assert "oracle/lanpaint_oracle.py" in out["sample"]
+
+
+def test_pmc_traffic_lookup_reads_committed_profile():
+    import bench
+    t = bench.pmc_traffic("c2_sdxl")
+    assert t is None or 0.9 * 36 * 65536 < t < 1.3 * 36 * 65536
+    assert bench.pmc_traffic("no_such_workload") is None
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lanpaint_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "liblanpaint_oracle" not in src, f

@@ -205,3 +205,40 @@ def test_graph_capture_with_live_process_group():
         assert len(eng._graphs) == 1 and torch.isfinite(out).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_full_c2_schedule_mse_below_target():
+    """BASELINE.json's acceptance number, literally: the whole C2 schedule (SDXL 1x4x128x128, 30 Karras
+    sigmas x 5 think iterations, Euler sampler between sigmas) on the HIP path vs the CPU oracle on the same
+    xi stream: MSE of the final latent and of every denoised output < 1e-5 (measured: ~1e-11)."""
+    import torch
+    from lanpaint_amd import LanPaint
+    shape, n_sig, n_think = (1, 4, 128, 128), 30, 5
+    sig = gc.karras_sigmas(n_sig)[:-1]
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    mask = gc.box_mask(shape)
+    x = (y + noise * sig[0]).astype(np.float32)
+    xi_rng_o, xi_rng_g = np.random.default_rng(9), np.random.default_rng(9)
+    o = OracleLanPaint(MODELS["linear_tuple"](), n_think, 15.0, 5.0, 1.0, 0.2,
+                       randn=lambda like: xi_rng_o.standard_normal(like.shape, dtype=np.float32))
+    eng = LanPaint(MODELS["linear_tuple"](), n_think, 15.0, 5.0, 1.0, 0.2,
+                   rng=lambda like: tt(xi_rng_g.standard_normal(tuple(like.shape), dtype=np.float32)))
+    xo, xg = x.copy(), tt(x)
+    yg, ng, mg = tt(y), tt(noise), tt(mask)
+    worst = 0.0
+    for i in range(n_sig):
+        s = np.float32([sig[i]])
+        times = times_from_sigma(s, False)
+        den_o = o(xo, y, noise, s, mask, times, None, 0)
+        den_g = eng(xg, yg, ng, tt(s), mg, tuple(tt(t) for t in times), None, 0)
+        worst = max(worst, float(np.mean((den_g.cpu().numpy().astype(np.float64) - den_o) ** 2)))
+        if i + 1 < n_sig:
+            r = np.float32((sig[i + 1] - sig[i]) / sig[i])
+            xo = (xo + (xo - den_o) * r).astype(np.float32)
+            xg = xg + (xg - den_g) * float(r)
+    mse_x = float(np.mean((xg.cpu().numpy().astype(np.float64) - xo) ** 2))
+    assert eng.iterations_run == o.iterations_run == n_sig * n_think
+    assert worst < 1e-5 and mse_x < 1e-5, (worst, mse_x)
+    assert worst < 1e-9 and mse_x < 1e-9, (worst, mse_x)       # what the build actually achieves
