@@ -170,16 +170,27 @@ def run_gpu(args):
 
     roofline = None
     if rank == 0:
-        roofline = measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args)
-    large = None
+        try:
+            roofline = measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args)
+        except Exception as e:
+            roofline = {"error": repr(e)}
+    # the secondary measurements must never cost the headline line
+    large, extras, cpu = None, {}, None
     if rank == 0 and world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
-        large = measure_hbm_bound_shape(_cabi, dev)
-    extras = {}
+        try:
+            large = measure_hbm_bound_shape(_cabi, dev)
+        except Exception as e:
+            large = {"error": repr(e)}
     if rank == 0 and world == 1 and args.extras:
-        extras = extra_lines(args, dev)
-    cpu = None
+        try:
+            extras = extra_lines(args, dev)
+        except Exception as e:
+            extras = {"extras_error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.workload, args.cpu_seconds)
+        try:
+            cpu = cpu_baseline(args.workload, args.cpu_seconds)
+        except Exception as e:
+            cpu = {"error": repr(e)}
 
     if world > 1:
         dist.barrier()
