@@ -285,8 +285,10 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
     mean_s = float(durs.mean())
     achieved = bytes_per_launch / mean_s / 1e9
     burst_us = graph_burst_us_per_launch(_cabi, args.workload, x0.device)
+    busy = measure_hbm_bound_shape(_cabi, x0.device, workload=args.workload, launches=120)   # same timers, GPU kept busy
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
+            "timed_back_to_back_mean_us": busy["mean_launch_us"], "timed_back_to_back_GBps": busy["achieved"],
             "graph_burst_us_per_launch": burst_us,
             "graph_burst_GBps": bytes_per_launch / burst_us / 1e3,
             "kernel": "lp::lp_step_kernel<VEC,false,POST_STEADY|PRE_HALF|EMIT> (steady-state think step; "
