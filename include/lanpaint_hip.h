@@ -242,10 +242,11 @@ int lp_boundary_ring(const float* mask, float* ring, int64_t planes, int32_t hei
 int lp_wmse_pair(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el,
                  double* acc, double* block_scratch, int32_t scratch_blocks, void* stream);
 
-/* K5  mask preparation (nodes.py:59-133), exact integer index math.
+/* K5  mask preparation (nodes.py:59-133); index math bit-for-bit with torch's nearest-exact.
  * dst[b][c][f][h][w] = max over the temporal window (video: 5 taps, -inf pad;
  * else 1 tap) of src[f_src(f+k)][h_src(h)][w_src(w)], with
- * idx_src(i) = min(((2i+1)*in)/(2*out), in-1)  (== F.interpolate nearest-exact),
+ * idx_src(i) = min(int(floorf((i + 0.5f) * (float(in) / float(out)))), in-1)  (ATen's fp32 form of
+ * F.interpolate nearest-exact, reproduced op for op),
  * with dst batch b reading src batch b % src_b and dst channel c reading src
  * channel c % src_c (the reference's repeat + slice).  `binarize`: 0 = copy value,
  * 1 = also apply 1 - (v > 0.5) (nodes.py:281-283).                              */

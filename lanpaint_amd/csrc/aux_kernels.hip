@@ -385,11 +385,16 @@ int wmse_dispatch(const float* a, const float* b, const float* mask, const float
 
 // ---------------------------------------------------------------------------------
 // K5: reshape_mask (nodes.py:59-133) as an output-indexed gather.  All index math is
-// 64-bit integer: src(i) = min(((2i+1)*in) / (2*out), in-1) == nearest-exact.
+// fp32 exactly as ATen's nearest-exact (UpSample.h): scale = float(in)/float(out);
+// src(i) = min(int(floorf((i + 0.5f) * scale)), in-1).  The fp32 rounding IS the reference behaviour
+// (the exact-rational index differs, e.g. in=14,out=201,i=100), so it is reproduced op for op.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int nearest_exact(int i, int in_size, int out_size) {
-    const long long s = ((2ll * i + 1) * in_size) / (2ll * out_size);
-    return static_cast<int>(s < in_size - 1 ? s : in_size - 1);
+#pragma clang fp contract(off)
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
+    const float pos = (static_cast<float>(i) + 0.5f) * scale;
+    const int s = static_cast<int>(floorf(pos));
+    return s < in_size - 1 ? s : in_size - 1;
 }
 
 __global__ __launch_bounds__(256) void lp_reshape_mask_kernel(const float* __restrict__ src, int sb, int sc, int sf,

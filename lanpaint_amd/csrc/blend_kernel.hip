@@ -12,9 +12,13 @@
 
 namespace lp {
 
+// ATen's nearest-exact source index, fp32 op for op (see lp_reshape_mask_kernel)
 __device__ __forceinline__ int blend_nearest(int i, int in_size, int out_size) {
-    const long long s = ((2ll * i + 1) * in_size) / (2ll * out_size);
-    return static_cast<int>(s < in_size - 1 ? s : in_size - 1);
+#pragma clang fp contract(off)
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
+    const float pos = (static_cast<float>(i) + 0.5f) * scale;
+    const int s = static_cast<int>(floorf(pos));
+    return s < in_size - 1 ? s : in_size - 1;
 }
 
 template <int TH, int TW>

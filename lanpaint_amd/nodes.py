@@ -2,7 +2,7 @@
 
 Mirrors the public surface of the reference's src/LanPaint/nodes.py for THIS path
 (file:line below are in /root/reference/src/LanPaint/nodes.py):
-    reshape_mask / prepare_mask            :59-133,159-160  -> HIP kernel lp_reshape_mask (exact integer index math)
+    reshape_mask / prepare_mask            :59-133,159-160  -> HIP kernel lp_reshape_mask (torch's nearest-exact index, bit for bit)
     min_step_frac_effective_steps          :134-144
     _sanitize_param                        :146-157
     sampling_function_LanPaint             :161-175   dual-CFG model function -> (x0, x0_BIG)
@@ -93,8 +93,8 @@ def _resample(src5, out_b, out_c, out_f, out_h, out_w, taps):
 
 def reshape_mask(input_mask, output_shape, video_inpainting=False, device=None):
     """nodes.py:59-133.  Nearest-exact resample to the latent grid, 5-wide temporal union for
-    video, channel / batch broadcast -- computed by one HIP launch with the source index taken in
-    exact integers, src = min(((2i+1)*in) // (2*out), in-1)  (== F.interpolate nearest-exact).
+    video, channel / batch broadcast -- computed by one HIP launch with ATen's own fp32 index formula
+    src = min(int(floorf((i + 0.5f) * (float(in) / float(out)))), in-1)  (== F.interpolate nearest-exact).
     Returns a float mask of `output_shape` on the HIP device the work ran on."""
     output_shape = tuple(int(s) for s in output_shape)
     dev = _hip_device(input_mask, device)

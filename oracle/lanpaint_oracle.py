@@ -176,14 +176,19 @@ def binarize_and_invert(denoise_mask):
 
 
 # ----------------------------------------------------------------------------
-# a17: mask preparation -- exact integer index math
+# a17: mask preparation -- index math bit-for-bit with torch's nearest-exact
 # ----------------------------------------------------------------------------
 def nearest_exact_src_index(out_size: int, in_size: int) -> np.ndarray:
-    """Source index chosen by F.interpolate(mode="nearest-exact") for each output
-    index (nodes.py:110-114,124-127 call sites).  src = floor((i + 0.5) * in/out),
-    evaluated in exact integers as ((2i+1)*in) // (2*out), clipped to in-1."""
-    i = np.arange(out_size, dtype=np.int64)
-    return np.minimum(((2 * i + 1) * in_size) // (2 * out_size), in_size - 1)
+    """Source index chosen by F.interpolate(mode="nearest-exact") for each output index
+    (nodes.py:110-114,124-127 call sites).  ATen evaluates it in FLOAT32 on every backend:
+        scale = float(in) / float(out);  src = min(int(floorf((i + 0.5f) * scale)), in - 1)
+    (aten/src/ATen/native/UpSample.h nearest_neighbor_exact_compute_source_index / nearest_exact_idx).
+    The fp32 rounding is part of the reference's behaviour: the exact-rational index
+    ((2i+1)*in)//(2*out) differs where (i+0.5)*in/out is an integer that fp32 lands just below
+    (e.g. in=14, out=201, i=100 -> 6, not 7), so the float form is restated, op for op."""
+    scale = np.float32(in_size) / np.float32(out_size)
+    pos = (np.arange(out_size, dtype=np.float32) + np.float32(0.5)) * scale
+    return np.minimum(np.floor(pos).astype(np.int64), in_size - 1)
 
 
 def _interp_nearest_exact(a: np.ndarray, sizes: Sequence[int]) -> np.ndarray:

@@ -286,8 +286,26 @@ def test_reshape_mask_reference_kats():
     assert out[0, 0, 0, 2, 3] == 1.0 and out[0, 0, 1, 4, 5] == 1.0
 
 
+def test_reshape_mask_index_math_equals_torch_gpu_interpolate_exhaustively():
+    """lp_reshape_mask vs torch's own GPU nearest-exact (1-D / 2-D / 3-D kernels) over every (in, out) pair of a
+    grid that includes up-sampling and the pairs where torch's CPU kernels deviate from ATen's formula: bit-exact."""
+    import torch
+    from lanpaint_amd.nodes import reshape_mask
+    for n_in in list(range(1, 16)) + [54, 124]:
+        ramp = torch.arange(n_in, dtype=torch.float32, device=DEV)
+        for n_out in range(1, 260, 3 if n_in > 4 else 1):
+            got = reshape_mask(ramp.reshape(1, n_in), (1, 1, 1, n_out)).reshape(-1)
+            want = torch.nn.functional.interpolate(ramp.reshape(1, 1, 1, n_in), size=(1, n_out), mode="nearest-exact").reshape(-1)
+            assert torch.equal(got, want), (n_in, n_out)
+    got = reshape_mask(torch.arange(2, dtype=torch.float32, device=DEV).reshape(1, 1, 2, 1, 1), (1, 1, 47, 1, 1), video_inpainting=False)
+    want = torch.nn.functional.interpolate(torch.arange(2, dtype=torch.float32, device=DEV).reshape(1, 1, 2, 1, 1), size=(47, 1, 1),
+                                           mode="nearest-exact")
+    assert torch.equal(got.reshape(-1), want.reshape(-1))
+
+
 def test_reshape_mask_equals_torch_interpolate_pipeline():
-    """Property check vs the exact torch ops the reference calls, on random sizes."""
+    """Property check vs the exact torch ops the reference calls, on random sizes (all below the smallest
+    output size, 41, at which torch's CPU kernels deviate from ATen's formula)."""
     import torch
     from lanpaint_amd.nodes import reshape_mask
     rng = np.random.default_rng(5)

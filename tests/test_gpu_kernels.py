@@ -1,5 +1,5 @@
 """Kernel-level checks through the C ABI: coefficient table, Philox stream, mask-edge ring,
-weighted-MSE reduction, mask resample (bit-exact integer index math)."""
+weighted-MSE reduction, mask resample (index math bit-exact with torch's nearest-exact)."""
 import ctypes
 
 import numpy as np
