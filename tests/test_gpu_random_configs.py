@@ -1,0 +1,84 @@
+"""Seeded random sweep of the engine against the CPU oracle: shapes (odd, 5-D, multi-row, both sides of the
+VEC=1 / VEC=4 switch), schedules, hyper-parameters, mask densities, step counts, model output forms."""
+import numpy as np
+import pytest
+
+from oracle.lanpaint_oracle import OracleLanPaint, times_from_sigma
+from tests.helpers import assert_close
+from tests.stubs import MODELS
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 4, 8, 8), (2, 4, 9, 7), (1, 3, 5, 7), (3, 2, 6, 10), (1, 16, 3, 6, 8), (2, 4, 2, 5, 5), (1, 1, 33),
+          (4, 4, 16, 16), (1, 4, 64, 64), (5, 1, 7, 3)]
+BIG = [(3, 4, 224, 224), (2, 3, 301, 301), (1, 16, 21, 60, 104)]        # > 512 K elements: float4 / large scalar paths
+
+
+def _case(seed, shape=None):
+    rng = np.random.default_rng(seed)
+    shape = shape or SHAPES[int(rng.integers(len(SHAPES)))]
+    flow = bool(rng.integers(2))
+    rows = shape[0]
+    per_row = bool(rng.integers(2))
+    if flow:
+        sig = rng.uniform(0.03, 0.97, size=rows if per_row else 1)
+    else:
+        sig = np.exp(rng.uniform(np.log(0.03), np.log(14.6), size=rows if per_row else 1))
+    sigma = np.broadcast_to(sig, (rows,)).astype(np.float32).copy()
+    hyper = dict(lamb=float(rng.choice([1.0, 5.0, 8.0, 0.3])), beta=float(rng.choice([1.0, 0.5, 2.0])),
+                 step=float(rng.choice([0.2, 0.05, 0.4])), msf=float(rng.choice([0.0, 0.0, 1.0, 0.3])))
+    n_steps = int(rng.choice([0, 1, 2, 3, 5]))
+    kind = rng.choice(["box", "random", "soft", "ones", "zeros"], p=[0.35, 0.35, 0.1, 0.1, 0.1])
+    if kind == "box":
+        mask = np.zeros(shape, dtype=np.float32)
+        mask[..., : max(1, shape[-1] // 2)] = 1.0
+    elif kind == "random":
+        mask = (rng.random(shape) > rng.uniform(0.2, 0.8)).astype(np.float32)
+    elif kind == "soft":
+        mask = rng.random(shape, dtype=np.float32)
+    else:
+        mask = np.full(shape, 1.0 if kind == "ones" else 0.0, dtype=np.float32)
+    model = str(rng.choice(["linear_tuple", "denoiser_single", "offset_tuple", "list_one"]))
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    x = rng.standard_normal(shape, dtype=np.float32) * np.float32(1.0 + sigma.max())
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(max(0, 2 * n_steps - 1))]
+    return dict(shape=shape, flow=flow, sigma=sigma, hyper=hyper, n_steps=n_steps, mask=mask, model=model, y=y, noise=noise,
+                x=x, draws=draws, kind=kind)
+
+
+def _run(c):
+    import torch
+    from lanpaint_amd import LanPaint
+    h = c["hyper"]
+    times = times_from_sigma(c["sigma"], c["flow"])
+    it = iter(c["draws"])
+    o = OracleLanPaint(MODELS[c["model"]](flow=c["flow"]), 5, 15.0, h["lamb"], h["beta"], h["step"], is_flow=c["flow"],
+                       min_step_frac=h["msf"], randn=lambda like: next(it))
+    xo = c["x"].copy()
+    out_o = o(xo, c["y"], c["noise"], c["sigma"], c["mask"], times, None, 0, n_steps=c["n_steps"])
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    it2 = iter(c["draws"])
+    eng = LanPaint(MODELS[c["model"]](flow=c["flow"]), 5, 15.0, h["lamb"], h["beta"], h["step"], IS_FLOW=c["flow"],
+                   MinStepFrac=h["msf"], rng=lambda like: tt(next(it2)))
+    xg = tt(c["x"])
+    out_g = eng(xg, tt(c["y"]), tt(c["noise"]), tt(c["sigma"]), tt(c["mask"]), tuple(tt(t) for t in times), None, 0,
+                n_steps=c["n_steps"])
+    what = f"shape={c['shape']} flow={c['flow']} sigma={c['sigma']} {h} n={c['n_steps']} mask={c['kind']} model={c['model']}"
+    assert_close(xg.cpu().numpy(), xo, "x | " + what, rel=5e-5, mse=1e-8)
+    assert_close(out_g.cpu().numpy(), out_o, "out | " + what, rel=5e-5, mse=1e-8)
+    assert next(it, None) is None and next(it2, None) is None
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_config_matches_oracle(seed):
+    _run(_case(1000 + seed))
+
+
+@pytest.mark.parametrize("idx", range(len(BIG)))
+def test_large_shapes_both_kernel_widths(idx):
+    c = _case(7000 + idx, BIG[idx])
+    c["n_steps"] = 2
+    rng = np.random.default_rng(idx)
+    c["draws"] = [rng.standard_normal(c["shape"], dtype=np.float32) for _ in range(3)]
+    _run(c)
