@@ -128,9 +128,10 @@ def run_gpu(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    lpd.init("nccl", dev)                               # backend "nccl" IS RCCL on ROCm; no-op at world size 1
+    dev_index = local_rank % max(1, torch.cuda.device_count())   # identity on an N-GPU node; lets a 1-GPU box rehearse N > 1
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    lpd.init(args.dist_backend, dev)                    # "nccl" IS RCCL on ROCm; no-op at world size 1
 
     shape, flow, n_sig, n_think = WORKLOADS[args.workload]
     sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
@@ -528,6 +529,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="1: replay each sigma call as one hipGraph (default); 0: eager launches")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo only to rehearse the N > 1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")
     ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")

@@ -97,7 +97,8 @@ def reduce_throughput(elapsed_s: float, units: int, device: Optional[torch.devic
     """(max elapsed over ranks, total units over ranks): whole-job throughput = units / elapsed."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return float(elapsed_s), int(units)
-    dev = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    dev = device if (device is not None and dist.get_backend(group) == "nccl") else (
+        torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
     n = torch.tensor([float(units)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
