@@ -27,3 +27,10 @@ done
 rm -rf /tmp/p_*
 cd $R
 ls -la $OUT
+# MFMA-busy evidence for the stand-in backbone (kept separate: MIOpen under --pmc FETCH_SIZE crashed rocprofv3 once)
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_mfma -o t -- python $R/scripts/unet_pass.py 4 > $OUT/unet_pmc_mfma.log 2>&1
+summ /tmp/p_mfma/t_results.db --pmc 2>&1 | grep -A400 "counter | dispatches" > $OUT/unet_pmc_mfma.md
+summ /tmp/p_mfma/t_results.db 2>&1 | head -25 > $OUT/unet_kernel_trace.md
+rm -rf /tmp/p_mfma
+cd $R
