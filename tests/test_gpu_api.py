@@ -375,3 +375,46 @@ def test_ksampler_x0_inpaint_matches_oracle(flow):
     # no-mask path: plain model call (nodes.py:302)
     out = k(x, tt(np.float32([sig[0]])), None, model_options={}, seed=0)
     assert torch.equal(out, 0.9 * x)
+
+
+# ---- argument forms the reference accepts through plain torch broadcasting -------------------------------
+def test_broadcastable_mask_scalar_sigma_and_half_latents():
+    import torch
+    from lanpaint_amd import LanPaint
+    from tests.helpers import load_golden, xi_list
+    case = gc.build_case("ve_basic")
+    g = load_golden("ve_basic")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)   # noqa: E731
+
+    def run(x, mask, sigma, times, y=None, noise=None):
+        it = iter([tt(d) for d in xi_list(g)])
+        eng = LanPaint(_DummyLinear(), 5, 15.0, 5.0, 1.0, 0.2, rng=lambda like: next(it))
+        out = eng(x, tt(case["y"]) if y is None else y, tt(case["noise"]) if noise is None else noise, sigma, mask, times, None, 0)
+        return x, out
+
+    # (1) mask given as [1, 1, H, W] (broadcast over channels), sigma / times as 0-d tensors
+    m11 = tt(case["mask"][:, :1])
+    s0 = torch.tensor(float(case["sigma"][0]), device=DEV)
+    t0 = tuple(torch.tensor(float(t[0]), device=DEV) for t in case["times"])
+    x, out = run(tt(case["x"].copy()), m11, s0, t0)
+    assert_close(x.cpu().numpy(), g["x_out"], "broadcast mask + 0-d sigma: x")
+    assert_close(out.cpu().numpy(), g["out"], "broadcast mask + 0-d sigma: out")
+    # (2) times given already broadcast as [B, 1, 1, 1]
+    t4 = tuple(tt(t).reshape(1, 1, 1, 1) for t in case["times"])
+    x, out = run(tt(case["x"].copy()), tt(case["mask"]), tt(case["sigma"]), t4)
+    assert_close(out.cpu().numpy(), g["out"], "[B,1,1,1] times: out")
+    # (3) fp16 sampler latent: computed in fp32, written back / returned in fp16
+    xh = tt(case["x"].copy()).half()
+    x, out = run(xh, tt(case["mask"]), tt(case["sigma"]), tuple(tt(t) for t in case["times"]))
+    assert x.dtype == torch.float16 and out.dtype == torch.float16 and x.data_ptr() == xh.data_ptr()
+    assert float((out.float().cpu() - torch.from_numpy(g["out"])).abs().max()) < 0.06
+    # (4) known latent / noise given as double precision
+    x, out = run(tt(case["x"].copy()), tt(case["mask"]), tt(case["sigma"]), tuple(tt(t) for t in case["times"]),
+                 y=tt(case["y"]).double(), noise=tt(case["noise"]).double())
+    assert_close(out.cpu().numpy(), g["out"], "float64 y / noise: out")
+
+
+class _DummyLinear(_DummyModel):
+    def __call__(self, x, sigma, model_options=None, seed=None):
+        self.calls += 1
+        return 0.9 * x, 0.8 * x
