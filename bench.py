@@ -318,7 +318,7 @@ def standalone_step(_cabi, workload, dev, phase=None):
     ve, abt, _ = times_from_sigma(sig, flow)
     coef = torch.empty((rows, _cabi.LP_COEF_STRIDE), device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
-    _cabi.check(lib.lp_coeffs(ctypes.byref(h), ve.data_ptr(), 1, abt.data_ptr(), 1, sig.data_ptr(), 1, None, 0, rows,
+    _cabi.check(lib.lp_coeffs(ctypes.byref(h), ve.data_ptr(), 1, abt.data_ptr(), 1, sig.data_ptr(), 1, None, 0, None, 0, rows,
                               coef.data_ptr(), st))
     d = _cabi.LpStepDesc()
     d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows

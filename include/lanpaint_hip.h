@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 2
+#define LP_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -43,7 +43,7 @@ extern "C" {
  * recomputes these ~40 tiny ops + 1 host sync EVERY iteration:
  * lanpaint.py:205,295-328).  Region r: 0 = inpaint ("x" branch, mask==0),
  * 1 = known ("y" branch, mask==1).                                          */
-#define LP_COEF_STRIDE   32
+#define LP_COEF_STRIDE   36
 #define LP_C_SCALE        0   /* flow: sqrt(abt)+sqrt(1-abt); VE: sqrt(1+sigma^2)  (lanpaint.py:96-99) */
 #define LP_C_SQRT_ABT     1
 #define LP_C_OMA          2   /* 1 - abt                                         */
@@ -68,6 +68,8 @@ extern "C" {
 #define LP_R_A            7
 #define LP_R_CX0          8   /* sqrt(abt)/(1-abt): C = CX0*x0s + CXT*x_t (lanpaint.py:219) */
 #define LP_R_CXT          9   /* A - 1/(1-abt)                                   */
+#define LP_C_TMODEL      32   /* the time the backbone is called with inside the loop (flow_t or VE sigma,
+                                 lanpaint.py:165,170): lets a replayed hipGraph hand `table[:, 32]` to the model */
 
 typedef struct lp_hyper {
     float    lambda;          /* LanPaint_Lambda   (lanpaint.py:11)             */
@@ -176,10 +178,11 @@ const char* lp_strerror(int code);
  * ve_sigma / abt / replace_sigma: device fp32, `rows` entries each, or 1 entry
  * broadcast when the matching *_stride is 0.  step_override (nullable): explicit
  * per-row step size (the `step_size` argument of the public langevin_dynamics,
- * lanpaint.py:192) instead of StepSize*max(1-abt, MinStepFrac).               */
+ * lanpaint.py:192) instead of StepSize*max(1-abt, MinStepFrac).  t_model (nullable):
+ * copied into slot LP_C_TMODEL.                                                */
 int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const float* abt, int abt_stride,
               const float* replace_sigma, int rs_stride, const float* step_override, int step_stride,
-              int rows, float* coef_table, void* stream);
+              const float* t_model, int t_stride, int rows, float* coef_table, void* stream);
 
 /* K1a  sigma -> (VE_sigma, abt, flow_t) per batch row plus the two scalars the inner-step rule needs,
  * in ONE launch.  Replaces the ~15 eager scalar ops + 2 host syncs of KSamplerX0Inpaint.__call__

@@ -13,14 +13,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
-LP_COEF_STRIDE = 32
+LP_COEF_STRIDE = 36
 (LP_C_SCALE, LP_C_SQRT_ABT, LP_C_OMA, LP_C_ABT, LP_C_RSIGMA, LP_C_DTX, LP_C_DTY, LP_C_AX, LP_C_AY, LP_C_DX, LP_C_DY,
  LP_C_VALID) = range(12)
-LP_C_REGION0, LP_C_REGION1 = 12, 22
+LP_C_REGION0, LP_C_REGION1, LP_C_TMODEL = 12, 22, 32
 (LP_R_E_FULL, LP_R_K_FULL, LP_R_STD_FULL, LP_R_E_HALF, LP_R_K_HALF, LP_R_STD_HALF, LP_R_DT, LP_R_A, LP_R_CX0,
  LP_R_CXT) = range(10)
 
@@ -79,7 +79,7 @@ EXPORTS = {
     "lp_abi_version": (C.c_int, []),
     "lp_strerror": (C.c_char_p, [C.c_int]),
     "lp_coeffs": (C.c_int, [C.POINTER(LpHyper), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                            C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                            C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lp_sigma_times": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_step": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p]),
     "lp_finalize": (C.c_int, [C.POINTER(LpFinalDesc), C.c_void_p]),

@@ -17,8 +17,8 @@ namespace lp {
 // ---------------------------------------------------------------------------------
 __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int ve_stride,
                                  const float* __restrict__ abt, int abt_stride, const float* __restrict__ rs,
-                                 int rs_stride, const float* __restrict__ step_ov, int step_stride, int rows,
-                                 float* __restrict__ table) {
+                                 int rs_stride, const float* __restrict__ step_ov, int step_stride,
+                                 const float* __restrict__ t_model, int t_stride, int rows, float* __restrict__ table) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float abt_f = abt[static_cast<int64_t>(r) * abt_stride];
@@ -46,6 +46,7 @@ __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int v
     c[LP_C_DX] = sqrtf(2.0f);                                                  // :326-327
     c[LP_C_DY] = sqrtf(2.0f);
     c[LP_C_VALID] = valid ? 1.0f : 0.0f;
+    c[LP_C_TMODEL] = t_model ? t_model[static_cast<int64_t>(r) * t_stride] : 0.0f;
 
     const double oma_d = static_cast<double>(oma);
     const double cx0 = sqrt(static_cast<double>(abt_f)) / oma_d;
@@ -142,13 +143,13 @@ int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, in
 }
 
 int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const float* abt, int abt_stride,
-                    const float* rs, int rs_stride, const float* step_ov, int step_stride, int rows, float* table,
-                    hipStream_t stream) {
+                    const float* rs, int rs_stride, const float* step_ov, int step_stride, const float* t_model,
+                    int t_stride, int rows, float* table, hipStream_t stream) {
     if (!h || !abt || !table || rows <= 0) return LP_E_INVALID;
     if (!h->is_flow && !ve) return LP_E_INVALID;
     const int block = 64;
     hipLaunchKernelGGL(lp_coeffs_kernel, dim3((rows + block - 1) / block), dim3(block), 0, stream, *h, ve, ve_stride,
-                       abt, abt_stride, rs, rs_stride, step_ov, step_stride, rows, table);
+                       abt, abt_stride, rs, rs_stride, step_ov, step_stride, t_model, t_stride, rows, table);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 

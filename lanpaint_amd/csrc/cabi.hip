@@ -9,8 +9,8 @@ int timer_create(void** out);
 int timer_destroy(void* h);
 int timer_elapsed_ns(void* h, double* ns);
 int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const float* abt, int abt_stride,
-                    const float* rs, int rs_stride, const float* step_ov, int step_stride, int rows, float* table,
-                    hipStream_t stream);
+                    const float* rs, int rs_stride, const float* step_ov, int step_stride, const float* t_model,
+                    int t_stride, int rows, float* table, hipStream_t stream);
 int finalize_dispatch(const lp_final_desc* d, hipStream_t stream);
 int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow, float* times,
                          float* scalars, hipStream_t stream);
@@ -42,10 +42,10 @@ const char* lp_strerror(int code) {
 }
 
 int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const float* abt, int abt_stride,
-              const float* replace_sigma, int rs_stride, const float* step_override, int step_stride, int rows,
-              float* coef_table, void* stream) {
+              const float* replace_sigma, int rs_stride, const float* step_override, int step_stride,
+              const float* t_model, int t_stride, int rows, float* coef_table, void* stream) {
     return lp::coeffs_dispatch(hyper, ve_sigma, ve_stride, abt, abt_stride, replace_sigma, rs_stride, step_override,
-                               step_stride, rows, coef_table, as_stream(stream));
+                               step_stride, t_model, t_stride, rows, coef_table, as_stream(stream));
 }
 
 int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,

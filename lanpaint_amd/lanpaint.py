@@ -60,30 +60,45 @@ def _noise_scaling_kind(model_sampling) -> str:
 
 
 class _Workspace:
-    """Device buffers reused across sigma calls of one engine (torch-owned)."""
+    """Device buffers reused across sigma calls of one engine (torch-owned).  static_io: also owns the
+    backbone-input / final-x buffers (a captured call bakes their addresses)."""
 
-    def __init__(self, like: torch.Tensor):
+    def __init__(self, like: torch.Tensor, static_io: bool = False, model_dtype=None):
         self.shape, self.device = tuple(like.shape), like.device
         self.x_t = torch.empty_like(like)
         self.C = torch.empty_like(like)
         self.coef = torch.empty((like.shape[0], _cabi.LP_COEF_STRIDE), dtype=torch.float32, device=like.device)
         self.x0s = []            # lazily: rotating buffers for LangevinState.x0 (early stop only)
+        self.static_io = static_io
+        if static_io:
+            self.x_final = torch.empty_like(like)
+            self.x_in = self.x_final if model_dtype is None else torch.empty_like(like, dtype=model_dtype)
 
     def matches(self, like):
         return self.shape == tuple(like.shape) and self.device == like.device
 
 
-class _CapturedCall:
-    """One sigma call captured as a hipGraph: static inputs [x, sigma, VE, abt, flow_t],
-    static output, the device-side Philox counter the captured launches read."""
+class _CallState:
+    """Everything one sigma call carries from its prologue to its loop and epilogue."""
+    __slots__ = ("input_x", "xc", "shape", "n_el", "rows", "flow", "ws", "stream", "sigma", "y", "m", "m_u8", "abt",
+                 "current_times", "base_flags", "keep", "t_model", "sigma_model", "compat", "n_steps", "x_final", "x_in",
+                 "xin_flag", "k0_desc", "replace_kind_static")
 
-    def __init__(self, static_in, counter):
+
+class _CapturedCall:
+    """The think loop + final backbone call of one sigma call captured as a hipGraph, with the workspace
+    whose addresses it bakes in and the device-side Philox counter its launches read."""
+
+    def __init__(self, counter):
         self.graph = torch.cuda.CUDAGraph()
-        self.static_in = static_in
         self.counter = counter
-        self.out = None
+        self.ws = None
+        self.final = None        # the backbone's final output object (static tensors)
         self.ran = 0
+        self.launches = 0
         self.keep = None
+        self.fast = False        # steady-state replay may reuse the snapshotted descriptors
+        self.rows, self.flow, self.hyper, self.k0_desc, self.f_desc = 0, False, None, None, None
 
 
 class LanPaint:
@@ -304,7 +319,7 @@ class LanPaint:
             self.noise = self.rng(noise) if callable(self.rng) else torch.randn_like(noise)
         if n_steps is None:
             n_steps = self.n_steps
-        run = self._call_graphed if self._graph_eligible(x, model_options) else self.LanPaint
+        run = self._call_graphed if self._graph_eligible(x, model_options, sigma, current_times) else self.LanPaint
         if x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):
                 return run(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX,
@@ -312,9 +327,12 @@ class LanPaint:
         return run(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX, self.IS_FLOW)
 
     # ------------------------------------------------------------------ hipGraph replay of one sigma call
-    def _graph_eligible(self, x, model_options):
+    def _graph_eligible(self, x, model_options, sigma, current_times):
         if not self.graph or callable(self.rng) or self._noise_regenerated:
             return False         # (regenerated noise is a fresh tensor per call: nothing stable to bake into a graph)
+        rows = x.shape[0] if x.ndim else 1
+        if any(t.numel() not in (1, rows) for t in (sigma, *current_times)):
+            return False         # per-element times: the general path, eager only
         if self.audio_indicator is not None or self.audio_correction is not None:
             return False
         if self.early_stop_threshold > 0.0 and self.early_stop_patience > 0:
@@ -324,59 +342,72 @@ class LanPaint:
         if self._overridden("langevin_dynamics") or self._overridden("score_model") or \
                 self._overridden("prepare_step_size"):
             return False
-        return x.dtype == torch.float32
+        return x.dtype == torch.float32 and x.numel() > 0
 
     def _call_graphed(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
-        """Stage the per-call inputs into the captured call's static buffers, replay, hand
-        back a fresh `out` and the in-place-updated x (same contract as the eager path)."""
-        # every pointer the capture bakes in is part of the key (the tensors themselves are the caller's)
+        """One sigma call with its think loop replayed as a hipGraph.  Only the part BETWEEN the replace step
+        and the finalise is captured (N x [backbone, fused step] + the final backbone call): the prologue
+        (lp_coeffs, replace) and the epilogue (lp_finalize) are ordinary launches that read / write the
+        caller's tensors directly, so nothing of x / noise / out has to be staged through static buffers."""
         m_u8 = getattr(latent_mask, "_lp_u8", None)
+        # every pointer the captured launches bake in is part of the key (y and the mask; the tensors stay the caller's)
         key = (tuple(x.shape), x.device.index, int(n_steps), bool(IS_FLUX), bool(IS_FLOW), self.latent_image.data_ptr(),
-               self.noise.data_ptr(), latent_mask.data_ptr(), m_u8.data_ptr() if m_u8 is not None else 0,
-               tuple(sigma.shape), tuple(tuple(t.shape) for t in current_times), id(model_options), seed, self.rng)
+               latent_mask.data_ptr(), m_u8.data_ptr() if m_u8 is not None else 0, int(sigma.numel()),
+               tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng)
         cap = self._graphs.get(key)
-        srcs = [x, sigma, current_times[0], current_times[1], current_times[2]]
         if cap is None:
-            cap = self._capture(key, srcs, latent_mask, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+            cap = self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
             while len(self._graphs) > self.MAX_GRAPHS:       # bound the static memory held by stale captures
                 self._graphs.popitem(last=False)
         else:
             self._graphs.move_to_end(key)
-        stream = self._stream(x.device)
-        if all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs):
-            # one staging launch in, one out (a foreach copy costs ~11 us on the device for these five)
-            cd = cap.copy_in
-            for k, t in enumerate(srcs):
-                cd.src[k] = t.data_ptr()
-            _cabi.check(self._lib.lp_copy_batch(ctypes.byref(cd), stream), "lp_copy_batch")
-            cap.graph.replay()
-            out = torch.empty_like(cap.out)
-            co = cap.copy_out
-            co.dst[0], co.dst[1] = x.data_ptr(), out.data_ptr()
-            _cabi.check(self._lib.lp_copy_batch(ctypes.byref(co), stream), "lp_copy_batch")
-        else:
-            torch._foreach_copy_(cap.static_in, srcs)
-            cap.graph.replay()
-            x.copy_(cap.static_in[0])
-            out = cap.out.clone()
         self.iterations_run += cap.ran
         self.last_inner_steps = cap.ran
+        srcs = (x, sigma, current_times[0], current_times[1], current_times[2], self.noise)
+        if cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape:
+            return self._replay_fast(cap, x, sigma, current_times)
+        st = self._prologue(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=cap.ws)
+        cap.graph.replay()
+        return self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None)
+
+    def _replay_fast(self, cap, x, sigma, current_times):
+        """Steady-state replay: the three eager launches around the graph (lp_coeffs, replace, lp_finalize) reuse
+        the descriptors snapshotted at capture; only the caller's pointers (x, noise, sigma, times, out) change."""
+        lib, stream = self._lib, self._stream(x.device)
+        rows = cap.rows
+        t_src = current_times[2] if cap.flow else current_times[0]
+        _cabi.check(lib.lp_coeffs(ctypes.byref(cap.hyper), current_times[0].data_ptr(), int(current_times[0].numel() > 1),
+                                  current_times[1].data_ptr(), int(current_times[1].numel() > 1), sigma.data_ptr(),
+                                  int(sigma.numel() > 1), None, 0, t_src.data_ptr(), int(t_src.numel() > 1), rows,
+                                  cap.ws.coef.data_ptr(), stream), "lp_coeffs")
+        k0 = cap.k0_desc
+        k0.x, k0.noise = x.data_ptr(), self.noise.data_ptr()
+        _cabi.check(lib.lp_step(ctypes.byref(k0), stream), "lp_step")
+        cap.graph.replay()
+        out = torch.empty_like(x)
+        f = cap.f_desc
+        f.x_dst, f.out = x.data_ptr(), out.data_ptr()
+        _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
         return out
 
-    def _capture(self, key, srcs, latent_mask, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
-        dev = srcs[0].device
-        static_in = [t.detach().clone().contiguous() for t in srcs]
+    def _capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
+        dev = x.device
         counter = self._rng_counters.get(dev)      # ONE Philox launch-sequence base per device, shared by
         if counter is None:                        # every captured call so their streams never overlap
             counter = self._rng_counters[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
-        cap = _CapturedCall(static_in, counter)
+        cap = _CapturedCall(counter)
+        cap.ws = _Workspace(x.detach().to(torch.float32).contiguous(), static_io=True, model_dtype=self.model_dtype)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         it0 = self.iterations_run
         rng_state = torch.cuda.get_rng_state(dev)   # warm-up + capture must not consume the user's torch stream
-        with torch.cuda.stream(side):              # one eager run on the side stream: lazy inits, workspace
-            x_s, sig_s, t_s = static_in[0], static_in[1], tuple(static_in[2:5])
-            self.LanPaint(x_s.clone(), sig_s, latent_mask, t_s, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+        with torch.cuda.stream(side):              # one complete eager call on the side stream: lazy inits
+            xw = x.detach().clone()
+            st = self._prologue(xw, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
+                                ws=cap.ws)
+            self._epilogue(st, self._think_and_final_model(st, model_options, seed))
+            st = self._prologue(xw, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
+                                ws=cap.ws)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.iterations_run = it0
@@ -385,48 +416,61 @@ class LanPaint:
             # thread_local: a live RCCL communicator's watchdog thread issues HIP calls of its own;
             # in the default "global" mode those would invalidate this thread's capture
             with torch.cuda.graph(cap.graph, stream=side, capture_error_mode="thread_local"):
-                cap.out = self.LanPaint(x_s, sig_s, latent_mask, t_s, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+                cap.final = self._think_and_final_model(st, model_options, seed)
         finally:
             self._capturing = None
+        cap.launches = self._cap_offset
         torch.cuda.set_rng_state(rng_state, dev)
         cap.ran = self.iterations_run - it0
         self.iterations_run = it0
-        cap.keep, self._ws = self._ws, None      # the captured call owns that workspace (pointers are baked in)
-        cd = cap.copy_in = _cabi.LpCopyDesc()
-        cd.n = len(static_in)
-        for k, t in enumerate(static_in):
-            cd.count[k], cd.src_stride[k], cd.dst[k] = t.numel(), 1, t.data_ptr()
-        co = cap.copy_out = _cabi.LpCopyDesc()
-        co.n = 2
-        co.count[0], co.src_stride[0], co.src[0] = static_in[0].numel(), 1, static_in[0].data_ptr()
-        co.count[1], co.src_stride[1], co.src[1] = cap.out.numel(), 1, cap.out.data_ptr()
+        cap.keep = st                              # descriptor-side tensors referenced by the baked launches
+        # descriptors of the three launches that stay outside the graph, for the steady-state replay path
+        cap.rows, cap.flow = st.rows, st.flow
+        cap.hyper = _cabi.LpHyper.from_buffer_copy(self._hyper)
+        cap.k0_desc = st.k0_desc
+        f = _cabi.LpFinalDesc()
+        dense_ok = self._fill_final_desc(f, st, cap.final, torch.empty(0), allow_convert=False)
+        if self.rng == "philox":
+            f.rng_bump_ptr, f.rng_bump = counter.data_ptr(), cap.launches
+        cap.f_desc = f
+        cap.fast = bool(dense_ok and st.k0_desc is not None and st.replace_kind_static and st.xc is st.input_x)
         self._graphs[key] = cap
         return cap
 
     def LanPaint(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
-        """lanpaint.py:56-157."""
-        lib, d = self._lib, self._desc
-        input_x = x
-        flow = bool(IS_FLUX or IS_FLOW)
+        """lanpaint.py:56-157: prologue (coefficients + replace step), think loop + final backbone call,
+        epilogue (reprojection + in-place write-back)."""
         if x.numel() == 0:               # empty batch: only the model-call structure of the reference remains
             for _ in range(n_steps if float(self.step_size) > 0.0 else 0):
                 self.inner_model(x, sigma, model_options=model_options, seed=seed)
             out, _ = self.unpack_model_output(self.inner_model(x, sigma, model_options=model_options, seed=seed))
             return out
-        xc = _as_f32c(x)
-        shape, n_el, rows = xc.shape, xc.numel(), xc.shape[0]
-        ws = self._workspace(xc)
-        stream = self._stream(xc.device)
-        y = _as_f32c(self.latent_image if self.latent_image.shape == shape else self.latent_image.expand(shape))
+        st = self._prologue(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+        final = self._think_and_final_model(st, model_options, seed)
+        return self._epilogue(st, final)
+
+    # ---- prologue: per-call descriptor, coefficient table, replace step ------------------------------------
+    def _prologue(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=None):
+        lib, d = self._lib, self._desc
+        st = _CallState()
+        st.input_x = x
+        st.flow = flow = bool(IS_FLUX or IS_FLOW)
+        st.xc = xc = _as_f32c(x)
+        st.shape, st.n_el, st.rows = shape, n_el, rows = xc.shape, xc.numel(), xc.shape[0]
+        st.ws = ws = ws if ws is not None else self._workspace(xc)
+        st.stream = stream = self._stream(xc.device)
+        st.sigma = sigma
+        st.y = y = _as_f32c(self.latent_image if self.latent_image.shape == shape else self.latent_image.expand(shape))
         nz = _as_f32c(self.noise if self.noise.shape == shape else self.noise.expand(shape))
         m = latent_mask if latent_mask.shape == shape else latent_mask.expand(shape)
-        m = _as_f32c(m)
+        st.m = m = _as_f32c(m)
         # a caller that KNOWS the mask is binary (KSamplerX0Inpaint builds it as 1 - (dm > 0.5)) may attach a
         # uint8 copy: the kernels then read 1 byte instead of 4 per element for the mask stream
         m_u8 = getattr(latent_mask, "_lp_u8", None)
         if m_u8 is not None and not (m_u8.dtype == torch.uint8 and m_u8.shape == shape and m_u8.is_contiguous()
                                      and m_u8.device == xc.device):
             m_u8 = None
+        st.m_u8 = m_u8
 
         VE_Sigma, abt, Flow_t = current_times
         replace_sigma = sigma
@@ -440,9 +484,14 @@ class LanPaint:
             current_times = (VE_Sigma, abt, Flow_t)
         if abt.numel() not in (1, rows) or VE_Sigma.numel() not in (1, rows) or replace_sigma.numel() not in (1, rows):
             per_el = True
+        st.abt, st.current_times = abt, current_times
+        if flow:
+            t_model = self.remove_none_dims(self.add_none_dims(Flow_t))
+        else:
+            t_model = self.remove_none_dims(self.add_none_dims(current_times[0]))
 
         # ---- per-call descriptor --------------------------------------------------
-        base_flags = (LP_FL_FLOW if flow else 0) | (LP_FL_MASK_U8 if m_u8 is not None else 0)
+        st.base_flags = base_flags = (LP_FL_FLOW if flow else 0) | (LP_FL_MASK_U8 if m_u8 is not None else 0)
         hyp = self._fill_hyper(flow)
         d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
         d.lambda_, d.one_plus_lambda, d.beta = hyp.lambda_, hyp.one_plus_lambda, hyp.beta
@@ -451,10 +500,10 @@ class LanPaint:
         d.mask = m_u8.data_ptr() if m_u8 is not None else m.data_ptr()
         d.x0s = None
         d.abt_el = d.ve_el = d.rsig_el = d.corr_el = None
-        keep = []          # tensors that must outlive the enqueued launches of this call
+        keep = st.keep = [nz]          # tensors that must outlive the enqueued launches of this call
         corr = self.audio_correction
         if per_el:
-            base_flags |= LP_FL_PER_ELEMENT
+            st.base_flags = base_flags = base_flags | LP_FL_PER_ELEMENT
             abt_el = _as_f32c(self.add_none_dims(abt).expand(shape))
             ve_el = _as_f32c(self.add_none_dims(VE_Sigma).expand(shape))
             rs_el = _as_f32c(self.add_none_dims(replace_sigma).expand(shape))
@@ -463,15 +512,22 @@ class LanPaint:
             d.coef = None
         else:
             ve_r, abt_r, rs_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1)), _as_f32c(replace_sigma.reshape(-1))
-            keep += [ve_r, abt_r, rs_r]
+            tm_r = _as_f32c(t_model.reshape(-1))
+            keep += [ve_r, abt_r, rs_r, tm_r]
             _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), ve_r.data_ptr(), int(ve_r.numel() > 1), abt_r.data_ptr(),
-                                      int(abt_r.numel() > 1), rs_r.data_ptr(), int(rs_r.numel() > 1), None, 0, rows,
-                                      ws.coef.data_ptr(), stream), "lp_coeffs")
+                                      int(abt_r.numel() > 1), rs_r.data_ptr(), int(rs_r.numel() > 1), None, 0,
+                                      tm_r.data_ptr(), int(tm_r.numel() > 1), rows, ws.coef.data_ptr(), stream), "lp_coeffs")
             d.coef = ws.coef.data_ptr()
         if corr is not None:
             corr_el = _as_f32c(corr if corr.shape == shape else corr.expand(shape))
             keep.append(corr_el)
             d.corr_el = corr_el.data_ptr()
+        if ws.static_io and not per_el:
+            # replayed loop: the backbone reads its time / sigma from the table the prologue just refreshed
+            n_t, n_s = (rows if t_model.numel() > 1 else 1), (rows if sigma.numel() > 1 else 1)
+            st.t_model, st.sigma_model = ws.coef[:n_t, _cabi.LP_C_TMODEL], ws.coef[:n_s, _cabi.LP_C_RSIGMA]
+        else:
+            st.t_model, st.sigma_model = t_model, sigma
 
         # ---- replace-step source (lanpaint.py:84-94) --------------------------------
         ms = self.inner_model.inner_model.model_sampling
@@ -492,58 +548,66 @@ class LanPaint:
         else:        # per-row sigma: the reference emulates the FLOW form elementwise (lanpaint.py:89-92)
             d.replace_kind, d.noise_scale = LP_REPLACE_FLOW, float(getattr(ms, "noise_scale", 1.0))
 
-        compat = self._overridden("langevin_dynamics") or self._overridden("score_model") or \
+        st.compat = self._overridden("langevin_dynamics") or self._overridden("score_model") or \
             self._overridden("prepare_step_size")
-        if n_steps > 0 and float(self.step_size) <= 0.0 and not compat:
+        if n_steps > 0 and float(self.step_size) <= 0.0 and not st.compat:
             n_steps = 0          # dtx <= 0: every iteration returns immediately (lanpaint.py:205)
+        st.n_steps = n_steps
 
-        # model-space buffers handed to the backbone; fresh per call so the tensor the final model call
-        # saw stays valid after we return.  x_final (fp32) is the x that is written back in place; with
-        # a half-precision model_dtype the in-loop emits go to a separate buffer in that dtype.
-        x_final = torch.empty_like(xc)
-        if self.model_dtype is None:
-            x_in, xin_flag = x_final, 0
+        # model-space buffers handed to the backbone.  Eager: fresh per call so the tensor the final model call
+        # saw stays valid after we return.  Replay: owned by the captured call's workspace.  x_final (fp32) is
+        # the x that is written back in place; with a half-precision model_dtype the in-loop emits go to a
+        # separate buffer in that dtype.
+        if ws.static_io:
+            st.x_final, st.x_in = ws.x_final, ws.x_in
         else:
-            x_in = torch.empty_like(xc, dtype=self.model_dtype)
-            xin_flag = LP_FL_XIN_BF16 if self.model_dtype == torch.bfloat16 else LP_FL_XIN_F16
-        self._emit_loop = (x_in.data_ptr(), xin_flag)
-        self._emit_final = (x_final.data_ptr(), 0)
-
-        def emit(final):
-            ptr, fl = self._emit_final if final else self._emit_loop
-            d.x_in = ptr
-            return fl
+            st.x_final = torch.empty_like(xc)
+            st.x_in = st.x_final if self.model_dtype is None else torch.empty_like(xc, dtype=self.model_dtype)
+        st.xin_flag = 0 if self.model_dtype is None else (LP_FL_XIN_BF16 if self.model_dtype == torch.bfloat16 else LP_FL_XIN_F16)
 
         d.x = xc.data_ptr()
         d.xi_post = d.xi_pre = None
         d.rng_offset_ptr = None
         d.rng_seed = int(self.philox_seed if self.philox_seed is not None else (seed or 0)) & 0xFFFFFFFFFFFFFFFF
-        d.flags, d.phases = base_flags | emit(n_steps == 0), LP_PH_REPLACE | LP_PH_EMIT
+        d.flags, d.phases = base_flags | self._emit(st, n_steps == 0), LP_PH_REPLACE | LP_PH_EMIT
         self._launch_step(stream)
+        st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
+        st.k0_desc = _cabi.LpStepDesc.from_buffer_copy(d) if ws.static_io else None
+        return st
 
-        # ---- think loop ---------------------------------------------------------------
-        if flow:
-            t_model = self.remove_none_dims(self.add_none_dims(Flow_t))
-        else:
-            t_model = self.remove_none_dims(self.add_none_dims(current_times[0]))
-        stopper = LanPaintEarlyStopper.from_options(
-            model_options=model_options if isinstance(model_options, dict) else None, latent_mask=m, abt=abt,
-            default_threshold=self.early_stop_threshold, default_patience=self.early_stop_patience,
-            default_distance_fn=self.early_stop_hook)
+    def _emit(self, st, final):
+        """Point the EMIT phase at the fp32 written-back x (final) or at the backbone-input buffer (in loop)."""
+        d = self._desc
+        if final:
+            d.x_in = st.x_final.data_ptr()
+            return 0
+        d.x_in = st.x_in.data_ptr()
+        return st.xin_flag
+
+    # ---- think loop + final backbone call (the part a hipGraph captures) -------------------------------------
+    def _think_and_final_model(self, st, model_options, seed):
+        d, ws, shape, base_flags, n_steps, stream = self._desc, st.ws, st.shape, st.base_flags, st.n_steps, st.stream
+        # a replayed capture bakes the descriptor of every launch: re-point the per-call fields it reads
+        d.n_el, d.el_per_row, d.rows = st.n_el, st.n_el // st.rows, st.rows
+        stopper = None
+        if self._capturing is None:
+            stopper = LanPaintEarlyStopper.from_options(
+                model_options=model_options if isinstance(model_options, dict) else None, latent_mask=st.m, abt=st.abt,
+                default_threshold=self.early_stop_threshold, default_patience=self.early_stop_patience,
+                default_distance_fn=self.early_stop_hook)
         ran = 0
-        if compat:
-            ran = self._loop_compat(ws, shape, m, y, abt, current_times, n_steps, model_options, seed, stopper)
+        if st.compat:
+            ran = self._loop_compat(ws, shape, st.m, st.y, st.abt, st.current_times, n_steps, model_options, seed, stopper)
             d.phases = LP_PH_EMIT
-            d.flags = base_flags | emit(True)
+            d.flags = base_flags | self._emit(st, True)
             self._launch_step(stream)
         elif stopper is not None:
-            ran = self._loop_unfused(ws, shape, x_in, t_model, base_flags, n_steps, model_options, seed, stopper,
-                                     stream, m, y, current_times, emit)
+            ran = self._loop_unfused(st, n_steps, model_options, seed, stopper)
         else:
             for i in range(n_steps):
                 last = i == n_steps - 1
-                alive = self._set_model_output(d, self.inner_model(x_in, t_model, model_options=model_options, seed=seed),
-                                               base_flags | emit(last), shape)
+                alive = self._set_model_output(d, self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed),
+                                               base_flags | self._emit(st, last), shape)
                 d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
                 self._set_xi(d, ws.x_t, want_pre=not last)
                 self._launch_step(stream)
@@ -551,18 +615,26 @@ class LanPaint:
             ran = n_steps
         self.iterations_run += ran
         self.last_inner_steps = ran
+        x_model = st.x_final if self.model_dtype is None else st.x_final.to(self.model_dtype)
+        return self.inner_model(x_model, st.sigma_model, model_options=model_options, seed=seed)     # lanpaint.py:151-153
 
-        # ---- final denoise + known-region reprojection + write-back (lanpaint.py:144-157) ----
-        x_model = x_final if self.model_dtype is None else x_final.to(self.model_dtype)
-        final = self.inner_model(x_model, sigma, model_options=model_options, seed=seed)
-        f = self._fdesc
+    # ---- epilogue: known-region reprojection + in-place write-back (lanpaint.py:144-157) ----------------------
+    def _fill_final_desc(self, f, st, final, out, allow_convert=True):
+        """lp_finalize descriptor for this call.  Returns False when a backbone output had to be converted /
+        made dense (then the descriptor points at a temporary and must not be reused for later replays)."""
+        shape = st.shape
+        converted = []
 
         def dense(t):
+            t0 = t
             if t.shape != shape:
                 t = t.expand(shape)
             if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
                 t = t.float()
-            return t if t.is_contiguous() else t.contiguous()
+            t = t if t.is_contiguous() else t.contiguous()
+            if t is not t0:
+                converted.append(t)
+            return t
 
         uncond = None
         if isinstance(final, FusedCFGHeads) and final._heads is None and final.cond.dtype == final.uncond.dtype:
@@ -570,24 +642,28 @@ class LanPaint:
             f.cfg_scale = final.scale
         else:
             out_model = dense(self.unpack_model_output(final)[0])
-        out = torch.empty_like(xc)
-        f.n_el = n_el
+        f.n_el = st.n_el
         f.flags = (LP_FL_X0_BF16 if out_model.dtype == torch.bfloat16 else
                    LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0) | (LP_FL_CFG_FUSED if uncond is not None else 0) \
-            | (LP_FL_MASK_U8 if m_u8 is not None else 0)
+            | (LP_FL_MASK_U8 if st.m_u8 is not None else 0)
         f.uncond = uncond.data_ptr() if uncond is not None else None
-        f.model_out, f.y = out_model.data_ptr(), y.data_ptr()
-        f.mask = m_u8.data_ptr() if m_u8 is not None else m.data_ptr()
-        f.x_src, f.x_dst, f.out = x_final.data_ptr(), xc.data_ptr(), out.data_ptr()
-        if self._capturing is not None and self.rng == "philox":
-            f.rng_bump_ptr, f.rng_bump = self._capturing.data_ptr(), self._cap_offset
-        else:
-            f.rng_bump_ptr, f.rng_bump = None, 0
-        _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
-        if xc is not input_x:
-            input_x.copy_(xc)
-        del keep
-        return out if out.dtype == input_x.dtype else out.to(input_x.dtype)
+        f.model_out, f.y = out_model.data_ptr(), st.y.data_ptr()
+        f.mask = st.m_u8.data_ptr() if st.m_u8 is not None else st.m.data_ptr()
+        f.x_src, f.x_dst, f.out = st.x_final.data_ptr(), st.xc.data_ptr(), out.data_ptr()
+        f.rng_bump_ptr, f.rng_bump = None, 0
+        self._final_alive = (out_model, uncond)
+        return not converted
+
+    def _epilogue(self, st, final, rng_bump=None):
+        f, xc = self._fdesc, st.xc
+        out = torch.empty_like(xc)
+        self._fill_final_desc(f, st, final, out)
+        if rng_bump is not None:       # replayed Philox launches read a device-side sequence counter: advance it
+            f.rng_bump_ptr, f.rng_bump = rng_bump[0].data_ptr(), int(rng_bump[1])
+        _cabi.check(self._lib.lp_finalize(ctypes.byref(f), st.stream), "lp_finalize")
+        if xc is not st.input_x:
+            st.input_x.copy_(xc)
+        return out if out.dtype == st.input_x.dtype else out.to(st.input_x.dtype)
 
     # ------------------------------------------------------------------ xi plumbing
     def _set_xi(self, d, like, want_pre, want_post=True):
@@ -620,20 +696,19 @@ class LanPaint:
         ws.x0s.append(buf)
         return buf
 
-    def _loop_unfused(self, ws, shape, x_in, t_model, base_flags, n_steps, model_options, seed, stopper, stream, m, y,
-                      current_times, emit):
+    def _loop_unfused(self, st, n_steps, model_options, seed, stopper):
         """Early stop enabled: the stopper decides after every iteration, so the POST
         half of iteration i cannot be fused with the PRE half of iteration i+1."""
-        d = self._desc
+        d, ws, shape, base_flags, stream = self._desc, st.ws, st.shape, st.base_flags, st.stream
         args = None
         ran = 0
         for i in range(n_steps):
             x_t_before = ws.x_t.clone() if args is None or stopper.has_custom_distance_fn else None
             if i > 0:
-                d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags | emit(False)
+                d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags | self._emit(st, False)
                 self._set_xi(d, ws.x_t, want_pre=True, want_post=False)
                 self._launch_step(stream)
-            output = self.inner_model(x_in, t_model, model_options=model_options, seed=seed)
+            output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
             x0s = self._x0s_buffer(ws, [args.x0 if args else None, stopper.x0_anchor])
             alive = self._set_model_output(d, output, base_flags | LP_FL_WRITE_X0S, shape)
             d.x0s = x0s.data_ptr()
@@ -643,14 +718,14 @@ class LanPaint:
             del alive
             prev_args, args = args, LangevinState(None, ws.C, x0s)
             ran += 1
-            ctx = {"step": i, "steps_done": i + 1, "n_steps": n_steps, "mask": m, "latent_image": y,
-                   "current_times": current_times, "seed": seed}
+            ctx = {"step": i, "steps_done": i + 1, "n_steps": n_steps, "mask": st.m, "latent_image": st.y,
+                   "current_times": st.current_times, "seed": seed}
             if stopper.step(i=i, n_steps=n_steps, x_t_before=x_t_before, x_t_after=ws.x_t,
                             x_t_prev_for_custom=x_t_before if stopper.has_custom_distance_fn else None,
                             prev_args=prev_args, args=args, ctx=ctx):
                 break
         d.x0s = None
-        d.phases, d.flags = LP_PH_EMIT, base_flags | emit(True)
+        d.phases, d.flags = LP_PH_EMIT, base_flags | self._emit(st, True)
         self._launch_step(stream)
         return ran
 
@@ -733,8 +808,8 @@ class LanPaint:
             ve_r, abt_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1))
             step_r = _as_f32c((step_t * sx0).reshape(-1))
             _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), ve_r.data_ptr(), int(ve_r.numel() > 1), abt_r.data_ptr(),
-                                      int(abt_r.numel() > 1), None, 0, step_r.data_ptr(), int(step_r.numel() > 1), rows,
-                                      coef.data_ptr(), stream), "lp_coeffs")
+                                      int(abt_r.numel() > 1), None, 0, step_r.data_ptr(), int(step_r.numel() > 1), None, 0,
+                                      rows, coef.data_ptr(), stream), "lp_coeffs")
             d.step_size, d.min_step_frac = hyp.step_size, 0.0
             d.coef = coef.data_ptr()
         d.rng_seed = int(self.philox_seed or 0)

@@ -45,7 +45,7 @@ def test_coeffs_table_matches_closed_form(lib, flow, sigmas, msf, lam, beta):
     table = torch.empty((rows, _cabi.LP_COEF_STRIDE), dtype=torch.float32, device="cuda")
     ve_d, abt_d, s_d = tt(ve.astype(np.float32)), tt(abt.astype(np.float32)), tt(s)
     _cabi.check(lib.lp_coeffs(ctypes.byref(h), ve_d.data_ptr(), 1, abt_d.data_ptr(), 1, s_d.data_ptr(), 1, None, 0,
-                              rows, table.data_ptr(), _stream()))
+                              s_d.data_ptr(), 1, rows, table.data_ptr(), _stream()))
     t = table.cpu().numpy()
     for r in range(rows):
         a32 = np.float32(abt[r])
@@ -64,7 +64,7 @@ def test_coeffs_table_matches_closed_form(lib, flow, sigmas, msf, lam, beta):
             assert t[r, base + _cabi.LP_R_A] == pytest.approx(a, rel=2e-7)
             assert want[g]["A"] == pytest.approx(a, rel=1e-6)
         assert t[r, _cabi.LP_C_ABT] == a32 and t[r, _cabi.LP_C_OMA] == oma
-        assert t[r, _cabi.LP_C_RSIGMA] == s[r] and t[r, _cabi.LP_C_VALID] == 1.0
+        assert t[r, _cabi.LP_C_RSIGMA] == s[r] and t[r, _cabi.LP_C_VALID] == 1.0 and t[r, _cabi.LP_C_TMODEL] == s[r]
         scale = (np.sqrt(a32) + np.sqrt(np.float32(1) - a32)) if flow else np.sqrt(np.float32(1) + np.float32(ve[r]) ** 2)
         assert t[r, _cabi.LP_C_SCALE] == pytest.approx(float(scale), rel=2e-7)
         assert t[r, _cabi.LP_C_DTX] == step
