@@ -141,6 +141,7 @@ def run_gpu(args):
         job = lpd.broadcast_job({"mask": mask, "y": y} if rank == 0 else None, src=0, device=dev)
         mask, y = job["mask"], job["y"]
         x0 = (float(sig_np[0]) * noise + (1 - float(sig_np[0])) * y) if flow else (y + noise * float(sig_np[0]))
+    mask = attach_mask_format(mask, args.mask_format)          # once per job, outside the timed region
     b = shape[0]
     sig_list = [torch.full((b,), float(s), dtype=torch.float32, device=dev) for s in sig_np]
     times_list = [times_from_sigma(s, flow) for s in sig_list]
@@ -210,7 +211,7 @@ def run_gpu(args):
         "config": {"workload": f"{args.workload}: latent {'x'.join(map(str, shape))} per GPU, {n_sig} sigmas x "
                                f"{n_think} think iterations, 50% box mask, stub backbone x->(0.9x,0.8x), "
                                f"{'flow' if flow else 'VE/Karras'} schedule",
-                   "rng": args.rng, "launch": "hipGraph replay per sigma call" if args.graph else "eager launches",
+                   "rng": args.rng, "mask_format": args.mask_format, "launch": "hipGraph replay per sigma call" if args.graph else "eager launches",
                    "replicas": args.gpus, "iterations_per_step": n_sig * n_think,
                    "latent_elements_per_gpu": n_el, "lambda": HYPER["Lambda"], "beta": HYPER["Beta"],
                    "step_size": HYPER["StepSize"]},
@@ -300,6 +301,19 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
             "timer": "hipExtLaunchKernelGGL start/stop events per dispatch (kernel begin->end) on the launch stream"}
 
 
+MASK_FORMAT = "bits"          # set from --mask-format; the standalone launches follow the headline's format
+
+
+def attach_mask_format(mask, fmt):
+    """The job-setup step that hands the kernels a compact copy of a binary mask."""
+    if fmt == "bits":
+        import lanpaint_amd
+        return lanpaint_amd.pack_mask(mask)
+    if fmt == "u8":
+        mask._lp_u8 = mask.to(torch.uint8).contiguous()
+    return mask
+
+
 def standalone_step(_cabi, workload, dev, phase=None):
     """A self-contained steady-state lp_step launch on synthetic buffers of `workload`'s shape
     (used for the HBM-bound supplementary roofline and by scripts/microbench_step.py)."""
@@ -323,11 +337,16 @@ def standalone_step(_cabi, workload, dev, phase=None):
     d = _cabi.LpStepDesc()
     d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
     d.phases = phase or (_cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT)
+    mask = attach_mask_format(mask, MASK_FORMAT)
     d.flags = _cabi.LP_FL_FLOW if flow else 0
     d.replace_kind, d.lambda_, d.one_plus_lambda, d.beta = _cabi.LP_REPLACE_VE, h.lambda_, h.one_plus_lambda, h.beta
     d.step_size, d.noise_scale = h.step_size, 1.0
     d.coef, d.x, d.noise, d.y, d.mask = (coef.data_ptr(), bufs["x"].data_ptr(), bufs["noise"].data_ptr(),
                                          bufs["y"].data_ptr(), mask.data_ptr())
+    if MASK_FORMAT == "bits":
+        d.mask, d.flags = mask._lp_bits.data_ptr(), d.flags | _cabi.LP_FL_MASK_BITS
+    elif MASK_FORMAT == "u8":
+        d.mask, d.flags = mask._lp_u8.data_ptr(), d.flags | _cabi.LP_FL_MASK_U8
     d.x_t, d.C, d.x0, d.x0_big, d.x_in = (bufs[k].data_ptr() for k in ("x_t", "C", "x0", "x0b", "x_in"))
     d.rng_seed = 1
     keep = (bufs, mask, coef, sig, ve, abt)
@@ -527,6 +546,9 @@ def main():
     ap.add_argument("--workload", default="c2_sdxl", choices=sorted(WORKLOADS))
     ap.add_argument("--rng", default="philox", choices=["philox", "torch"])
     ap.add_argument("--graph", type=int, default=1, help="1: replay each sigma call as one hipGraph (default); 0: eager launches")
+    ap.add_argument("--mask-format", default="bits", choices=["bits", "u8", "f32"],
+                    help="how the (binary) latent mask is streamed by the kernels: bit-packed once per job by "
+                         "lanpaint_amd.pack_mask (what KSamplerX0Inpaint does), one byte, or the reference's fp32")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -535,6 +557,8 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")
     ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")
     args = ap.parse_args()
+    global MASK_FORMAT
+    MASK_FORMAT = args.mask_format
     run_gpu(args)
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 3
+#define LP_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -106,6 +106,10 @@ typedef struct lp_hyper {
                                           backbone pass; the kernel forms both CFG heads itself,
                                           head = uncond + (cond - uncond) * scale  (nodes.py:161-175 +
                                           ComfyUI cfg_function) instead of 2 x 3 eager elementwise passes */
+#define LP_FL_MASK_BITS     (1u << 11) /* mask buffer is bit-packed latent_mask (1 = known): element i is
+                                          bit (i & 31) of 32-bit word (i >> 5), as lp_pack_mask writes it;
+                                          0.125 B/element instead of 4.  Not combinable with MASK_DENOISE /
+                                          MASK_U8; binary masks only (SURVEY 8b `mask_kind`)            */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 
@@ -253,6 +257,16 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
  * with dst batch b reading src batch b % src_b and dst channel c reading src
  * channel c % src_c (the reference's repeat + slice).  `binarize`: 0 = copy value,
  * 1 = also apply 1 - (v > 0.5) (nodes.py:281-283).                              */
+/* Bytes of the bit-packed form of an n_el-element mask (whole 64-bit ballot words). */
+#define LP_MASK_BITS_BYTES(n_el) ((((n_el) + 63) / 64) * 8)
+
+/* Pack a binary fp32 mask into the LP_FL_MASK_BITS layout: one wave64 ballot per 64 elements.
+ * flags = 0: `mask` is latent_mask, bit = (v > 0.5); flags = LP_FL_MASK_DENOISE: `mask` is ComfyUI's
+ * denoise_mask, bit = !(v > 0.5) (nodes.py:281-283 folded in).  `bits` holds LP_MASK_BITS_BYTES(n_el)
+ * bytes, 8-byte aligned; tail bits are 0.  `nonbinary` (nullable, device int32) is set to 1 when an
+ * input value is neither 0 nor 1 (soft mask: the packed form would not be equivalent).             */
+int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream);
+
 int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
                     float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
                     int32_t temporal_taps, int32_t binarize, void* stream);

@@ -7,7 +7,7 @@ MI355X (gfx950), behind the reference's own Python API.
 Importing the engine loads liblanpaint_hip.so and fails loudly when it is missing.
 """
 from .types import FusedCFGHeads, LangevinState  # noqa: F401
-from .lanpaint import LanPaint  # noqa: F401
+from .lanpaint import LanPaint, pack_mask  # noqa: F401
 
-__all__ = ["LanPaint", "LangevinState", "FusedCFGHeads"]
+__all__ = ["LanPaint", "LangevinState", "FusedCFGHeads", "pack_mask"]
 __version__ = "0.1.0"

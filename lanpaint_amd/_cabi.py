@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -27,7 +27,12 @@ LP_C_REGION0, LP_C_REGION1, LP_C_TMODEL = 12, 22, 32
 LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT = 1, 2, 4, 8, 16
 LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
-LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED = 256, 512, 1024
+LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED, LP_FL_MASK_BITS = 256, 512, 1024, 2048
+
+
+def mask_bits_bytes(n_el: int) -> int:
+    """LP_MASK_BITS_BYTES of the header."""
+    return ((int(n_el) + 63) // 64) * 8
 LP_REPLACE_KNOWN, LP_REPLACE_VE, LP_REPLACE_FLOW = 0, 1, 2
 
 
@@ -93,6 +98,7 @@ EXPORTS = {
     "lp_boundary_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "lp_wmse_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_void_p]),
+    "lp_pack_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_reshape_mask": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]),
 }
 

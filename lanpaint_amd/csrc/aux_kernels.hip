@@ -231,10 +231,12 @@ int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
     if (d.n_el <= 0 || !d.model_out || !d.y || !d.mask || !d.out) return LP_E_INVALID;
     if (d.x_dst && !d.x_src) return LP_E_INVALID;
     if ((d.flags & LP_FL_CFG_FUSED) && !d.uncond) return LP_E_INVALID;
+    if ((d.flags & LP_FL_MASK_BITS) && ((d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_DENOISE)) || !aligned(d.mask, 4)))
+        return LP_E_INVALID;
     const bool half = x0_dtype(d.flags) != DT_F32;
     const bool vec4 = (d.n_el % 4 == 0) && aligned(d.model_out, half ? 8 : 16) && aligned(d.uncond, half ? 8 : 16) &&
                       aligned(d.y, 16) &&
-                      aligned(d.mask, (d.flags & LP_FL_MASK_U8) ? 4 : 16) && aligned(d.x_src, 16) &&
+                      aligned(d.mask, (d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_BITS)) ? 4 : 16) && aligned(d.x_src, 16) &&
                       aligned(d.x_dst, 16) && aligned(d.out, 16);
     const int vec = vec4 ? 4 : 1;
     const int64_t groups = d.n_el / vec;
@@ -437,6 +439,39 @@ int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int 
     if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(lp_reshape_mask_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, src, sb, sc, sf,
                        sh, sw, dst, db, dc, df, dh, dw, taps, binarize);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------
+// bit-packed mask: one wave64 ballot turns 64 consecutive elements into one 64-bit word
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lp_pack_mask_kernel(const float* __restrict__ mask, int64_t n_el, uint32_t flags,
+                                                           unsigned long long* __restrict__ bits,
+                                                           int32_t* __restrict__ nonbinary) {
+    const int64_t words = (n_el + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    bool soft = false;
+    for (int64_t w = wave; w < words; w += n_waves) {
+        const int64_t i = w * 64 + lane;
+        const float v = (i < n_el) ? mask[i] : ((flags & LP_FL_MASK_DENOISE) ? 1.0f : 0.0f);
+        soft |= !(v == 0.0f || v == 1.0f);
+        const bool hi = v > 0.5f;
+        const unsigned long long word = __ballot((flags & LP_FL_MASK_DENOISE) ? !hi : hi);
+        if (lane == 0) bits[w] = word;
+    }
+    if (nonbinary && !(flags & LP_FL_MASK_DENOISE) && __ballot(soft) != 0ull && lane == 0) *nonbinary = 1;
+}
+
+int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary,
+                       hipStream_t stream) {
+    if (!mask || !bits || n_el <= 0 || (flags & ~LP_FL_MASK_DENOISE) || !aligned(bits, 8)) return LP_E_INVALID;
+    const int64_t words = (n_el + 63) / 64;
+    int64_t bx = (words + 3) / 4;                       // 4 waves per block
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(lp_pack_mask_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, mask, n_el, flags,
+                       static_cast<unsigned long long*>(bits), nonbinary);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 

@@ -20,6 +20,7 @@ int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, ui
 int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream);
 int wmse_dispatch(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
                   double* scratch, int scratch_blocks, hipStream_t stream);
+int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, hipStream_t stream);
 int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int sw, float* dst, int db, int dc, int df,
                           int dh, int dw, int taps, int binarize, hipStream_t stream);
 }  // namespace lp
@@ -80,6 +81,10 @@ int lp_boundary_ring(const float* mask, float* ring, int64_t planes, int32_t hei
 int lp_wmse_pair(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
                  double* block_scratch, int32_t scratch_blocks, void* stream) {
     return lp::wmse_dispatch(a, b, mask, ring, n_el, acc, block_scratch, scratch_blocks, as_stream(stream));
+}
+
+int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream) {
+    return lp::pack_mask_dispatch(mask, n_el, flags, bits, nonbinary, as_stream(stream));
 }
 
 int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,

@@ -139,6 +139,14 @@ __device__ __forceinline__ void store_any(void* __restrict__ p, int dt, int64_t 
 // reference's `1 - (denoise_mask > 0.5)` (nodes.py:281-283) on the fly.
 template <int V>
 __device__ __forceinline__ void load_mask(const void* __restrict__ p, uint32_t flags, int64_t i, float (&m)[V]) {
+    if (flags & LP_FL_MASK_BITS) {
+        // 64 lanes x V elements share 2*V words: the loads broadcast out of one cache line
+        const uint32_t w = static_cast<const uint32_t*>(p)[i >> 5];
+        const uint32_t sh = static_cast<uint32_t>(i) & 31u;          // V == 4: i % 4 == 0, the nibble never straddles
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = static_cast<float>((w >> (sh + k)) & 1u);
+        return;
+    }
     if (flags & LP_FL_MASK_U8) {
         const uint8_t* q = static_cast<const uint8_t*>(p) + i;
         if constexpr (V == 4) {

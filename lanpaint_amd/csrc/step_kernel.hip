@@ -393,6 +393,8 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if (d.n_el <= 0 || d.rows <= 0 || d.el_per_row <= 0 || d.n_el != d.el_per_row * d.rows) return LP_E_INVALID;
     if (d.rows > 65535) return LP_E_UNSUPPORTED;
     if (!d.mask || !d.x_t) return LP_E_INVALID;
+    if ((d.flags & LP_FL_MASK_BITS) && ((d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_DENOISE)) || !aligned(d.mask, 4)))
+        return LP_E_INVALID;
     const uint32_t ph = d.phases;
     if (ph == 0 || (ph & ~0x1fu)) return LP_E_INVALID;
     if ((ph & LP_PH_POST_FIRST) && (ph & LP_PH_POST_STEADY)) return LP_E_INVALID;
@@ -423,7 +425,7 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     const bool x0_half = x0_dtype(d.flags) != DT_F32, xin_half = xin_dtype(d.flags) != DT_F32;
     const bool can_vec4 = (d.el_per_row % 4 == 0) && aligned(d.x, f_al) && aligned(d.known, f_al) &&
                           aligned(d.noise, f_al) && aligned(d.y, f_al) &&
-                          aligned(d.mask, (d.flags & LP_FL_MASK_U8) ? 4 : f_al) && aligned(d.x_t, f_al) &&
+                          aligned(d.mask, (d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_BITS)) ? 4 : f_al) && aligned(d.x_t, f_al) &&
                           aligned(d.C, f_al) && aligned(d.x0s, f_al) && aligned(d.x0, x0_half ? half_al : f_al) &&
                           aligned(d.x0_big, x0_half ? half_al : f_al) && aligned(d.x_in, xin_half ? half_al : f_al) &&
                           aligned(d.xi_post, f_al) && aligned(d.xi_pre, f_al) && aligned(d.abt_el, f_al) &&

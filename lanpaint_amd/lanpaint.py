@@ -29,7 +29,7 @@ from functools import partial
 import torch
 
 from . import _cabi
-from ._cabi import (LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
+from ._cabi import (LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_BITS, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
                     LP_PH_EMIT, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_REPLACE, LP_REPLACE_FLOW,
                     LP_REPLACE_KNOWN, LP_REPLACE_VE)
 from .earlystop import LanPaintEarlyStopper
@@ -39,6 +39,42 @@ def _as_f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.to(torch.float32).contiguous()
     return t
+
+
+def _compact_mask(latent_mask, shape, device):
+    """(tensor, LP_FL_MASK_* flag) of the compact copy attached to a binary mask, or (None, 0).
+    `_lp_bits`: uint8 storage of the bit-packed form (`pack_mask`); `_lp_u8`: one byte per element."""
+    bits = getattr(latent_mask, "_lp_bits", None)
+    if bits is not None and bits.dtype == torch.uint8 and bits.is_contiguous() and bits.device == device \
+            and tuple(latent_mask.shape) == tuple(shape) and bits.numel() == _cabi.mask_bits_bytes(latent_mask.numel()):
+        return bits, LP_FL_MASK_BITS
+    u8 = getattr(latent_mask, "_lp_u8", None)
+    if u8 is not None and u8.dtype == torch.uint8 and u8.shape == shape and u8.is_contiguous() and u8.device == device:
+        return u8, LP_FL_MASK_U8
+    return None, 0
+
+
+def pack_mask(latent_mask: torch.Tensor, *, denoise_mask: bool = False, check: bool = True) -> torch.Tensor:
+    """Attach the bit-packed form of a BINARY mask (LP_FL_MASK_BITS, 1 bit per latent element) so that every
+    launch of the think loop reads 0.125 B instead of 4 B per element for it.  Returns the fp32 latent mask
+    (1 = known) carrying `_lp_bits`; with `denoise_mask=True` the input is ComfyUI's denoise_mask and
+    nodes.py:281-283 (`1 - (dm > 0.5)`) is folded into the same launch.  `check` (one host read) rejects soft
+    masks, for which the packed form would not be equivalent.  The mask must not be modified afterwards."""
+    if not latent_mask.is_cuda:
+        raise ValueError("pack_mask needs a mask on a HIP device")
+    src = _as_f32c(latent_mask)
+    n = src.numel()
+    bits = torch.empty(_cabi.mask_bits_bytes(n), dtype=torch.uint8, device=src.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=src.device) if (check and not denoise_mask) else None
+    with torch.cuda.device(src.device):
+        _cabi.check(_cabi.load().lp_pack_mask(src.data_ptr(), n, _cabi.LP_FL_MASK_DENOISE if denoise_mask else 0,
+                                              bits.data_ptr(), flag.data_ptr() if flag is not None else None,
+                                              torch.cuda.current_stream(src.device).cuda_stream), "lp_pack_mask")
+    if flag is not None and int(flag.item()):
+        raise ValueError("pack_mask: the mask has values other than 0 and 1; soft masks cannot be bit-packed")
+    out = (1 - (src > 0.5).to(torch.float32)) if denoise_mask else src
+    out._lp_bits = bits
+    return out
 
 
 def _noise_scaling_kind(model_sampling) -> str:
@@ -80,7 +116,7 @@ class _Workspace:
 
 class _CallState:
     """Everything one sigma call carries from its prologue to its loop and epilogue."""
-    __slots__ = ("input_x", "xc", "shape", "n_el", "rows", "flow", "ws", "stream", "sigma", "y", "m", "m_u8", "abt",
+    __slots__ = ("input_x", "xc", "shape", "n_el", "rows", "flow", "ws", "stream", "sigma", "y", "m", "m_c", "m_flag", "abt",
                  "current_times", "base_flags", "keep", "t_model", "sigma_model", "compat", "n_steps", "x_final", "x_in",
                  "xin_flag", "k0_desc", "replace_kind_static")
 
@@ -349,10 +385,10 @@ class LanPaint:
         and the finalise is captured (N x [backbone, fused step] + the final backbone call): the prologue
         (lp_coeffs, replace) and the epilogue (lp_finalize) are ordinary launches that read / write the
         caller's tensors directly, so nothing of x / noise / out has to be staged through static buffers."""
-        m_u8 = getattr(latent_mask, "_lp_u8", None)
+        m_c, _ = _compact_mask(latent_mask, x.shape, x.device)
         # every pointer the captured launches bake in is part of the key (y and the mask; the tensors stay the caller's)
         key = (tuple(x.shape), x.device.index, int(n_steps), bool(IS_FLUX), bool(IS_FLOW), self.latent_image.data_ptr(),
-               latent_mask.data_ptr(), m_u8.data_ptr() if m_u8 is not None else 0, int(sigma.numel()),
+               latent_mask.data_ptr(), m_c.data_ptr() if m_c is not None else 0, int(sigma.numel()),
                tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng)
         cap = self._graphs.get(key)
         if cap is None:
@@ -464,13 +500,9 @@ class LanPaint:
         nz = _as_f32c(self.noise if self.noise.shape == shape else self.noise.expand(shape))
         m = latent_mask if latent_mask.shape == shape else latent_mask.expand(shape)
         st.m = m = _as_f32c(m)
-        # a caller that KNOWS the mask is binary (KSamplerX0Inpaint builds it as 1 - (dm > 0.5)) may attach a
-        # uint8 copy: the kernels then read 1 byte instead of 4 per element for the mask stream
-        m_u8 = getattr(latent_mask, "_lp_u8", None)
-        if m_u8 is not None and not (m_u8.dtype == torch.uint8 and m_u8.shape == shape and m_u8.is_contiguous()
-                                     and m_u8.device == xc.device):
-            m_u8 = None
-        st.m_u8 = m_u8
+        # a caller that KNOWS the mask is binary (KSamplerX0Inpaint builds it as 1 - (dm > 0.5); `pack_mask`)
+        # may attach a compact copy: the kernels then read 1 bit / 1 byte instead of 4 bytes per element
+        st.m_c, st.m_flag = m_c, m_flag = _compact_mask(latent_mask, shape, xc.device)
 
         VE_Sigma, abt, Flow_t = current_times
         replace_sigma = sigma
@@ -491,13 +523,13 @@ class LanPaint:
             t_model = self.remove_none_dims(self.add_none_dims(current_times[0]))
 
         # ---- per-call descriptor --------------------------------------------------
-        st.base_flags = base_flags = (LP_FL_FLOW if flow else 0) | (LP_FL_MASK_U8 if m_u8 is not None else 0)
+        st.base_flags = base_flags = (LP_FL_FLOW if flow else 0) | m_flag
         hyp = self._fill_hyper(flow)
         d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
         d.lambda_, d.one_plus_lambda, d.beta = hyp.lambda_, hyp.one_plus_lambda, hyp.beta
         d.step_size, d.min_step_frac = hyp.step_size, hyp.min_step_frac
         d.y, d.x_t, d.C = y.data_ptr(), ws.x_t.data_ptr(), ws.C.data_ptr()
-        d.mask = m_u8.data_ptr() if m_u8 is not None else m.data_ptr()
+        d.mask = m_c.data_ptr() if m_c is not None else m.data_ptr()
         d.x0s = None
         d.abt_el = d.ve_el = d.rsig_el = d.corr_el = None
         keep = st.keep = [nz]          # tensors that must outlive the enqueued launches of this call
@@ -645,10 +677,10 @@ class LanPaint:
         f.n_el = st.n_el
         f.flags = (LP_FL_X0_BF16 if out_model.dtype == torch.bfloat16 else
                    LP_FL_X0_F16 if out_model.dtype == torch.float16 else 0) | (LP_FL_CFG_FUSED if uncond is not None else 0) \
-            | (LP_FL_MASK_U8 if st.m_u8 is not None else 0)
+            | st.m_flag
         f.uncond = uncond.data_ptr() if uncond is not None else None
         f.model_out, f.y = out_model.data_ptr(), st.y.data_ptr()
-        f.mask = st.m_u8.data_ptr() if st.m_u8 is not None else st.m.data_ptr()
+        f.mask = st.m_c.data_ptr() if st.m_c is not None else st.m.data_ptr()
         f.x_src, f.x_dst, f.out = st.x_final.data_ptr(), st.xc.data_ptr(), out.data_ptr()
         f.rng_bump_ptr, f.rng_bump = None, 0
         self._final_alive = (out_model, uncond)

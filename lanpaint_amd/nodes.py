@@ -27,7 +27,7 @@ import torch
 
 from . import _cabi
 from .blend import MaskBlend, gaussian_kernel_2d, merge_video_with_mask  # noqa: F401
-from .lanpaint import LanPaint
+from .lanpaint import LanPaint, pack_mask
 from .types import FusedCFGHeads
 
 try:                                    # ComfyUI present (or stubbed by tests)
@@ -270,9 +270,11 @@ class KSamplerX0Inpaint:
         denoise_mask_function may hand back a fresh tensor at a recycled address every step)."""
         c = self._mask_cache
         if c is None or c[0]() is not denoise_mask or c[1] != denoise_mask._version:
-            keep = denoise_mask > 0.5
-            latent_mask = 1 - keep.float()
-            latent_mask._lp_u8 = (~keep).to(torch.uint8).contiguous()          # binary by construction: 1 B/element stream
+            if denoise_mask.is_cuda:
+                # binary by construction: the think loop streams 1 bit / element for it (one ballot launch)
+                latent_mask = pack_mask(denoise_mask, denoise_mask=True)
+            else:
+                latent_mask = 1 - (denoise_mask > 0.5).float()
             self._mask_cache = c = (weakref.ref(denoise_mask), denoise_mask._version, latent_mask)
         return c[2]
 

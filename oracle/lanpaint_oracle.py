@@ -649,3 +649,21 @@ def merge_video_with_mask(orig: np.ndarray, inpainted: np.ndarray, mask: np.ndar
         m = _interp_nearest_exact(m, orig.shape[1:3])
     sm = smooth_mask(np.ascontiguousarray(m), blend_overlap)[..., None]
     return (orig * (1 - sm) + inpainted * sm).astype(np.float32)
+
+
+def pack_mask_bits(mask, denoise_mask=False):
+    """Bit-packed mask layout of include/lanpaint_hip.h (LP_FL_MASK_BITS; SURVEY 8b `mask_kind`): element i is bit
+    (i & 31) of little-endian 32-bit word (i >> 5), padded with zero bits to whole 64-bit words.  Bit = latent_mask
+    value (1 = known): `v > 0.5` of a binary latent mask, or `not (v > 0.5)` of ComfyUI's denoise_mask
+    (the reference's `1 - (denoise_mask > 0.5)`, nodes.py:281-283).  Returns uint8[((n + 63) // 64) * 8]."""
+    v = np.asarray(mask, dtype=np.float32).reshape(-1)
+    bit = ~(v > 0.5) if denoise_mask else (v > 0.5)
+    out = np.zeros(((v.size + 63) // 64) * 8, dtype=np.uint8)
+    packed = np.packbits(bit.astype(np.uint8), bitorder="little")
+    out[:packed.size] = packed
+    return out
+
+
+def unpack_mask_bits(bits, n_el):
+    """Inverse of pack_mask_bits: float32 latent mask of n_el elements."""
+    return np.unpackbits(np.asarray(bits, dtype=np.uint8), bitorder="little")[:n_el].astype(np.float32)

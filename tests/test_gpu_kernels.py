@@ -275,3 +275,37 @@ def test_sigma_times_bit_exact_vs_reference_cpu_ops(lib, flow):
                 assert float(got[3 * rows + 1]) == float((1.0 - abt).mean())
             for a, b in zip(ref_ops(sigma), (got[:rows], got[rows:2 * rows], got[2 * rows:3 * rows])):
                 torch.testing.assert_close(a.cpu(), b, rtol=2.5e-7, atol=0)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4 * 128 * 128, 16 * 21 * 60 * 104 + 7])
+@pytest.mark.parametrize("denoise", [False, True])
+def test_pack_mask_bit_exact(lib, n, denoise):
+    """lp_pack_mask (wave64 ballot) == the oracle's little-endian bit layout, tail bits zero."""
+    import torch
+    from lanpaint_amd import _cabi
+    from oracle.lanpaint_oracle import pack_mask_bits
+    rng = np.random.default_rng(n)
+    m = (rng.random(n) < 0.4).astype(np.float32)
+    src = torch.from_numpy(m).cuda()
+    bits = torch.full((_cabi.mask_bits_bytes(n),), 0xAB, dtype=torch.uint8, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _cabi.check(lib.lp_pack_mask(src.data_ptr(), n, _cabi.LP_FL_MASK_DENOISE if denoise else 0, bits.data_ptr(),
+                                 flag.data_ptr(), torch.cuda.current_stream().cuda_stream), "lp_pack_mask")
+    assert np.array_equal(bits.cpu().numpy(), pack_mask_bits(m, denoise_mask=denoise))
+    assert int(flag.item()) == 0
+
+
+def test_pack_mask_flags_soft_masks_and_rejects_bad_arguments(lib):
+    import torch
+    import lanpaint_amd
+    from lanpaint_amd import _cabi
+    soft = torch.tensor([0.0, 1.0, 0.25, 1.0] * 40, device="cuda")
+    with pytest.raises(ValueError):
+        lanpaint_amd.pack_mask(soft)
+    ok = lanpaint_amd.pack_mask(soft, denoise_mask=True)                 # the threshold makes it binary
+    assert torch.equal(ok, 1 - (soft > 0.5).float()) and ok._lp_bits.numel() == _cabi.mask_bits_bytes(160)
+    bits = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.lp_pack_mask(soft.data_ptr(), 0, 0, bits.data_ptr(), None, s) < 0
+    assert lib.lp_pack_mask(soft.data_ptr(), 160, _cabi.LP_FL_MASK_U8, bits.data_ptr(), None, s) < 0
+    assert lib.lp_pack_mask(None, 160, 0, bits.data_ptr(), None, s) < 0

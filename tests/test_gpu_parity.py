@@ -333,3 +333,62 @@ def test_uint8_mask_attachment_is_bitwise_equivalent():
             outs.append((x.cpu().numpy(), out.cpu().numpy()))
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
         assert_close(outs[1][0], g["x_out"], f"{name}: u8-mask x")
+
+
+def test_bit_packed_mask_is_bitwise_equivalent():
+    """pack_mask attaches the 1-bit/element form (LP_FL_MASK_BITS): identical results on golden cases (VEC=1 path)."""
+    import torch
+    import lanpaint_amd
+    from lanpaint_amd import LanPaint
+    for name in ("ve_basic", "ve_odd_numel", "flow_video5d", "ve_batch_rows"):
+        if name not in gc.CASES:
+            continue
+        case = gc.build_case(name)
+        g = load_golden(name)
+        outs = []
+        for attach in (False, True):
+            it = iter([torch.from_numpy(d).cuda() for d in xi_list(g)])
+            model = MODELS[case["model"]](flow=case["flow"])
+            eng = LanPaint(model, 5, 15.0, 5.0, 1.0, 0.2, IS_FLOW=case["flow"], rng=lambda like: next(it))
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+            mask = tt(case["mask"])
+            if attach:
+                mask = lanpaint_amd.pack_mask(mask)
+                assert hasattr(mask, "_lp_bits")
+            x = tt(case["x"].copy())
+            out = eng(x, tt(case["y"]), tt(case["noise"]), tt(case["sigma"]), mask, tuple(tt(t) for t in case["times"]), None, 0)
+            outs.append((x.cpu().numpy(), out.cpu().numpy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert_close(outs[1][0], g["x_out"], f"{name}: bit-mask x")
+
+
+def test_bit_packed_mask_vec4_rows_not_word_aligned():
+    """Float4 path (n_el > 512 Ki) with rows whose length is a multiple of 4 but not of 32: every row starts in
+    the middle of a mask word.  Philox noise, fp32 / u8 / bit masks must agree bitwise, eager and under graph replay."""
+    import torch
+    import lanpaint_amd
+    from lanpaint_amd import LanPaint
+    torch.manual_seed(5)
+    shape = (2, 4, 258, 262)
+    assert (shape[1] * shape[2] * shape[3]) % 32 == 16
+    y = torch.randn(shape, device="cuda")
+    noise = torch.randn(shape, device="cuda")
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    sig = torch.tensor([3.0, 1.5], device="cuda")
+    times = (sig.clone(), 1 / (1 + sig ** 2), torch.sqrt(1 - 1 / (1 + sig ** 2)))
+    res = []
+    for kind in ("f32", "u8", "bits", "f32_graph", "bits_graph"):
+        m = mask.clone()
+        if kind == "u8":
+            m._lp_u8 = m.to(torch.uint8)
+        elif kind.startswith("bits"):
+            m = lanpaint_amd.pack_mask(m)
+        eng = LanPaint(MODELS["linear_tuple"](flow=False), 4, 15.0, 5.0, 1.0, 0.2, rng="philox", philox_seed=11,
+                       graph=kind.endswith("graph"))
+        x = (y + noise * 3.0).clone()
+        out = eng(x, y, noise, sig, m, times, {}, 0)
+        res.append((x.cpu(), out.cpu()))
+    for r in res[1:3]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1])
+    # a replayed graph draws its Philox sequence numbers from the device-side counter: compare graph with graph
+    assert torch.equal(res[4][0], res[3][0]) and torch.equal(res[4][1], res[3][1])

@@ -113,3 +113,20 @@ def test_think_iteration_is_affine_in_state_and_noise(sigma, lamb, beta, flow, s
     want = a * run(*A) + b * run(*B)
     got = run(*AB)
     assert np.abs(got - want).max() <= 2e-4 * max(1.0, float(np.abs(want).max()))
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 700), st.booleans(), st.integers(0, 2**31 - 1))
+def test_mask_bit_packing_round_trip(n, denoise, seed):
+    """pack -> unpack is the identity on binary masks; word / bit positions follow the header's layout."""
+    from oracle.lanpaint_oracle import pack_mask_bits, unpack_mask_bits
+    rng = np.random.default_rng(seed)
+    m = (rng.random(n) < 0.5).astype(np.float32)
+    bits = pack_mask_bits(m, denoise_mask=denoise)
+    assert bits.dtype == np.uint8 and bits.size == ((n + 63) // 64) * 8
+    want = 1.0 - m if denoise else m
+    assert np.array_equal(unpack_mask_bits(bits, n), want)
+    words = bits.view("<u4")
+    for i in rng.integers(0, n, size=min(n, 16)):
+        assert (int(words[i >> 5]) >> (int(i) & 31)) & 1 == int(want[i])
+    assert not np.unpackbits(bits, bitorder="little")[n:].any()          # tail bits are zero
