@@ -41,6 +41,9 @@ WORKLOADS = {
     "c3_sdxl_b4": ((4, 4, 128, 128), False, 30, 5),
     "c4_flux":  ((1, 16, 64, 64), True, 28, 10),
     "c5_wan":   ((1, 16, 21, 60, 104), True, 30, 5),
+    # not BASELINE configs: larger batches of the video latent, to see the kernel once the fixed launch cost is amortised
+    "x_wan_b4": ((4, 16, 21, 60, 104), True, 30, 5),
+    "x_wan_b16": ((16, 16, 21, 60, 104), True, 30, 5),
 }
 HYPER = dict(NSteps=5, Friction=15.0, Lambda=5.0, Beta=1.0, StepSize=0.2, MinStepFrac=0.0)
 BYTES_PER_EL_STEADY = 36          # read x_t,x0,x0_BIG,y,m,C ; write x_t,C,x_in (fp32, in-kernel RNG)

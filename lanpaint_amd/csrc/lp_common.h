@@ -42,7 +42,10 @@ __device__ __forceinline__ float u01(uint32_t x) {
 __device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_t seed, float& z_post, float& z_pre) {
     uint32_t c0 = static_cast<uint32_t>(elem), c1 = static_cast<uint32_t>(seq);
     philox2x32_10(c0, c1, philox_key(seed, seq, elem));
-    const float r = sqrtf(-2.0f * __logf(u01(c0)));
+    // r = sqrt(-2 ln u) with u in (2^-33, 1]: v_log_f32 (log2) and v_sqrt_f32 directly -- the argument is never
+    // denormal, so the library sqrtf's rescaling / refinement sequence (~12 instructions) buys nothing here
+    // (c5_wan steady launch 13.2 -> 12.8 us)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c0)));
     const float t = u01(c1);
     z_post = r * __builtin_amdgcn_cosf(t);
     z_pre = r * __builtin_amdgcn_sinf(t);

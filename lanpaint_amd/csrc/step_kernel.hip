@@ -109,8 +109,15 @@ __device__ __forceinline__ float ou_general(float x, float tau, float a, float c
 constexpr uint32_t kPost = LP_PH_POST_FIRST | LP_PH_POST_STEADY;
 constexpr uint32_t kTouchXt = LP_PH_REPLACE | kPost | LP_PH_PRE_HALF;
 
-template <int VEC, bool PER_EL, uint32_t PH>
+// MODE: 0 = per-row coefficient table, any mask (soft values take the per-element branch);
+//       1 = per-element times (AV packs);  2 = per-row table + mask known to be hard 0/1 (bit-packed):
+//       the general branch -- divisions, expm1, the soft-mask blend -- is compiled out of the hot kernel.
+enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
+
+template <int VEC, int MODE, uint32_t PH>
 __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
+    constexpr bool PER_EL = MODE == MODE_PER_EL;
+    constexpr bool HARD = MODE == MODE_HARD;
     const int row = blockIdx.y;
     const uint32_t ph = PH ? PH : d.phases;          // compile-time for the hot combinations
     const uint32_t fl = d.flags;
@@ -224,8 +231,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float mk = m[k];
-                const bool binary = (mk == 0.0f) || (mk == 1.0f);
-                if (!PER_EL && binary && !has_corr) {
+                const bool table = HARD || (!PER_EL && !has_corr && ((mk == 0.0f) || (mk == 1.0f)));
+                if (table) {
                     // table path: two regions per row, no transcendental per element
                     if (rc.valid != 0.0f) {
                         const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                     } else {
                         x0s[k] = x0[k];
                     }
-                } else {
+                } else if constexpr (!HARD) {
                     ElemCoef e;
                     if constexpr (PER_EL) {
                         e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size,
@@ -285,13 +292,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float mk = m[k];
-                const bool binary = (mk == 0.0f) || (mk == 1.0f);
-                if (!PER_EL && binary) {
+                const bool table = HARD || (!PER_EL && ((mk == 0.0f) || (mk == 1.0f)));
+                if (table) {
                     if (rc.valid != 0.0f) {
                         const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
                         xt[k] = q.e_half * xt[k] + q.k_half * cv[k] + q.std_half * xi_b[k];
                     }
-                } else {
+                } else if constexpr (!HARD) {
                     ElemCoef e;
                     if constexpr (PER_EL) {
                         e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size,
@@ -347,40 +354,53 @@ static const Tune& tune() {
     return t;
 }
 
-template <int VEC, bool PER_EL, uint32_t PH>
+template <int VEC, int MODE, uint32_t PH>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     const Tune& t = tune();
     const int64_t groups = d.el_per_row / VEC;
     const int block = t.block ? t.block : 256;
     int64_t bx = (groups + block - 1) / block;
-    // large latents: cap near 8 blocks per CU and grid-stride the rest (c5_wan with non-temporal
-    // accesses: 2048 -> 12.8 us, 1280 -> 13.1 us; profiles/r01_microbench_kernel_variants.log)
-    const int64_t cap_total = t.max_blocks ? t.max_blocks : 2048;
+    // One group per lane, no grid-stride loop, up to far beyond any video latent: capping the grid at 2048
+    // blocks cost 30 % on a 33 M-element batch (220 -> 170 us; profiles/r01_microbench_kernel_variants.log);
+    // the BASELINE shapes all fit in <= 2048 blocks anyway.
+    const int64_t cap_total = t.max_blocks ? t.max_blocks : (int64_t(1) << 20);
     const int64_t cap = (cap_total + d.rows - 1) / d.rows;
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
     if (timer) {
-        hipExtLaunchKernelGGL((lp_step_kernel<VEC, PER_EL, PH>), grid, dim3(block), 0, stream, timer->start,
+        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH>), grid, dim3(block), 0, stream, timer->start,
                               timer->stop, 0, d);
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, PER_EL, PH>), grid, dim3(block), 0, stream, d);
+        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH>), grid, dim3(block), 0, stream, d);
     }
     return hipGetLastError();
 }
 
 template <int VEC>
 static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
-    if (d.flags & LP_FL_PER_ELEMENT) return launch<VEC, true, 0>(d, stream, timer);
+    if (d.flags & LP_FL_PER_ELEMENT) return launch<VEC, MODE_PER_EL, 0>(d, stream, timer);
     constexpr uint32_t R = LP_PH_REPLACE, F = LP_PH_POST_FIRST, S = LP_PH_POST_STEADY, P = LP_PH_PRE_HALF,
                        E = LP_PH_EMIT;
+    // a bit-packed mask is hard by construction; the audio correction needs the general branch
+    const bool hard = (d.flags & LP_FL_MASK_BITS) && d.corr_el == nullptr;
+    if (hard) {
+        switch (d.phases) {
+            case S | P | E: return launch<VEC, MODE_HARD, S | P | E>(d, stream, timer);   // steady state
+            case F | P | E: return launch<VEC, MODE_HARD, F | P | E>(d, stream, timer);   // iteration 0
+            case S | E: return launch<VEC, MODE_HARD, S | E>(d, stream, timer);           // last iteration
+            case F | E: return launch<VEC, MODE_HARD, F | E>(d, stream, timer);           // n_steps == 1
+            case R | E: return launch<VEC, MODE_HARD, R | E>(d, stream, timer);           // replace step
+            default: return launch<VEC, MODE_HARD, 0>(d, stream, timer);                  // unfused (early stop) etc.
+        }
+    }
     switch (d.phases) {
-        case S | P | E: return launch<VEC, false, S | P | E>(d, stream, timer);   // steady state
-        case F | P | E: return launch<VEC, false, F | P | E>(d, stream, timer);   // iteration 0
-        case S | E: return launch<VEC, false, S | E>(d, stream, timer);           // last iteration
-        case F | E: return launch<VEC, false, F | E>(d, stream, timer);           // n_steps == 1
-        case R | E: return launch<VEC, false, R | E>(d, stream, timer);           // replace step
-        default: return launch<VEC, false, 0>(d, stream, timer);                  // unfused (early stop) etc.
+        case S | P | E: return launch<VEC, MODE_ROW, S | P | E>(d, stream, timer);
+        case F | P | E: return launch<VEC, MODE_ROW, F | P | E>(d, stream, timer);
+        case S | E: return launch<VEC, MODE_ROW, S | E>(d, stream, timer);
+        case F | E: return launch<VEC, MODE_ROW, F | E>(d, stream, timer);
+        case R | E: return launch<VEC, MODE_ROW, R | E>(d, stream, timer);
+        default: return launch<VEC, MODE_ROW, 0>(d, stream, timer);
     }
 }
 
