@@ -202,23 +202,25 @@ __global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d)
          g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int64_t i = g * VEC;
         float m[VEC], mo[VEC], yv[VEC], o[VEC];
-        load_mask<VEC>(d.mask, d.flags, i, m);
-        load_any<VEC>(d.model_out, dt, i, mo);
+        Raw<VEC> m_raw, mo_raw, un_raw;                 // issue every load, decode afterwards (lp_common.h)
+        load_mask_raw<VEC>(d.mask, d.flags, i, m_raw);
+        load_raw<VEC>(d.model_out, dt, i, mo_raw);
+        if (d.flags & LP_FL_CFG_FUSED) load_raw<VEC>(d.uncond, dt, i, un_raw);
+        load_f32<VEC>(d.y, i, yv);
+        float xs[VEC];
+        if (d.x_dst) load_f32<VEC>(d.x_src, i, xs);
+        cvt_mask<VEC>(d.flags, i, m_raw, m);
+        cvt_raw<VEC>(dt, mo_raw, mo);
         if (d.flags & LP_FL_CFG_FUSED) {
             float un[VEC];
-            load_any<VEC>(d.uncond, dt, i, un);
+            cvt_raw<VEC>(dt, un_raw, un);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) mo[k] = un[k] + (mo[k] - un[k]) * d.cfg_scale;
         }
-        load_f32<VEC>(d.y, i, yv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o[k] = mo[k] * (1.0f - m[k]) + yv[k] * m[k];
         store_f32<VEC>(d.out, i, o);
-        if (d.x_dst) {
-            float xs[VEC];
-            load_f32<VEC>(d.x_src, i, xs);
-            store_f32<VEC>(d.x_dst, i, xs);
-        }
+        if (d.x_dst) store_f32<VEC>(d.x_dst, i, xs);
     }
     if (d.rng_bump_ptr && blockIdx.x == 0 && threadIdx.x == 0) *d.rng_bump_ptr += d.rng_bump;
 }

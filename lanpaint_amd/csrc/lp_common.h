@@ -100,24 +100,57 @@ __device__ __forceinline__ void store_f32(float* __restrict__ p, int64_t i, cons
     }
 }
 
-// dtype is wave-uniform (a launch flag), so the branch costs one scalar compare.
+// Loads of tensors whose storage type is a launch flag come in two halves: `load_raw*` only ISSUES the load
+// (the untouched bits stay in registers), `cvt_raw*` decodes them later.  Decoding inside the dtype branch
+// would put an s_waitcnt behind every such load -- the bit-packed mask alone cost a full memory round trip
+// ahead of all other loads of the step kernel.
 template <int V>
-__device__ __forceinline__ void load_any(const void* __restrict__ p, int dt, int64_t i, float (&o)[V]) {
+struct Raw {
+    uint32_t w[V];
+};
+
+template <int V>
+__device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, int64_t i, Raw<V>& r) {
     if (dt == DT_F32) {
-        load_f32<V>(static_cast<const float*>(p), i, o);
+        float t[V];
+        load_f32<V>(static_cast<const float*>(p), i, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) r.w[k] = __float_as_uint(t[k]);
     } else {
         const uint16_t* q = static_cast<const uint16_t*>(p) + i;
-        uint16_t h[V];
         if constexpr (V == 4) {
             const uint2 t = *reinterpret_cast<const uint2*>(q);
-            h[0] = t.x & 0xffffu; h[1] = t.x >> 16; h[2] = t.y & 0xffffu; h[3] = t.y >> 16;
+            r.w[0] = t.x; r.w[1] = t.y;
         } else {
 #pragma unroll
-            for (int k = 0; k < V; ++k) h[k] = q[k];
+            for (int k = 0; k < V; ++k) r.w[k] = q[k];
+        }
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V]) {
+    if (dt == DT_F32) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = __uint_as_float(r.w[k]);
+    } else {
+        uint16_t h[V];
+        if constexpr (V == 4) {
+            h[0] = r.w[0] & 0xffffu; h[1] = r.w[0] >> 16; h[2] = r.w[1] & 0xffffu; h[3] = r.w[1] >> 16;
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) h[k] = static_cast<uint16_t>(r.w[k]);
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) o[k] = (dt == DT_BF16) ? bf16_to_f32(h[k]) : f16_to_f32(h[k]);
     }
+}
+
+template <int V>
+__device__ __forceinline__ void load_any(const void* __restrict__ p, int dt, int64_t i, float (&o)[V]) {
+    Raw<V> r;
+    load_raw<V>(p, dt, i, r);
+    cvt_raw<V>(dt, r, o);
 }
 
 template <int V>
@@ -138,35 +171,55 @@ __device__ __forceinline__ void store_any(void* __restrict__ p, int dt, int64_t 
     }
 }
 
-// mask -> latent_mask value m (1 = known).  LP_FL_MASK_DENOISE applies the
+// mask -> latent_mask value m (1 = known), same issue / decode split.  LP_FL_MASK_DENOISE applies the
 // reference's `1 - (denoise_mask > 0.5)` (nodes.py:281-283) on the fly.
 template <int V>
-__device__ __forceinline__ void load_mask(const void* __restrict__ p, uint32_t flags, int64_t i, float (&m)[V]) {
+__device__ __forceinline__ void load_mask_raw(const void* __restrict__ p, uint32_t flags, int64_t i, Raw<V>& r) {
     if (flags & LP_FL_MASK_BITS) {
         // 64 lanes x V elements share 2*V words: the loads broadcast out of one cache line
-        const uint32_t w = static_cast<const uint32_t*>(p)[i >> 5];
+        r.w[0] = static_cast<const uint32_t*>(p)[i >> 5];
+    } else if (flags & LP_FL_MASK_U8) {
+        const uint8_t* q = static_cast<const uint8_t*>(p) + i;
+        if constexpr (V == 4) {
+            r.w[0] = *reinterpret_cast<const uint32_t*>(q);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) r.w[k] = q[k];
+        }
+    } else {
+        float t[V];
+        load_f32<V>(static_cast<const float*>(p), i, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) r.w[k] = __float_as_uint(t[k]);
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void cvt_mask(uint32_t flags, int64_t i, const Raw<V>& r, float (&m)[V]) {
+    if (flags & LP_FL_MASK_BITS) {
         const uint32_t sh = static_cast<uint32_t>(i) & 31u;          // V == 4: i % 4 == 0, the nibble never straddles
 #pragma unroll
-        for (int k = 0; k < V; ++k) m[k] = static_cast<float>((w >> (sh + k)) & 1u);
+        for (int k = 0; k < V; ++k) m[k] = static_cast<float>((r.w[0] >> (sh + k)) & 1u);
         return;
     }
     if (flags & LP_FL_MASK_U8) {
-        const uint8_t* q = static_cast<const uint8_t*>(p) + i;
-        if constexpr (V == 4) {
-            const uint32_t t = *reinterpret_cast<const uint32_t*>(q);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) m[k] = static_cast<float>((t >> (8 * k)) & 0xffu);
-        } else {
-#pragma unroll
-            for (int k = 0; k < V; ++k) m[k] = static_cast<float>(q[k]);
-        }
+        for (int k = 0; k < V; ++k) m[k] = static_cast<float>(V == 4 ? ((r.w[0] >> (8 * k)) & 0xffu) : r.w[k]);
     } else {
-        load_f32<V>(static_cast<const float*>(p), i, m);
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = __uint_as_float(r.w[k]);
     }
     if (flags & LP_FL_MASK_DENOISE) {
 #pragma unroll
         for (int k = 0; k < V; ++k) m[k] = 1.0f - ((m[k] > 0.5f) ? 1.0f : 0.0f);
     }
+}
+
+template <int V>
+__device__ __forceinline__ void load_mask(const void* __restrict__ p, uint32_t flags, int64_t i, float (&m)[V]) {
+    Raw<V> r;
+    load_mask_raw<V>(p, flags, i, r);
+    cvt_mask<V>(flags, i, r, m);
 }
 
 __host__ __device__ inline int x0_dtype(uint32_t flags) {

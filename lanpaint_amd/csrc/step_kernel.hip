@@ -133,19 +133,23 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     RowCoef rc;
     if constexpr (!PER_EL) rc = load_row(d.coef, row);
 
-    uint64_t seq = d.rng_offset;
-    if (d.rng_offset_ptr) seq += *d.rng_offset_ptr;
     const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
     const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
 
-    for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < groups;
-         g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    // one group per lane and no grid-stride loop: the launch covers the row (see launch()), which keeps every
+    // address in this straight-line body a kernarg pointer + one offset and lets the scalar loads (coefficient
+    // row, replayed-graph RNG counter) fly together with the vector loads instead of ahead of a loop
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    {
         const int64_t i = row_base + g * VEC;
 
         // ---- issue every load of this launch before any arithmetic ---------------------
         float m[VEC], xt[VEC], yv[VEC], cv[VEC], x0[VEC], x0b[VEC], xi_a[VEC], xi_b[VEC], corr[VEC];
         float xv[VEC], kn[VEC], nv[VEC], rs[VEC], abt_e[VEC], ve_e[VEC];
-        load_mask<VEC>(d.mask, fl, i, m);
+        Raw<VEC> m_raw, x0_raw, x0b_raw;
+        const uint32_t mfl = HARD ? static_cast<uint32_t>(LP_FL_MASK_BITS) : fl;      // HARD: bit-packed by dispatch
+        load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
         if constexpr (PER_EL) {
             load_f32<VEC>(d.abt_el, i, abt_e);
             if (!flow) load_f32<VEC>(d.ve_el, i, ve_e);
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         }
         if ((ph & LP_PH_POST_STEADY) || ((ph & LP_PH_PRE_HALF) && !post)) load_f32<VEC>(d.C, i, cv);
         if (post) {
-            load_any<VEC>(d.x0, x0dt, i, x0);
-            if (!(d.x0_big == d.x0 || given)) load_any<VEC>(d.x0_big, x0dt, i, x0b);
+            load_raw<VEC>(d.x0, x0dt, i, x0_raw);
+            if (!(d.x0_big == d.x0 || given)) load_raw<VEC>(d.x0_big, x0dt, i, x0b_raw);
             if (!given) load_f32<VEC>(d.y, i, yv);
             if (host_post) load_f32<VEC>(d.xi_post, i, xi_a);
             if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
@@ -174,6 +178,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 
         // ---- Philox + Box-Muller while the loads are in flight ----------------------------
         if (need_rng) {
+            uint64_t seq = d.rng_offset;
+            if (d.rng_offset_ptr) seq += *d.rng_offset_ptr;      // device-side counter of a replayed graph
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 float za, zb;
@@ -181,6 +187,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                 if (!host_post) xi_a[k] = za;
                 if (!host_pre) xi_b[k] = zb;
             }
+        }
+
+        // ---- decode what was loaded in a storage format --------------------------------------------
+        cvt_mask<VEC>(mfl, i, m_raw, m);
+        if (post) {
+            cvt_raw<VEC>(x0dt, x0_raw, x0);
+            if (!(d.x0_big == d.x0 || given)) cvt_raw<VEC>(x0dt, x0b_raw, x0b);
         }
 
         // ---- REPLACE: x = x(1-m) + known*m ; x_t = VP(x) -----------------------------------
@@ -338,13 +351,12 @@ struct Timer {
 };
 
 struct Tune {
-    int vec = 0, block = 0, max_blocks = 0;   // 0 = automatic
+    int vec = 0, block = 0;   // 0 = automatic
     int64_t small_elems = 0;
     Tune() {
         // developer knobs for the micro-benchmarks (scripts/microbench_step.py); not an API
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_VEC")) vec = std::atoi(e);
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_BLOCK")) block = std::atoi(e);
-        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_MAXBLOCKS")) max_blocks = std::atoi(e);
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_SMALL")) small_elems = std::atoll(e);
     }
 };
@@ -360,13 +372,11 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     const int64_t groups = d.el_per_row / VEC;
     const int block = t.block ? t.block : 256;
     int64_t bx = (groups + block - 1) / block;
-    // One group per lane, no grid-stride loop, up to far beyond any video latent: capping the grid at 2048
-    // blocks cost 30 % on a 33 M-element batch (220 -> 170 us; profiles/r01_microbench_kernel_variants.log);
-    // the BASELINE shapes all fit in <= 2048 blocks anyway.
-    const int64_t cap_total = t.max_blocks ? t.max_blocks : (int64_t(1) << 20);
-    const int64_t cap = (cap_total + d.rows - 1) / d.rows;
-    if (bx > cap) bx = cap;
+    // One group per lane, no grid-stride loop: capping the grid at 2048 blocks cost 30 % on a 33 M-element
+    // batch (220 -> 170 us; profiles/r01_microbench_kernel_variants.log); the BASELINE shapes all fit in
+    // <= 2048 blocks anyway.
     if (bx < 1) bx = 1;
+    if (bx > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
     if (timer) {
         hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH>), grid, dim3(block), 0, stream, timer->start,
