@@ -146,6 +146,14 @@ __device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V]) 
     }
 }
 
+// Same with the storage width fixed at compile time (W = 4: fp32, W = 2: bf16 / fp16, W = 0: run-time `dt`).
+template <int V, int W>
+__device__ __forceinline__ void load_raw_w(const void* __restrict__ p, int dt, int64_t i, Raw<V>& r) {
+    if constexpr (W == 4) load_raw<V>(p, DT_F32, i, r);
+    else if constexpr (W == 2) load_raw<V>(p, DT_BF16, i, r);        // bf16 and fp16 load alike; cvt_raw tells them apart
+    else load_raw<V>(p, dt, i, r);
+}
+
 template <int V>
 __device__ __forceinline__ void load_any(const void* __restrict__ p, int dt, int64_t i, float (&o)[V]) {
     Raw<V> r;

@@ -22,6 +22,12 @@
 
 #include "lp_common.h"
 
+// No implicit a*b+c contraction: the table path spells its fused multiply-adds out (fmaf), the general path
+// rounds every product and sum on its own as the reference's eager PyTorch ops do.  The many instantiations
+// of lp_step_kernel then compute bit-identical results whichever one a launch is routed to (fp32 / uint8 /
+// bit-packed mask, fused or unfused schedule) instead of depending on what the optimiser fused where.
+#pragma clang fp contract(off)
+
 namespace lp {
 
 struct RegionCoef {
@@ -114,7 +120,12 @@ constexpr uint32_t kTouchXt = LP_PH_REPLACE | kPost | LP_PH_PRE_HALF;
 //       the general branch -- divisions, expm1, the soft-mask blend -- is compiled out of the hot kernel.
 enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 
-template <int VEC, int MODE, uint32_t PH>
+// X0W: storage width of x0 / x0_big known at compile time (4 = fp32, 2 = bf16/fp16) or 0 = read the flag at
+// run time.  With a run-time dtype branch around the loads the two sides share registers and the compiler
+// has to put an s_waitcnt vmcnt(0) at their join -- ahead of the remaining loads -- so the hot phase
+// combinations are instantiated per width; likewise they only take fp32 (MODE_ROW) or bit-packed (MODE_HARD)
+// masks, a uint8 mask goes through the PH = 0 kernel.
+template <int VEC, int MODE, uint32_t PH, int X0W>
 __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     constexpr bool PER_EL = MODE == MODE_PER_EL;
     constexpr bool HARD = MODE == MODE_HARD;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     const bool post = ph & kPost;
     const bool given = fl & LP_FL_X0S_GIVEN;
     const bool has_corr = d.corr_el != nullptr && !given;
-    const int x0dt = x0_dtype(fl), xindt = xin_dtype(fl);
+    const int x0dt = X0W == 4 ? static_cast<int>(DT_F32) : x0_dtype(fl), xindt = xin_dtype(fl);
     const int64_t groups = d.el_per_row / VEC;
     const int64_t row_base = static_cast<int64_t>(row) * d.el_per_row;
     const float lam = d.lambda, opl = d.one_plus_lambda;
@@ -148,7 +159,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         float m[VEC], xt[VEC], yv[VEC], cv[VEC], x0[VEC], x0b[VEC], xi_a[VEC], xi_b[VEC], corr[VEC];
         float xv[VEC], kn[VEC], nv[VEC], rs[VEC], abt_e[VEC], ve_e[VEC];
         Raw<VEC> m_raw, x0_raw, x0b_raw;
-        const uint32_t mfl = HARD ? static_cast<uint32_t>(LP_FL_MASK_BITS) : fl;      // HARD: bit-packed by dispatch
+        // HARD: bit-packed by dispatch; hot MODE_ROW variants: fp32 (uint8 masks are routed to PH = 0)
+        const uint32_t mfl = HARD ? static_cast<uint32_t>(LP_FL_MASK_BITS) : (PH != 0 ? (fl & ~LP_FL_MASK_U8) : fl);
         load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
         if constexpr (PER_EL) {
             load_f32<VEC>(d.abt_el, i, abt_e);
@@ -168,8 +180,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         }
         if ((ph & LP_PH_POST_STEADY) || ((ph & LP_PH_PRE_HALF) && !post)) load_f32<VEC>(d.C, i, cv);
         if (post) {
-            load_raw<VEC>(d.x0, x0dt, i, x0_raw);
-            if (!(d.x0_big == d.x0 || given)) load_raw<VEC>(d.x0_big, x0dt, i, x0b_raw);
+            load_raw_w<VEC, X0W>(d.x0, x0dt, i, x0_raw);
+            if (!(d.x0_big == d.x0 || given)) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i, x0b_raw);
             if (!given) load_f32<VEC>(d.y, i, yv);
             if (host_post) load_f32<VEC>(d.xi_post, i, xi_a);
             if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
@@ -202,13 +214,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     const float r = PER_EL ? rs[k] : rc.rsigma;
-                    kn[k] = (d.replace_kind == LP_REPLACE_VE) ? (yv[k] + nv[k] * r)
+                    kn[k] = (d.replace_kind == LP_REPLACE_VE) ? fmaf(nv[k], r, yv[k])
                                                               : (r * (d.noise_scale * nv[k]) + (1.0f - r) * yv[k]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float xr = xv[k] * (1.0f - m[k]) + kn[k] * m[k];
+                const float xr = fmaf(kn[k], m[k], xv[k] * (1.0f - m[k]));
                 float sc;
                 if constexpr (PER_EL) {
                     sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
@@ -229,8 +241,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     const float c = x0[k], u = x0b[k], diff = c - u;
-                    x0[k] = u + diff * d.cfg_scale;
-                    x0b[k] = u + diff * d.cfg_scale_big;
+                    x0[k] = fmaf(diff, d.cfg_scale, u);
+                    x0b[k] = fmaf(diff, d.cfg_scale_big, u);
                 }
             }
             if (given) {
@@ -250,13 +262,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                     if (rc.valid != 0.0f) {
                         const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
                         const float s0 = (given || mk != 1.0f) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
-                        const float cn = q.cx0 * s0 + q.cxt * xt[k];
+                        const float cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
                         x0s[k] = s0;
                         if (ph & LP_PH_POST_FIRST) {
-                            xt[k] = q.e_full * xt[k] + q.k_full * cn + q.std_full * xi_a[k];
+                            xt[k] = fmaf(q.e_full, xt[k], fmaf(q.k_full, cn, q.std_full * xi_a[k]));
                         } else {
-                            const float xd = xt[k] + (cn - cv[k]) * q.dt;
-                            xt[k] = q.e_half * xd + q.k_half * cv[k] + q.std_half * xi_a[k];
+                            const float xd = fmaf(cn - cv[k], q.dt, xt[k]);
+                            xt[k] = fmaf(q.e_half, xd, fmaf(q.k_half, cv[k], q.std_half * xi_a[k]));
                         }
                         cv[k] = cn;
                     } else {
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                 if (table) {
                     if (rc.valid != 0.0f) {
                         const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
-                        xt[k] = q.e_half * xt[k] + q.k_half * cv[k] + q.std_half * xi_b[k];
+                        xt[k] = fmaf(q.e_half, xt[k], fmaf(q.k_half, cv[k], q.std_half * xi_b[k]));
                     }
                 } else if constexpr (!HARD) {
                     ElemCoef e;
@@ -366,7 +378,7 @@ static const Tune& tune() {
     return t;
 }
 
-template <int VEC, int MODE, uint32_t PH>
+template <int VEC, int MODE, uint32_t PH, int X0W = 0>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     const Tune& t = tune();
     const int64_t groups = d.el_per_row / VEC;
@@ -379,10 +391,10 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     if (bx > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
     if (timer) {
-        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH>), grid, dim3(block), 0, stream, timer->start,
+        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W>), grid, dim3(block), 0, stream, timer->start,
                               timer->stop, 0, d);
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH>), grid, dim3(block), 0, stream, d);
+        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W>), grid, dim3(block), 0, stream, d);
     }
     return hipGetLastError();
 }
@@ -394,24 +406,28 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
                        E = LP_PH_EMIT;
     // a bit-packed mask is hard by construction; the audio correction needs the general branch
     const bool hard = (d.flags & LP_FL_MASK_BITS) && d.corr_el == nullptr;
+    const bool x0_half = x0_dtype(d.flags) != DT_F32;
+    if (d.flags & LP_FL_MASK_U8) return launch<VEC, MODE_ROW, 0>(d, stream, timer);   // legacy format: run-time everything
+    if (d.phases == (R | E))                                                         // replace step: no x0 at all
+        return hard ? launch<VEC, MODE_HARD, R | E>(d, stream, timer) : launch<VEC, MODE_ROW, R | E>(d, stream, timer);
+#define LP_HOT(MODE_, PH_) (x0_half ? launch<VEC, MODE_, PH_, 2>(d, stream, timer) : launch<VEC, MODE_, PH_, 4>(d, stream, timer))
     if (hard) {
         switch (d.phases) {
-            case S | P | E: return launch<VEC, MODE_HARD, S | P | E>(d, stream, timer);   // steady state
-            case F | P | E: return launch<VEC, MODE_HARD, F | P | E>(d, stream, timer);   // iteration 0
-            case S | E: return launch<VEC, MODE_HARD, S | E>(d, stream, timer);           // last iteration
-            case F | E: return launch<VEC, MODE_HARD, F | E>(d, stream, timer);           // n_steps == 1
-            case R | E: return launch<VEC, MODE_HARD, R | E>(d, stream, timer);           // replace step
-            default: return launch<VEC, MODE_HARD, 0>(d, stream, timer);                  // unfused (early stop) etc.
+            case S | P | E: return LP_HOT(MODE_HARD, S | P | E);   // steady state
+            case F | P | E: return LP_HOT(MODE_HARD, F | P | E);   // iteration 0
+            case S | E: return LP_HOT(MODE_HARD, S | E);           // last iteration
+            case F | E: return LP_HOT(MODE_HARD, F | E);           // n_steps == 1
+            default: return launch<VEC, MODE_HARD, 0>(d, stream, timer);   // unfused (early stop) etc.
         }
     }
     switch (d.phases) {
-        case S | P | E: return launch<VEC, MODE_ROW, S | P | E>(d, stream, timer);
-        case F | P | E: return launch<VEC, MODE_ROW, F | P | E>(d, stream, timer);
-        case S | E: return launch<VEC, MODE_ROW, S | E>(d, stream, timer);
-        case F | E: return launch<VEC, MODE_ROW, F | E>(d, stream, timer);
-        case R | E: return launch<VEC, MODE_ROW, R | E>(d, stream, timer);
+        case S | P | E: return LP_HOT(MODE_ROW, S | P | E);
+        case F | P | E: return LP_HOT(MODE_ROW, F | P | E);
+        case S | E: return LP_HOT(MODE_ROW, S | E);
+        case F | E: return LP_HOT(MODE_ROW, F | E);
         default: return launch<VEC, MODE_ROW, 0>(d, stream, timer);
     }
+#undef LP_HOT
 }
 
 static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
