@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 4
+#define LP_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -187,6 +187,26 @@ const char* lp_strerror(int code);
 int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const float* abt, int abt_stride,
               const float* replace_sigma, int rs_stride, const float* step_override, int step_stride,
               const float* t_model, int t_stride, int rows, float* coef_table, void* stream);
+
+/* One sigma call's whole enqueue sequence in ONE host call, for callers that replay the think loop as a
+ * hipGraph (the loop between the replace step and the finalise, captured by the caller):
+ *     lp_coeffs(...) ; lp_step(replace) ; hipGraphLaunch(graph_exec, stream) ; lp_finalize(final).
+ * Host-side launch cost matters at SDXL-latent sizes (the whole call is ~40 us of GPU time): four trips through
+ * an FFI cost more than the kernels they start.  `graph_exec` is a hipGraphExec_t (NULL: skip the graph launch).
+ * Stops at the first failing step and returns its code.                                              */
+typedef struct lp_call_desc {
+    const lp_hyper*      hyper;
+    const float*         ve_sigma;      int32_t ve_stride;
+    const float*         abt;           int32_t abt_stride;
+    const float*         replace_sigma; int32_t rs_stride;
+    const float*         t_model;       int32_t t_stride;
+    int32_t              rows;
+    float*               coef_table;
+    const lp_step_desc*  replace;       /* LP_PH_REPLACE | LP_PH_EMIT launch                    */
+    void*                graph_exec;    /* hipGraphExec_t of the captured think loop, or NULL   */
+    const lp_final_desc* final;         /* lp_finalize descriptor                               */
+} lp_call_desc;
+int lp_replay_call(const lp_call_desc* call, void* stream);
 
 /* K1a  sigma -> (VE_sigma, abt, flow_t) per batch row plus the two scalars the inner-step rule needs,
  * in ONE launch.  Replaces the ~15 eager scalar ops + 2 host syncs of KSamplerX0Inpaint.__call__

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -63,6 +63,21 @@ class LpFinalDesc(C.Structure):
     ]
 
 
+class LpCallDesc(C.Structure):
+    _fields_ = [
+        ("hyper", C.POINTER(LpHyper)),
+        ("ve_sigma", C.c_void_p), ("ve_stride", C.c_int32),
+        ("abt", C.c_void_p), ("abt_stride", C.c_int32),
+        ("replace_sigma", C.c_void_p), ("rs_stride", C.c_int32),
+        ("t_model", C.c_void_p), ("t_stride", C.c_int32),
+        ("rows", C.c_int32),
+        ("coef_table", C.c_void_p),
+        ("replace", C.POINTER(LpStepDesc)),
+        ("graph_exec", C.c_void_p),
+        ("final", C.POINTER(LpFinalDesc)),
+    ]
+
+
 LP_COPY_MAX = 6
 
 
@@ -98,6 +113,7 @@ EXPORTS = {
     "lp_boundary_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "lp_wmse_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_void_p]),
+    "lp_replay_call": (C.c_int, [C.POINTER(LpCallDesc), C.c_void_p]),
     "lp_pack_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_reshape_mask": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]),
 }

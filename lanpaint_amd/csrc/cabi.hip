@@ -83,6 +83,18 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
     return lp::wmse_dispatch(a, b, mask, ring, n_el, acc, block_scratch, scratch_blocks, as_stream(stream));
 }
 
+int lp_replay_call(const lp_call_desc* c, void* stream) {
+    if (!c || !c->hyper || !c->replace || !c->final) return LP_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    int rc = lp::coeffs_dispatch(c->hyper, c->ve_sigma, c->ve_stride, c->abt, c->abt_stride, c->replace_sigma,
+                                 c->rs_stride, nullptr, 0, c->t_model, c->t_stride, c->rows, c->coef_table, s);
+    if (rc != LP_OK) return rc;
+    rc = lp::step_dispatch(c->replace, s, nullptr);
+    if (rc != LP_OK) return rc;
+    if (c->graph_exec && hipGraphLaunch(static_cast<hipGraphExec_t>(c->graph_exec), s) != hipSuccess) return LP_E_LAUNCH;
+    return lp::finalize_dispatch(c->final, s);
+}
+
 int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream) {
     return lp::pack_mask_dispatch(mask, n_el, flags, bits, nonbinary, as_stream(stream));
 }

@@ -135,6 +135,9 @@ class _CapturedCall:
         self.keep = None
         self.fast = False        # steady-state replay may reuse the snapshotted descriptors
         self.rows, self.flow, self.hyper, self.k0_desc, self.f_desc = 0, False, None, None, None
+        self.call = None         # lp_call_desc: the whole enqueue sequence of a replay in one C call
+        self.raw_exec = None     # hipGraphExec_t, when launching it without torch's replay() is equivalent
+        self.ident = None        # what the caller passed last time (identity pre-check of the next call)
 
 
 class LanPaint:
@@ -184,6 +187,7 @@ class LanPaint:
             raise ValueError(f"model_dtype must be None, float32, bfloat16 or float16, got {model_dtype}")
         self.model_dtype = None if model_dtype == torch.float32 else model_dtype
         self._graphs = OrderedDict()             # key -> _CapturedCall, LRU-bounded (MAX_GRAPHS)
+        self._last_cap = None                    # the capture the previous call replayed (identity pre-check)
         self._rng_counters = {}                  # device -> u64 counter read by captured Philox launches
         self._capturing = None                   # device u64 Philox counter while capturing
         self._cap_offset = 0
@@ -355,6 +359,11 @@ class LanPaint:
             self.noise = self.rng(noise) if callable(self.rng) else torch.randn_like(noise)
         if n_steps is None:
             n_steps = self.n_steps
+        cap = self._last_cap
+        if cap is not None and self._same_call(cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed):
+            self.iterations_run += cap.ran           # same tensors / shapes / options as the previous call:
+            self.last_inner_steps = cap.ran          # skip the key construction, go straight to the replay
+            return self._replay_fast(cap, x, sigma, current_times)
         run = self._call_graphed if self._graph_eligible(x, model_options, sigma, current_times) else self.LanPaint
         if x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):
@@ -363,6 +372,31 @@ class LanPaint:
         return run(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX, self.IS_FLOW)
 
     # ------------------------------------------------------------------ hipGraph replay of one sigma call
+    def _same_call(self, cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed):
+        """Identity pre-check of the steady state (a sampler calls the engine once per sigma with the same
+        latent_image / mask / options objects): everything `_graph_eligible` and the graph key look at, without
+        building the key.  Any miss falls through to the full path."""
+        i = cap.ident
+        y, nz = self.latent_image, self.noise
+        ve, abt, ft = current_times
+        f32 = torch.float32
+        return (i[0] is y and i[1] is latent_mask and i[2] is model_options and i[3] == x.shape and i[4] == n_steps
+                and i[5] == seed and i[6] is self.rng and self.graph and not self._noise_regenerated
+                and i[7] == y.data_ptr() and i[8] == latent_mask.data_ptr()
+                and i[9] is getattr(latent_mask, "_lp_bits", None) and i[10] is getattr(latent_mask, "_lp_u8", None)
+                and i[11] == x.device and i[12] == sigma.numel() and i[13] == ve.numel() and i[14] == abt.numel()
+                and i[15] == ft.numel() and self.audio_indicator is None and self.audio_correction is None
+                and not (self.early_stop_threshold > 0.0 and self.early_stop_patience > 0)
+                and x.dtype == f32 and sigma.dtype == f32 and ve.dtype == f32 and abt.dtype == f32 and ft.dtype == f32
+                and nz.dtype == f32 and nz.shape == x.shape and x.is_contiguous() and sigma.is_contiguous()
+                and ve.is_contiguous() and abt.is_contiguous() and ft.is_contiguous() and nz.is_contiguous()
+                and x.device.index == torch.cuda.current_device() and i[16] == self._override_state()
+                and not (isinstance(model_options, dict) and "lanpaint_semantic_stop" in model_options))
+
+    def _override_state(self):
+        return (self._overridden("langevin_dynamics"), self._overridden("score_model"),
+                self._overridden("prepare_step_size"), self.IS_FLUX, self.IS_FLOW, self.model_dtype)
+
     def _graph_eligible(self, x, model_options, sigma, current_times):
         if not self.graph or callable(self.rng) or self._noise_regenerated:
             return False         # (regenerated noise is a fresh tensor per call: nothing stable to bake into a graph)
@@ -401,28 +435,43 @@ class LanPaint:
         self.last_inner_steps = cap.ran
         srcs = (x, sigma, current_times[0], current_times[1], current_times[2], self.noise)
         if cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape:
+            if not isinstance(model_options, dict) or "lanpaint_semantic_stop" not in model_options:
+                cap.ident = (self.latent_image, latent_mask, model_options, x.shape, n_steps, seed, self.rng,
+                             self.latent_image.data_ptr(), latent_mask.data_ptr(), getattr(latent_mask, "_lp_bits", None),
+                             getattr(latent_mask, "_lp_u8", None), x.device, sigma.numel(), current_times[0].numel(),
+                             current_times[1].numel(), current_times[2].numel(), self._override_state())
+                self._last_cap = cap
             return self._replay_fast(cap, x, sigma, current_times)
+        self._last_cap = None
         st = self._prologue(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=cap.ws)
         cap.graph.replay()
         return self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None)
 
     def _replay_fast(self, cap, x, sigma, current_times):
-        """Steady-state replay: the three eager launches around the graph (lp_coeffs, replace, lp_finalize) reuse
-        the descriptors snapshotted at capture; only the caller's pointers (x, noise, sigma, times, out) change."""
+        """Steady-state replay: the launches around the graph (lp_coeffs, replace, lp_finalize) reuse the
+        descriptors snapshotted at capture; only the caller's pointers (x, noise, sigma, times, out) change.
+        With the raw hipGraphExec_t the whole sequence is ONE trip through the FFI (lp_replay_call)."""
         lib, stream = self._lib, self._stream(x.device)
-        rows = cap.rows
-        t_src = current_times[2] if cap.flow else current_times[0]
-        _cabi.check(lib.lp_coeffs(ctypes.byref(cap.hyper), current_times[0].data_ptr(), int(current_times[0].numel() > 1),
-                                  current_times[1].data_ptr(), int(current_times[1].numel() > 1), sigma.data_ptr(),
-                                  int(sigma.numel() > 1), None, 0, t_src.data_ptr(), int(t_src.numel() > 1), rows,
-                                  cap.ws.coef.data_ptr(), stream), "lp_coeffs")
-        k0 = cap.k0_desc
+        ve, abt = current_times[0], current_times[1]
+        t_src = current_times[2] if cap.flow else ve
+        out = torch.empty_like(x)
+        k0, f = cap.k0_desc, cap.f_desc
         k0.x, k0.noise = x.data_ptr(), self.noise.data_ptr()
+        f.x_dst, f.out = k0.x, out.data_ptr()
+        if cap.raw_exec is not None:
+            c = cap.call
+            c.ve_sigma, c.ve_stride = ve.data_ptr(), ve.numel() > 1
+            c.abt, c.abt_stride = abt.data_ptr(), abt.numel() > 1
+            c.replace_sigma, c.rs_stride = sigma.data_ptr(), sigma.numel() > 1
+            c.t_model, c.t_stride = t_src.data_ptr(), t_src.numel() > 1
+            _cabi.check(lib.lp_replay_call(ctypes.byref(c), stream), "lp_replay_call")
+            return out
+        _cabi.check(lib.lp_coeffs(ctypes.byref(cap.hyper), ve.data_ptr(), int(ve.numel() > 1), abt.data_ptr(),
+                                  int(abt.numel() > 1), sigma.data_ptr(), int(sigma.numel() > 1), None, 0,
+                                  t_src.data_ptr(), int(t_src.numel() > 1), cap.rows, cap.ws.coef.data_ptr(), stream),
+                    "lp_coeffs")
         _cabi.check(lib.lp_step(ctypes.byref(k0), stream), "lp_step")
         cap.graph.replay()
-        out = torch.empty_like(x)
-        f = cap.f_desc
-        f.x_dst, f.out = x.data_ptr(), out.data_ptr()
         _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
         return out
 
@@ -446,6 +495,9 @@ class LanPaint:
                                 ws=cap.ws)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        # did the warm-up (backbone included) draw from torch's generator?  Then only torch's own replay() keeps
+        # the captured Philox offsets moving and the graph must not be launched behind its back.
+        torch_rng_used = not torch.equal(torch.cuda.get_rng_state(dev), rng_state)
         self.iterations_run = it0
         self._capturing, self._cap_offset = counter, 0
         try:
@@ -470,6 +522,15 @@ class LanPaint:
             f.rng_bump_ptr, f.rng_bump = counter.data_ptr(), cap.launches
         cap.f_desc = f
         cap.fast = bool(dense_ok and st.k0_desc is not None and st.replace_kind_static and st.xc is st.input_x)
+        if cap.fast:
+            if self.rng == "philox" and not torch_rng_used and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0":
+                try:
+                    cap.raw_exec = int(cap.graph.raw_cuda_graph_exec()) or None
+                except Exception:
+                    cap.raw_exec = None
+            c = cap.call = _cabi.LpCallDesc()
+            c.hyper, c.replace, c.final = ctypes.pointer(cap.hyper), ctypes.pointer(cap.k0_desc), ctypes.pointer(f)
+            c.rows, c.coef_table, c.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.raw_exec
         self._graphs[key] = cap
         return cap
 

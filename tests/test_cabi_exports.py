@@ -59,6 +59,7 @@ def test_struct_layout_matches_c(tmp_path):
     import subprocess
     fields_step = [f for f, _ in _cabi.LpStepDesc._fields_]
     fields_final = [f for f, _ in _cabi.LpFinalDesc._fields_]
+    fields_call = [f for f, _ in _cabi.LpCallDesc._fields_]
     cname = lambda f: "lambda" if f == "lambda_" else f      # noqa: E731
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "lanpaint_hip.h"', 'int main(void){',
             'printf("%zu %zu %zu\\n", sizeof(lp_step_desc), sizeof(lp_final_desc), sizeof(lp_hyper));']
@@ -67,7 +68,10 @@ def test_struct_layout_matches_c(tmp_path):
     prog.append('printf("\\n");')
     for f in fields_final:
         prog.append(f'printf("%zu ", offsetof(lp_final_desc, {cname(f)}));')
-    prog.append('printf("\\n"); return 0;}')
+    prog.append('printf("\\n");')
+    for f in fields_call:
+        prog.append(f'printf("%zu ", offsetof(lp_call_desc, {f}));')
+    prog.append('printf("%zu\\n", sizeof(lp_call_desc)); return 0;}')
     src = tmp_path / "layout.c"
     src.write_text("\n".join(prog))
     exe = tmp_path / "layout"
@@ -77,6 +81,8 @@ def test_struct_layout_matches_c(tmp_path):
     assert sizes == [ctypes.sizeof(_cabi.LpStepDesc), ctypes.sizeof(_cabi.LpFinalDesc), ctypes.sizeof(_cabi.LpHyper)]
     assert [int(v) for v in lines[1].split()] == [getattr(_cabi.LpStepDesc, f).offset for f in fields_step]
     assert [int(v) for v in lines[2].split()] == [getattr(_cabi.LpFinalDesc, f).offset for f in fields_final]
+    assert [int(v) for v in lines[3].split()] == [getattr(_cabi.LpCallDesc, f).offset for f in fields_call] + \
+        [ctypes.sizeof(_cabi.LpCallDesc)]
 
 
 def test_engine_refuses_cpu_tensors(hip_lib):
