@@ -11,65 +11,62 @@
 namespace lp {
 
 // ---------------------------------------------------------------------------------
-// K1: one thread per batch row.  fp32 fields mirror the reference's own op order
-// (prepare_step_size, lanpaint.py:295-328); the per-region closed-form factors are
-// evaluated in double from those fp32 inputs (lanpaint.py:241-252 in exact arithmetic).
+// K1: FOUR lanes per batch row, one per (region, tau in {dt, dt/2}): the closed-form factors are 12
+// dependent double-precision exp / expm1 evaluations per row, and the table sits on the critical path of
+// every sigma call, so the chain is cut to 3 per lane.  fp32 fields mirror the reference's own op order
+// (prepare_step_size, lanpaint.py:295-328); the per-region factors are evaluated in double from those
+// fp32 inputs (lanpaint.py:241-252 in exact arithmetic).
 // ---------------------------------------------------------------------------------
 __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int ve_stride,
                                  const float* __restrict__ abt, int abt_stride, const float* __restrict__ rs,
                                  int rs_stride, const float* __restrict__ step_ov, int step_stride,
                                  const float* __restrict__ t_model, int t_stride, int rows, float* __restrict__ table) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = t >> 2, g = (t >> 1) & 1, s = t & 1;
     if (r >= rows) return;
     const float abt_f = abt[static_cast<int64_t>(r) * abt_stride];
-    const float ve_f = ve ? ve[static_cast<int64_t>(r) * ve_stride] : 0.0f;
-    const float rs_f = rs ? rs[static_cast<int64_t>(r) * rs_stride] : 0.0f;
     float* c = table + static_cast<int64_t>(r) * LP_COEF_STRIDE;
 
     const float oma = 1.0f - abt_f;
     const float step = step_ov ? step_ov[static_cast<int64_t>(r) * step_stride]
                                : h.step_size * fmaxf(oma, h.min_step_frac);  // lanpaint.py:81
     const float dtx2 = 2.0f * step * 1.0f, dty2 = 2.0f * step * h.beta;        // :300-301
-    const float atx = (1.0f / oma) * dtx2 / 2.0f;                              // :315
-    const float aty = (h.one_plus_lambda / oma) * dty2 / 2.0f;                 // :316
     const float dtx = dtx2 / 2.0f, dty = dty2 / 2.0f;                          // :328
-    const bool valid = step > 0.0f;                                            // :205 (per row)
-    c[LP_C_SCALE] = h.is_flow ? (sqrtf(abt_f) + sqrtf(1.0f - abt_f)) : sqrtf(1.0f + ve_f * ve_f);   // :96-99
-    c[LP_C_SQRT_ABT] = sqrtf(abt_f);
-    c[LP_C_OMA] = oma;
-    c[LP_C_ABT] = abt_f;
-    c[LP_C_RSIGMA] = rs_f;
-    c[LP_C_DTX] = dtx;
-    c[LP_C_DTY] = dty;
-    c[LP_C_AX] = atx / dtx;                                                    // :319
-    c[LP_C_AY] = aty / dty;                                                    // :320
-    c[LP_C_DX] = sqrtf(2.0f);                                                  // :326-327
-    c[LP_C_DY] = sqrtf(2.0f);
-    c[LP_C_VALID] = valid ? 1.0f : 0.0f;
-    c[LP_C_TMODEL] = t_model ? t_model[static_cast<int64_t>(r) * t_stride] : 0.0f;
+    if (g == 0 && s == 0) {                  // the row header
+        const float ve_f = ve ? ve[static_cast<int64_t>(r) * ve_stride] : 0.0f;
+        const float rs_f = rs ? rs[static_cast<int64_t>(r) * rs_stride] : 0.0f;
+        const float atx = (1.0f / oma) * dtx2 / 2.0f;                              // :315
+        const float aty = (h.one_plus_lambda / oma) * dty2 / 2.0f;                 // :316
+        const bool valid = step > 0.0f;                                            // :205 (per row)
+        c[LP_C_SCALE] = h.is_flow ? (sqrtf(abt_f) + sqrtf(1.0f - abt_f)) : sqrtf(1.0f + ve_f * ve_f);   // :96-99
+        c[LP_C_SQRT_ABT] = sqrtf(abt_f);
+        c[LP_C_OMA] = oma;
+        c[LP_C_ABT] = abt_f;
+        c[LP_C_RSIGMA] = rs_f;
+        c[LP_C_DTX] = dtx;
+        c[LP_C_DTY] = dty;
+        c[LP_C_AX] = atx / dtx;                                                    // :319
+        c[LP_C_AY] = aty / dty;                                                    // :320
+        c[LP_C_DX] = sqrtf(2.0f);                                                  // :326-327
+        c[LP_C_DY] = sqrtf(2.0f);
+        c[LP_C_VALID] = valid ? 1.0f : 0.0f;
+        c[LP_C_TMODEL] = t_model ? t_model[static_cast<int64_t>(r) * t_stride] : 0.0f;
+    }
 
     const double oma_d = static_cast<double>(oma);
-    const double cx0 = sqrt(static_cast<double>(abt_f)) / oma_d;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);
-        const double a = (g ? static_cast<double>(h.one_plus_lambda) : 1.0) / oma_d;
-        const double dt = static_cast<double>(g ? dty : dtx);
-        double e[2], k[2], sd[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const double tau = s ? dt * 0.5 : dt;
-            e[s] = exp(-a * tau);
-            k[s] = -expm1(-a * tau) / a;
-            const double k2 = -expm1(-2.0 * a * tau) / (2.0 * a);
-            sd[s] = sqrt(fmax(2.0 * k2, 0.0));
-        }
-        q[LP_R_E_FULL] = static_cast<float>(e[0]);
-        q[LP_R_K_FULL] = static_cast<float>(k[0]);
-        q[LP_R_STD_FULL] = static_cast<float>(sd[0]);
-        q[LP_R_E_HALF] = static_cast<float>(e[1]);
-        q[LP_R_K_HALF] = static_cast<float>(k[1]);
-        q[LP_R_STD_HALF] = static_cast<float>(sd[1]);
+    float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);
+    const double a = (g ? static_cast<double>(h.one_plus_lambda) : 1.0) / oma_d;
+    const double dt = static_cast<double>(g ? dty : dtx);
+    const double tau = s ? dt * 0.5 : dt;
+    const double e = exp(-a * tau);
+    const double k = -expm1(-a * tau) / a;
+    const double k2 = -expm1(-2.0 * a * tau) / (2.0 * a);
+    const double sd = sqrt(fmax(2.0 * k2, 0.0));
+    q[s ? LP_R_E_HALF : LP_R_E_FULL] = static_cast<float>(e);
+    q[s ? LP_R_K_HALF : LP_R_K_FULL] = static_cast<float>(k);
+    q[s ? LP_R_STD_HALF : LP_R_STD_FULL] = static_cast<float>(sd);
+    if (s == 0) {
+        const double cx0 = sqrt(static_cast<double>(abt_f)) / oma_d;
         q[LP_R_DT] = static_cast<float>(dt);
         q[LP_R_A] = static_cast<float>(a);
         q[LP_R_CX0] = static_cast<float>(cx0);
@@ -147,8 +144,8 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
                     int t_stride, int rows, float* table, hipStream_t stream) {
     if (!h || !abt || !table || rows <= 0) return LP_E_INVALID;
     if (!h->is_flow && !ve) return LP_E_INVALID;
-    const int block = 64;
-    hipLaunchKernelGGL(lp_coeffs_kernel, dim3((rows + block - 1) / block), dim3(block), 0, stream, *h, ve, ve_stride,
+    const int block = 64, lanes = rows * 4;
+    hipLaunchKernelGGL(lp_coeffs_kernel, dim3((lanes + block - 1) / block), dim3(block), 0, stream, *h, ve, ve_stride,
                        abt, abt_stride, rs, rs_stride, step_ov, step_stride, t_model, t_stride, rows, table);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
@@ -198,8 +195,8 @@ template <int VEC>
 __global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d) {
     const int64_t groups = d.n_el / VEC;
     const int dt = x0_dtype(d.flags);
-    for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < groups;
-         g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;     // one group per lane
+    if (g < groups) {
         const int64_t i = g * VEC;
         float m[VEC], mo[VEC], yv[VEC], o[VEC];
         Raw<VEC> m_raw, mo_raw, un_raw;                 // issue every load, decode afterwards (lp_common.h)
@@ -243,8 +240,8 @@ int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
     const int vec = vec4 ? 4 : 1;
     const int64_t groups = d.n_el / vec;
     const int block = groups <= 64 * 1024 ? 64 : 256;
-    int64_t bx = (groups + block - 1) / block;
-    if (bx > 2048) bx = 2048;
+    const int64_t bx = (groups + block - 1) / block;
+    if (bx > 0x7fffffff) return LP_E_INVALID;
     if (vec4)
         hipLaunchKernelGGL(lp_finalize_kernel<4>, dim3(static_cast<unsigned>(bx)), dim3(block), 0, stream, d);
     else
