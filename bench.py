@@ -416,21 +416,23 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
     for k in range(10):
         d.rng_offset = k
         _cabi.check(lib.lp_step(ctypes.byref(d), st))
-    timers = []
-    for k in range(launches):
+    lead = 16                                     # dispatches that start on an idle chip, not counted
+    timers = (ctypes.c_void_p * (launches + lead))()
+    for k in range(launches + lead):
         t = ctypes.c_void_p()
         _cabi.check(lib.lp_timer_create(ctypes.byref(t)))
-        d.rng_offset = 100 + k
-        _cabi.check(lib.lp_step_timed(ctypes.byref(d), st, t))
-        timers.append(t)
+        timers[k] = t
+    d.rng_offset = 100
+    torch.cuda.synchronize(dev)
+    _cabi.check(lib.lp_step_timed_burst(ctypes.byref(d), st, timers, launches + lead))   # one host call: GPU stays busy
     torch.cuda.synchronize(dev)
     durs = []
     for t in timers:
         ns = ctypes.c_double()
-        _cabi.check(lib.lp_timer_elapsed_ns(t, ctypes.byref(ns)))
+        _cabi.check(lib.lp_timer_elapsed_ns(ctypes.c_void_p(t), ctypes.byref(ns)))
         durs.append(ns.value * 1e-9)
-        lib.lp_timer_destroy(t)
-    durs = np.asarray(durs)
+        lib.lp_timer_destroy(ctypes.c_void_p(t))
+    durs = np.asarray(durs[lead:])
     bytes_per_launch = BYTES_PER_EL_STEADY * n_el
     achieved = bytes_per_launch / float(durs.mean()) / 1e9
     shape = WORKLOADS[workload][0]

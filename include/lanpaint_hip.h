@@ -231,6 +231,10 @@ int lp_step(const lp_step_desc* desc, void* stream);
 int lp_timer_create(void** timer);
 int lp_timer_destroy(void* timer);
 int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);
+/* n timed launches of the same descriptor from one host call (rng_offset + i per launch), so the GPU stays
+ * busy between them: launched one by one through an FFI the host paces a ~10 us kernel and every dispatch
+ * starts on an idle chip (measured 13.0 us instead of the 10.5 us rocprofv3 reports for the same kernel). */
+int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n);
 int lp_timer_elapsed_ns(void* timer, double* ns);
 
 /* Staging for hipGraph replay: up to LP_COPY_MAX independent fp32 copies in ONE launch

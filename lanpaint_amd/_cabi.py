@@ -108,6 +108,7 @@ EXPORTS = {
     "lp_timer_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "lp_timer_destroy": (C.c_int, [C.c_void_p]),
     "lp_step_timed": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.c_void_p]),
+    "lp_step_timed_burst": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.POINTER(C.c_void_p), C.c_int32]),
     "lp_timer_elapsed_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "lp_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "lp_boundary_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

@@ -95,6 +95,17 @@ int lp_replay_call(const lp_call_desc* c, void* stream) {
     return lp::finalize_dispatch(c->final, s);
 }
 
+int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n) {
+    if (!desc || !timers || n <= 0) return LP_E_INVALID;
+    lp_step_desc d = *desc;
+    for (int32_t i = 0; i < n; ++i) {
+        d.rng_offset = desc->rng_offset + static_cast<uint64_t>(i);
+        const int rc = lp::step_dispatch(&d, as_stream(stream), timers[i]);
+        if (rc != LP_OK) return rc;
+    }
+    return LP_OK;
+}
+
 int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream) {
     return lp::pack_mask_dispatch(mask, n_el, flags, bits, nonbinary, as_stream(stream));
 }
