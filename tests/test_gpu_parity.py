@@ -392,3 +392,70 @@ def test_bit_packed_mask_vec4_rows_not_word_aligned():
         assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1])
     # a replayed graph draws its Philox sequence numbers from the device-side counter: compare graph with graph
     assert torch.equal(res[4][0], res[3][0]) and torch.equal(res[4][1], res[3][1])
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 40, 36), (2, 4, 258, 262)], ids=["vec1", "vec4"])
+@pytest.mark.parametrize("flow", [False, True], ids=["ve", "flow"])
+def test_kernel_instantiation_matrix_is_consistent(shape, flow):
+    """Every hot instantiation of the step kernel (mask fp32 / uint8 / bits x backbone output fp32 / bf16 / fp16 x
+    plain / fused-CFG heads, both vector widths): for one output dtype all mask formats are BITWISE equal, the
+    16-bit variants stay within their storage precision of the fp32 run, and fused CFG equals CFG formed eagerly."""
+    import torch
+    import lanpaint_amd
+    from lanpaint_amd import FusedCFGHeads, LanPaint
+    torch.manual_seed(3)
+    y = torch.randn(shape, device="cuda")
+    noise = torch.randn(shape, device="cuda")
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    if flow:
+        sig = torch.tensor([0.8, 0.45], device="cuda")
+        abt = (1 - sig) ** 2 / ((1 - sig) ** 2 + sig ** 2)
+        times = (sig / (1 - sig), abt, sig.clone())
+        x_start = sig.view(-1, 1, 1, 1) * noise + (1 - sig.view(-1, 1, 1, 1)) * y
+    else:
+        sig = torch.tensor([3.0, 0.9], device="cuda")
+        abt = 1 / (1 + sig ** 2)
+        times = (sig.clone(), abt, torch.sqrt(1 - abt) / (torch.sqrt(1 - abt) + torch.sqrt(abt)))
+        x_start = y + noise * sig.view(-1, 1, 1, 1)
+
+    class Net:
+        """two 'heads' with a little structure; `dtype` selects the storage type of the outputs."""
+        def __init__(self, dtype, fused):
+            self.inner_model = self
+            self.model_sampling = (MODELS["linear_tuple"](flow=flow)).inner_model.model_sampling
+            self.dtype, self.fused = dtype, fused
+
+        def __call__(self, x, t, model_options=None, seed=None):
+            cond, uncond = (0.9 * x + 0.05).to(self.dtype), (0.7 * x - 0.02).to(self.dtype)
+            if self.fused:
+                return FusedCFGHeads(cond, uncond, 3.0, 5.0)
+            c, u = cond.float(), uncond.float()
+            return (u + (c - u) * 3.0).to(self.dtype), (u + (c - u) * 5.0).to(self.dtype)
+
+    def run(mask_kind, dtype, fused):
+        m = mask.clone()
+        if mask_kind == "u8":
+            m._lp_u8 = m.to(torch.uint8)
+        elif mask_kind == "bits":
+            m = lanpaint_amd.pack_mask(m)
+        eng = LanPaint(Net(dtype, fused), 4, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, rng="philox", philox_seed=5)
+        x = x_start.clone()
+        out = eng(x, y, noise, sig, m, times, {}, 0)
+        assert torch.isfinite(x).all() and torch.isfinite(out).all()
+        return x, out
+
+    ref = {}
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        for fused in (False, True):
+            base = run("f32", dtype, fused)
+            for mk in ("u8", "bits"):
+                other = run(mk, dtype, fused)
+                assert torch.equal(other[0], base[0]) and torch.equal(other[1], base[1]), (mk, dtype, fused)
+            ref[(dtype, fused)] = base
+    f32 = ref[(torch.float32, False)]
+    scale = float(f32[0].abs().max())
+    # CFG formed inside the kernel (fp32, fmaf) vs formed eagerly and stored: fp32 identical up to rounding
+    assert float((ref[(torch.float32, True)][0] - f32[0]).abs().max()) <= 2e-5 * scale
+    for dtype, tol in ((torch.bfloat16, 6e-2), (torch.float16, 8e-3)):
+        for fused in (False, True):
+            assert float((ref[(dtype, fused)][0] - f32[0]).abs().max()) <= tol * scale, (dtype, fused)
