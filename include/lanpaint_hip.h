@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 5
+#define LP_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -236,20 +236,6 @@ int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);
  * starts on an idle chip (measured 13.0 us instead of the 10.5 us rocprofv3 reports for the same kernel). */
 int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n);
 int lp_timer_elapsed_ns(void* timer, double* ns);
-
-/* Staging for hipGraph replay: up to LP_COPY_MAX independent fp32 copies in ONE launch
- * (the sampler's x, sigma and the three time tensors into a captured call's static
- * buffers; its x / out back out).  src_stride 0 broadcasts element 0.                  */
-#define LP_COPY_MAX 6
-typedef struct lp_copy_desc {
-    int32_t      n;                       /* number of copies                    */
-    int32_t      reserved0;
-    int64_t      count[LP_COPY_MAX];      /* elements written per copy           */
-    int32_t      src_stride[LP_COPY_MAX]; /* 1 = dense, 0 = broadcast element 0  */
-    const float* src[LP_COPY_MAX];
-    float*       dst[LP_COPY_MAX];
-} lp_copy_desc;
-int lp_copy_batch(const lp_copy_desc* desc, void* stream);
 
 /* K3  finalise: known-region reprojection + in-place write-back.
  * Replaces: lanpaint.py:154,156.                                               */

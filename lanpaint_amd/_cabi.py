@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -78,15 +78,6 @@ class LpCallDesc(C.Structure):
     ]
 
 
-LP_COPY_MAX = 6
-
-
-class LpCopyDesc(C.Structure):
-    _fields_ = [("n", C.c_int32), ("reserved0", C.c_int32), ("count", C.c_int64 * LP_COPY_MAX),
-                ("src_stride", C.c_int32 * LP_COPY_MAX), ("src", C.c_void_p * LP_COPY_MAX),
-                ("dst", C.c_void_p * LP_COPY_MAX)]
-
-
 class LpBlendDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
                 ("k", C.c_int32), ("mask_batch", C.c_int32), ("mask_h", C.c_int32), ("mask_w", C.c_int32),
@@ -103,7 +94,6 @@ EXPORTS = {
     "lp_sigma_times": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_step": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p]),
     "lp_finalize": (C.c_int, [C.POINTER(LpFinalDesc), C.c_void_p]),
-    "lp_copy_batch": (C.c_int, [C.POINTER(LpCopyDesc), C.c_void_p]),
     "lp_mask_blend": (C.c_int, [C.POINTER(LpBlendDesc), C.c_void_p]),
     "lp_timer_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "lp_timer_destroy": (C.c_int, [C.c_void_p]),

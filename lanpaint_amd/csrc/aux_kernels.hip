@@ -151,44 +151,6 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
 }
 
 // ---------------------------------------------------------------------------------
-// batched staging copy (graph replay): blockIdx.y selects the copy
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lp_copy_batch_kernel(const lp_copy_desc d) {
-    const int a = blockIdx.y;
-    const int64_t n = d.count[a];
-    const float* __restrict__ src = d.src[a];
-    float* __restrict__ dst = d.dst[a];
-    const int64_t stride = d.src_stride[a];
-    const bool vec = stride == 1 && (n % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
-                     (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
-    if (vec) {
-        for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n / 4;
-             q += static_cast<int64_t>(gridDim.x) * blockDim.x)
-            reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(src)[q];
-    } else {
-        for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
-             i += static_cast<int64_t>(gridDim.x) * blockDim.x)
-            dst[i] = src[i * stride];
-    }
-}
-
-int copy_batch_dispatch(const lp_copy_desc* dp, hipStream_t stream) {
-    if (!dp || dp->n <= 0 || dp->n > LP_COPY_MAX) return LP_E_INVALID;
-    int64_t max_n = 0;
-    for (int a = 0; a < dp->n; ++a) {
-        if (!dp->src[a] || !dp->dst[a] || dp->count[a] <= 0) return LP_E_INVALID;
-        if (dp->src_stride[a] != 0 && dp->src_stride[a] != 1) return LP_E_INVALID;
-        if (dp->count[a] > max_n) max_n = dp->count[a];
-    }
-    int64_t bx = (max_n / 4 + 255) / 256;
-    if (bx < 1) bx = 1;
-    if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(lp_copy_batch_kernel, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(dp->n)), dim3(256), 0,
-                       stream, *dp);
-    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
-}
-
-// ---------------------------------------------------------------------------------
 // K3: out = model_out*(1-m) + y*m ; x_dst <- x_src      (lanpaint.py:154,156)
 // ---------------------------------------------------------------------------------
 template <int VEC>

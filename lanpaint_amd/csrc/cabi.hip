@@ -14,7 +14,6 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
 int finalize_dispatch(const lp_final_desc* d, hipStream_t stream);
 int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow, float* times,
                          float* scalars, hipStream_t stream);
-int copy_batch_dispatch(const lp_copy_desc* d, hipStream_t stream);
 int blend_dispatch(const lp_blend_desc* d, hipStream_t stream);
 int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream);
 int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream);
@@ -66,7 +65,6 @@ int lp_timer_elapsed_ns(void* timer, double* ns) { return lp::timer_elapsed_ns(t
 
 int lp_mask_blend(const lp_blend_desc* desc, void* stream) { return lp::blend_dispatch(desc, as_stream(stream)); }
 
-int lp_copy_batch(const lp_copy_desc* desc, void* stream) { return lp::copy_batch_dispatch(desc, as_stream(stream)); }
 
 int lp_finalize(const lp_final_desc* desc, void* stream) { return lp::finalize_dispatch(desc, as_stream(stream)); }
 
