@@ -517,7 +517,7 @@ class LanPaint:
         cap.hyper = _cabi.LpHyper.from_buffer_copy(self._hyper)
         cap.k0_desc = st.k0_desc
         f = _cabi.LpFinalDesc()
-        dense_ok = self._fill_final_desc(f, st, cap.final, torch.empty(0), allow_convert=False)
+        dense_ok = self._fill_final_desc(f, st, cap.final, torch.empty(0))
         if self.rng == "philox":
             f.rng_bump_ptr, f.rng_bump = counter.data_ptr(), cap.launches
         cap.f_desc = f
@@ -712,7 +712,7 @@ class LanPaint:
         return self.inner_model(x_model, st.sigma_model, model_options=model_options, seed=seed)     # lanpaint.py:151-153
 
     # ---- epilogue: known-region reprojection + in-place write-back (lanpaint.py:144-157) ----------------------
-    def _fill_final_desc(self, f, st, final, out, allow_convert=True):
+    def _fill_final_desc(self, f, st, final, out):
         """lp_finalize descriptor for this call.  Returns False when a backbone output had to be converted /
         made dense (then the descriptor points at a temporary and must not be reused for later replays)."""
         shape = st.shape
