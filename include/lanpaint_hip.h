@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 6
+#define LP_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -89,6 +89,10 @@ typedef struct lp_hyper {
 #define LP_PH_POST_STEADY  (1u << 2) /* C'=coefC; x_t+=(C'-C)dt; x_t=OU(x_t,dt/2,C_old); C=C'  :281-284 */
 #define LP_PH_PRE_HALF     (1u << 3) /* x_t = OU(x_t,dt/2,C) -- first half of the NEXT iteration  :280  */
 #define LP_PH_EMIT         (1u << 4) /* x_in = model-space(x_t)           lanpaint.py:144-147,163,168 */
+#define LP_PH_COEFFS       (1u << 5) /* with LP_PH_REPLACE: this launch ALSO writes the call's coefficient table
+                                        (lp_coeffs folded in: one launch less per sigma call) from the raw per-row
+                                        times `t_*`; its own replace / emit use the row's scale and replace sigma
+                                        computed from the same inputs.  Not with LP_FL_PER_ELEMENT.             */
 
 /* ---- flags ---------------------------------------------------------------- */
 #define LP_FL_FLOW          (1u << 0)  /* flow/flux VP scaling, else VE                        */
@@ -154,6 +158,13 @@ typedef struct lp_step_desc {
     const float* ve_el;        /*                    per-element VE sigma                 */
     const float* rsig_el;      /*                    per-element replace sigma            */
     const float* corr_el;      /* audio_correction (lanpaint.py:173-180) or NULL          */
+    /* LP_PH_COEFFS: the inputs of lp_coeffs (same meaning, same strides) and the table to write */
+    const float* t_ve;         /* [rows] VE sigma (NULL for flow)                         */
+    const float* t_abt;        /* [rows] abt                                              */
+    const float* t_rsig;       /* [rows] replace sigma                                    */
+    const float* t_model;      /* [rows] backbone time argument -> slot LP_C_TMODEL       */
+    float*       coef_out;     /* [rows][LP_COEF_STRIDE]                                  */
+    int32_t      t_ve_stride, t_abt_stride, t_rsig_stride, t_model_stride;   /* 0 = broadcast row 0 */
 } lp_step_desc;
 
 typedef struct lp_final_desc {
@@ -190,7 +201,8 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
 
 /* One sigma call's whole enqueue sequence in ONE host call, for callers that replay the think loop as a
  * hipGraph (the loop between the replace step and the finalise, captured by the caller):
- *     lp_coeffs(...) ; lp_step(replace) ; hipGraphLaunch(graph_exec, stream) ; lp_finalize(final).
+ *     [lp_coeffs(...)] ; lp_step(replace) ; hipGraphLaunch(graph_exec, stream) ; lp_finalize(final).
+ * `hyper` NULL skips the separate lp_coeffs launch (the replace descriptor then carries LP_PH_COEFFS).
  * Host-side launch cost matters at SDXL-latent sizes (the whole call is ~40 us of GPU time): four trips through
  * an FFI cost more than the kernels they start.  `graph_exec` is a hipGraphExec_t (NULL: skip the graph launch).
  * Stops at the first failing step and returns its code.                                              */

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -24,7 +24,7 @@ LP_C_REGION0, LP_C_REGION1, LP_C_TMODEL = 12, 22, 32
 (LP_R_E_FULL, LP_R_K_FULL, LP_R_STD_FULL, LP_R_E_HALF, LP_R_K_HALF, LP_R_STD_HALF, LP_R_DT, LP_R_A, LP_R_CX0,
  LP_R_CXT) = range(10)
 
-LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT = 1, 2, 4, 8, 16
+LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT, LP_PH_COEFFS = 1, 2, 4, 8, 16, 32
 LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
 LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED, LP_FL_MASK_BITS = 256, 512, 1024, 2048
@@ -52,6 +52,9 @@ class LpStepDesc(C.Structure):
         ("x0_big", C.c_void_p), ("x_in", C.c_void_p), ("xi_post", C.c_void_p), ("xi_pre", C.c_void_p),
         ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64), ("rng_offset_ptr", C.c_void_p),
         ("abt_el", C.c_void_p), ("ve_el", C.c_void_p), ("rsig_el", C.c_void_p), ("corr_el", C.c_void_p),
+        ("t_ve", C.c_void_p), ("t_abt", C.c_void_p), ("t_rsig", C.c_void_p), ("t_model", C.c_void_p),
+        ("coef_out", C.c_void_p), ("t_ve_stride", C.c_int32), ("t_abt_stride", C.c_int32),
+        ("t_rsig_stride", C.c_int32), ("t_model_stride", C.c_int32),
     ]
 
 

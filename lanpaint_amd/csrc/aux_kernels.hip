@@ -22,56 +22,16 @@ __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int v
                                  int rs_stride, const float* __restrict__ step_ov, int step_stride,
                                  const float* __restrict__ t_model, int t_stride, int rows, float* __restrict__ table) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = t >> 2, g = (t >> 1) & 1, s = t & 1;
+    const int r = t >> 2;
     if (r >= rows) return;
     const float abt_f = abt[static_cast<int64_t>(r) * abt_stride];
-    float* c = table + static_cast<int64_t>(r) * LP_COEF_STRIDE;
-
+    const float ve_f = ve ? ve[static_cast<int64_t>(r) * ve_stride] : 0.0f;
+    const float rs_f = rs ? rs[static_cast<int64_t>(r) * rs_stride] : 0.0f;
+    const float tm_f = t_model ? t_model[static_cast<int64_t>(r) * t_stride] : 0.0f;
     const float oma = 1.0f - abt_f;
     const float step = step_ov ? step_ov[static_cast<int64_t>(r) * step_stride]
                                : h.step_size * fmaxf(oma, h.min_step_frac);  // lanpaint.py:81
-    const float dtx2 = 2.0f * step * 1.0f, dty2 = 2.0f * step * h.beta;        // :300-301
-    const float dtx = dtx2 / 2.0f, dty = dty2 / 2.0f;                          // :328
-    if (g == 0 && s == 0) {                  // the row header
-        const float ve_f = ve ? ve[static_cast<int64_t>(r) * ve_stride] : 0.0f;
-        const float rs_f = rs ? rs[static_cast<int64_t>(r) * rs_stride] : 0.0f;
-        const float atx = (1.0f / oma) * dtx2 / 2.0f;                              // :315
-        const float aty = (h.one_plus_lambda / oma) * dty2 / 2.0f;                 // :316
-        const bool valid = step > 0.0f;                                            // :205 (per row)
-        c[LP_C_SCALE] = h.is_flow ? (sqrtf(abt_f) + sqrtf(1.0f - abt_f)) : sqrtf(1.0f + ve_f * ve_f);   // :96-99
-        c[LP_C_SQRT_ABT] = sqrtf(abt_f);
-        c[LP_C_OMA] = oma;
-        c[LP_C_ABT] = abt_f;
-        c[LP_C_RSIGMA] = rs_f;
-        c[LP_C_DTX] = dtx;
-        c[LP_C_DTY] = dty;
-        c[LP_C_AX] = atx / dtx;                                                    // :319
-        c[LP_C_AY] = aty / dty;                                                    // :320
-        c[LP_C_DX] = sqrtf(2.0f);                                                  // :326-327
-        c[LP_C_DY] = sqrtf(2.0f);
-        c[LP_C_VALID] = valid ? 1.0f : 0.0f;
-        c[LP_C_TMODEL] = t_model ? t_model[static_cast<int64_t>(r) * t_stride] : 0.0f;
-    }
-
-    const double oma_d = static_cast<double>(oma);
-    float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);
-    const double a = (g ? static_cast<double>(h.one_plus_lambda) : 1.0) / oma_d;
-    const double dt = static_cast<double>(g ? dty : dtx);
-    const double tau = s ? dt * 0.5 : dt;
-    const double e = exp(-a * tau);
-    const double k = -expm1(-a * tau) / a;
-    const double k2 = -expm1(-2.0 * a * tau) / (2.0 * a);
-    const double sd = sqrt(fmax(2.0 * k2, 0.0));
-    q[s ? LP_R_E_HALF : LP_R_E_FULL] = static_cast<float>(e);
-    q[s ? LP_R_K_HALF : LP_R_K_FULL] = static_cast<float>(k);
-    q[s ? LP_R_STD_HALF : LP_R_STD_FULL] = static_cast<float>(sd);
-    if (s == 0) {
-        const double cx0 = sqrt(static_cast<double>(abt_f)) / oma_d;
-        q[LP_R_DT] = static_cast<float>(dt);
-        q[LP_R_A] = static_cast<float>(a);
-        q[LP_R_CX0] = static_cast<float>(cx0);
-        q[LP_R_CXT] = g ? static_cast<float>(a - 1.0 / oma_d) : 0.0f;
-    }
+    coeffs_lane(h, abt_f, ve_f, rs_f, tm_f, step, (t >> 1) & 1, t & 1, table + static_cast<int64_t>(r) * LP_COEF_STRIDE);
 }
 
 // ---------------------------------------------------------------------------------

@@ -82,9 +82,11 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
 }
 
 int lp_replay_call(const lp_call_desc* c, void* stream) {
-    if (!c || !c->hyper || !c->replace || !c->final) return LP_E_INVALID;
+    if (!c || !c->replace || !c->final) return LP_E_INVALID;
     hipStream_t s = as_stream(stream);
-    int rc = lp::coeffs_dispatch(c->hyper, c->ve_sigma, c->ve_stride, c->abt, c->abt_stride, c->replace_sigma,
+    int rc = LP_OK;
+    if (c->hyper)       // NULL: the replace launch carries LP_PH_COEFFS and writes the table itself
+        rc = lp::coeffs_dispatch(c->hyper, c->ve_sigma, c->ve_stride, c->abt, c->abt_stride, c->replace_sigma,
                                  c->rs_stride, nullptr, 0, c->t_model, c->t_stride, c->rows, c->coef_table, s);
     if (rc != LP_OK) return rc;
     rc = lp::step_dispatch(c->replace, s, nullptr);

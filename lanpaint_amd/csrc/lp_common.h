@@ -230,6 +230,62 @@ __device__ __forceinline__ void load_mask(const void* __restrict__ p, uint32_t f
     cvt_mask<V>(flags, i, r, m);
 }
 
+// ---- per-row coefficient table (K1) ---------------------------------------------------
+// One of the FOUR lanes that build a row: lane (g, s) = (region, tau in {dt, dt/2}) evaluates its 3 dependent
+// double-precision exp / expm1 factors; lane (0, 0) also writes the row header.  fp32 fields mirror the
+// reference's own op order (prepare_step_size, lanpaint.py:295-328); the per-region closed-form factors are
+// evaluated in double from those fp32 inputs (lanpaint.py:241-252 in exact arithmetic).  Shared by
+// lp_coeffs_kernel and the LP_PH_COEFFS form of the replace launch.
+__device__ __forceinline__ float row_scale(bool flow, float abt_f, float ve_f) {        // lanpaint.py:96-99
+#pragma clang fp contract(off)
+    return flow ? (sqrtf(abt_f) + sqrtf(1.0f - abt_f)) : sqrtf(1.0f + ve_f * ve_f);
+}
+
+__device__ inline void coeffs_lane(const lp_hyper& h, float abt_f, float ve_f, float rs_f, float tm_f, float step,
+                                   int g, int s, float* __restrict__ c) {
+#pragma clang fp contract(off)
+    const float oma = 1.0f - abt_f;
+    const float dtx2 = 2.0f * step * 1.0f, dty2 = 2.0f * step * h.beta;        // :300-301
+    const float dtx = dtx2 / 2.0f, dty = dty2 / 2.0f;                          // :328
+    if (g == 0 && s == 0) {                  // the row header
+        const float atx = (1.0f / oma) * dtx2 / 2.0f;                              // :315
+        const float aty = (h.one_plus_lambda / oma) * dty2 / 2.0f;                 // :316
+        const bool valid = step > 0.0f;                                            // :205 (per row)
+        c[LP_C_SCALE] = row_scale(h.is_flow, abt_f, ve_f);
+        c[LP_C_SQRT_ABT] = sqrtf(abt_f);
+        c[LP_C_OMA] = oma;
+        c[LP_C_ABT] = abt_f;
+        c[LP_C_RSIGMA] = rs_f;
+        c[LP_C_DTX] = dtx;
+        c[LP_C_DTY] = dty;
+        c[LP_C_AX] = atx / dtx;                                                    // :319
+        c[LP_C_AY] = aty / dty;                                                    // :320
+        c[LP_C_DX] = sqrtf(2.0f);                                                  // :326-327
+        c[LP_C_DY] = sqrtf(2.0f);
+        c[LP_C_VALID] = valid ? 1.0f : 0.0f;
+        c[LP_C_TMODEL] = tm_f;
+    }
+    const double oma_d = static_cast<double>(oma);
+    float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);
+    const double a = (g ? static_cast<double>(h.one_plus_lambda) : 1.0) / oma_d;
+    const double dt = static_cast<double>(g ? dty : dtx);
+    const double tau = s ? dt * 0.5 : dt;
+    const double e = exp(-a * tau);
+    const double k = -expm1(-a * tau) / a;
+    const double k2 = -expm1(-2.0 * a * tau) / (2.0 * a);
+    const double sd = sqrt(fmax(2.0 * k2, 0.0));
+    q[s ? LP_R_E_HALF : LP_R_E_FULL] = static_cast<float>(e);
+    q[s ? LP_R_K_HALF : LP_R_K_FULL] = static_cast<float>(k);
+    q[s ? LP_R_STD_HALF : LP_R_STD_FULL] = static_cast<float>(sd);
+    if (s == 0) {
+        const double cx0 = sqrt(static_cast<double>(abt_f)) / oma_d;
+        q[LP_R_DT] = static_cast<float>(dt);
+        q[LP_R_A] = static_cast<float>(a);
+        q[LP_R_CX0] = static_cast<float>(cx0);
+        q[LP_R_CXT] = g ? static_cast<float>(a - 1.0 / oma_d) : 0.0f;
+    }
+}
+
 __host__ __device__ inline int x0_dtype(uint32_t flags) {
     return (flags & LP_FL_X0_BF16) ? DT_BF16 : (flags & LP_FL_X0_F16) ? DT_F16 : DT_F32;
 }

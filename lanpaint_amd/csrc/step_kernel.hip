@@ -142,7 +142,28 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     const float lam = d.lambda, opl = d.one_plus_lambda;
 
     RowCoef rc;
-    if constexpr (!PER_EL) rc = load_row(d.coef, row);
+    const bool fold_coeffs = (ph & LP_PH_COEFFS) != 0;       // compile-time for PH != 0
+    if (fold_coeffs) {
+        // lp_coeffs folded into the replace launch: every block derives the two row scalars its own work needs
+        // (same expressions as the table's), lanes 0..3 of the row's first block build the table for the
+        // launches that follow
+        const float abt_f = d.t_abt[static_cast<int64_t>(row) * d.t_abt_stride];
+        const float ve_f = d.t_ve ? d.t_ve[static_cast<int64_t>(row) * d.t_ve_stride] : 0.0f;
+        const float rs_f = d.t_rsig ? d.t_rsig[static_cast<int64_t>(row) * d.t_rsig_stride] : 0.0f;
+        rc.scale = row_scale(flow, abt_f, ve_f);
+        rc.rsigma = rs_f;
+        if (blockIdx.x == 0 && threadIdx.x < 4) {
+            lp_hyper h;
+            h.lambda = d.lambda; h.beta = d.beta; h.step_size = d.step_size; h.min_step_frac = d.min_step_frac;
+            h.is_flow = flow ? 1 : 0; h.one_plus_lambda = d.one_plus_lambda;
+            const float tm_f = d.t_model ? d.t_model[static_cast<int64_t>(row) * d.t_model_stride] : 0.0f;
+            const float step = d.step_size * fmaxf(1.0f - abt_f, d.min_step_frac);                 // lanpaint.py:81
+            coeffs_lane(h, abt_f, ve_f, rs_f, tm_f, step, (threadIdx.x >> 1) & 1, threadIdx.x & 1,
+                        d.coef_out + static_cast<int64_t>(row) * LP_COEF_STRIDE);
+        }
+    } else {
+        if constexpr (!PER_EL) rc = load_row(d.coef, row);
+    }
 
     const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
     const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
@@ -410,6 +431,9 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     if (d.flags & LP_FL_MASK_U8) return launch<VEC, MODE_ROW, 0>(d, stream, timer);   // legacy format: run-time everything
     if (d.phases == (R | E))                                                         // replace step: no x0 at all
         return hard ? launch<VEC, MODE_HARD, R | E>(d, stream, timer) : launch<VEC, MODE_ROW, R | E>(d, stream, timer);
+    if (d.phases == (R | E | LP_PH_COEFFS))                                          // ... + the coefficient table
+        return hard ? launch<VEC, MODE_HARD, R | E | LP_PH_COEFFS>(d, stream, timer)
+                    : launch<VEC, MODE_ROW, R | E | LP_PH_COEFFS>(d, stream, timer);
 #define LP_HOT(MODE_, PH_) (x0_half ? launch<VEC, MODE_, PH_, 2>(d, stream, timer) : launch<VEC, MODE_, PH_, 4>(d, stream, timer))
     if (hard) {
         switch (d.phases) {
@@ -442,11 +466,16 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if ((d.flags & LP_FL_MASK_BITS) && ((d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_DENOISE)) || !aligned(d.mask, 4)))
         return LP_E_INVALID;
     const uint32_t ph = d.phases;
-    if (ph == 0 || (ph & ~0x1fu)) return LP_E_INVALID;
+    if (ph == 0 || (ph & ~0x3fu)) return LP_E_INVALID;
+    if (ph & LP_PH_COEFFS) {       // only as the fused replace launch of a row-table call
+        if (ph != (LP_PH_REPLACE | LP_PH_EMIT | LP_PH_COEFFS) || (d.flags & LP_FL_PER_ELEMENT)) return LP_E_INVALID;
+        if (!d.t_abt || !d.coef_out || (!(d.flags & LP_FL_FLOW) && !d.t_ve)) return LP_E_INVALID;
+        if (d.replace_kind != LP_REPLACE_KNOWN && !d.t_rsig) return LP_E_INVALID;
+    }
     if ((ph & LP_PH_POST_FIRST) && (ph & LP_PH_POST_STEADY)) return LP_E_INVALID;
     if ((ph & LP_PH_REPLACE) && (ph & (kPost | LP_PH_PRE_HALF))) return LP_E_INVALID;
     const bool per_el = d.flags & LP_FL_PER_ELEMENT;
-    if (!per_el && !d.coef) return LP_E_INVALID;
+    if (!per_el && !d.coef && !(ph & LP_PH_COEFFS)) return LP_E_INVALID;
     if (per_el && (!d.abt_el || (!(d.flags & LP_FL_FLOW) && !d.ve_el))) return LP_E_INVALID;
     if (ph & LP_PH_REPLACE) {
         if (!d.x) return LP_E_INVALID;

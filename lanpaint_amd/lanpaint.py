@@ -448,8 +448,8 @@ class LanPaint:
         return self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None)
 
     def _replay_fast(self, cap, x, sigma, current_times):
-        """Steady-state replay: the launches around the graph (lp_coeffs, replace, lp_finalize) reuse the
-        descriptors snapshotted at capture; only the caller's pointers (x, noise, sigma, times, out) change.
+        """Steady-state replay: the two launches around the graph (replace + coefficient table, lp_finalize) reuse
+        the descriptors snapshotted at capture; only the caller's pointers (x, noise, sigma, times, out) change.
         With the raw hipGraphExec_t the whole sequence is ONE trip through the FFI (lp_replay_call)."""
         lib, stream = self._lib, self._stream(x.device)
         ve, abt = current_times[0], current_times[1]
@@ -457,19 +457,12 @@ class LanPaint:
         out = torch.empty_like(x)
         k0, f = cap.k0_desc, cap.f_desc
         k0.x, k0.noise = x.data_ptr(), self.noise.data_ptr()
+        # the replace launch also rebuilds the coefficient table from this call's sigma / times (LP_PH_COEFFS)
+        k0.t_ve, k0.t_abt, k0.t_rsig, k0.t_model = ve.data_ptr(), abt.data_ptr(), sigma.data_ptr(), t_src.data_ptr()
         f.x_dst, f.out = k0.x, out.data_ptr()
         if cap.raw_exec is not None:
-            c = cap.call
-            c.ve_sigma, c.ve_stride = ve.data_ptr(), ve.numel() > 1
-            c.abt, c.abt_stride = abt.data_ptr(), abt.numel() > 1
-            c.replace_sigma, c.rs_stride = sigma.data_ptr(), sigma.numel() > 1
-            c.t_model, c.t_stride = t_src.data_ptr(), t_src.numel() > 1
-            _cabi.check(lib.lp_replay_call(ctypes.byref(c), stream), "lp_replay_call")
+            _cabi.check(lib.lp_replay_call(ctypes.byref(cap.call), stream), "lp_replay_call")
             return out
-        _cabi.check(lib.lp_coeffs(ctypes.byref(cap.hyper), ve.data_ptr(), int(ve.numel() > 1), abt.data_ptr(),
-                                  int(abt.numel() > 1), sigma.data_ptr(), int(sigma.numel() > 1), None, 0,
-                                  t_src.data_ptr(), int(t_src.numel() > 1), cap.rows, cap.ws.coef.data_ptr(), stream),
-                    "lp_coeffs")
         _cabi.check(lib.lp_step(ctypes.byref(k0), stream), "lp_step")
         cap.graph.replay()
         _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
@@ -528,8 +521,8 @@ class LanPaint:
                     cap.raw_exec = int(cap.graph.raw_cuda_graph_exec()) or None
                 except Exception:
                     cap.raw_exec = None
-            c = cap.call = _cabi.LpCallDesc()
-            c.hyper, c.replace, c.final = ctypes.pointer(cap.hyper), ctypes.pointer(cap.k0_desc), ctypes.pointer(f)
+            c = cap.call = _cabi.LpCallDesc()          # hyper = NULL: no separate lp_coeffs launch, the replace does it
+            c.replace, c.final = ctypes.pointer(cap.k0_desc), ctypes.pointer(f)
             c.rows, c.coef_table, c.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.raw_exec
         self._graphs[key] = cap
         return cap
@@ -607,10 +600,11 @@ class LanPaint:
             ve_r, abt_r, rs_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1)), _as_f32c(replace_sigma.reshape(-1))
             tm_r = _as_f32c(t_model.reshape(-1))
             keep += [ve_r, abt_r, rs_r, tm_r]
-            _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), ve_r.data_ptr(), int(ve_r.numel() > 1), abt_r.data_ptr(),
-                                      int(abt_r.numel() > 1), rs_r.data_ptr(), int(rs_r.numel() > 1), None, 0,
-                                      tm_r.data_ptr(), int(tm_r.numel() > 1), rows, ws.coef.data_ptr(), stream), "lp_coeffs")
-            d.coef = ws.coef.data_ptr()
+            # the coefficient table is written by the replace launch itself (LP_PH_COEFFS: lp_coeffs folded in)
+            d.t_ve, d.t_abt, d.t_rsig, d.t_model = ve_r.data_ptr(), abt_r.data_ptr(), rs_r.data_ptr(), tm_r.data_ptr()
+            d.t_ve_stride, d.t_abt_stride = ve_r.numel() > 1, abt_r.numel() > 1
+            d.t_rsig_stride, d.t_model_stride = rs_r.numel() > 1, tm_r.numel() > 1
+            d.coef = d.coef_out = ws.coef.data_ptr()
         if corr is not None:
             corr_el = _as_f32c(corr if corr.shape == shape else corr.expand(shape))
             keep.append(corr_el)
@@ -662,7 +656,8 @@ class LanPaint:
         d.xi_post = d.xi_pre = None
         d.rng_offset_ptr = None
         d.rng_seed = int(self.philox_seed if self.philox_seed is not None else (seed or 0)) & 0xFFFFFFFFFFFFFFFF
-        d.flags, d.phases = base_flags | self._emit(st, n_steps == 0), LP_PH_REPLACE | LP_PH_EMIT
+        d.flags = base_flags | self._emit(st, n_steps == 0)
+        d.phases = LP_PH_REPLACE | LP_PH_EMIT | (0 if per_el else _cabi.LP_PH_COEFFS)
         self._launch_step(stream)
         st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
         st.k0_desc = _cabi.LpStepDesc.from_buffer_copy(d) if ws.static_io else None

@@ -309,3 +309,55 @@ def test_pack_mask_flags_soft_masks_and_rejects_bad_arguments(lib):
     assert lib.lp_pack_mask(soft.data_ptr(), 0, 0, bits.data_ptr(), None, s) < 0
     assert lib.lp_pack_mask(soft.data_ptr(), 160, _cabi.LP_FL_MASK_U8, bits.data_ptr(), None, s) < 0
     assert lib.lp_pack_mask(None, 160, 0, bits.data_ptr(), None, s) < 0
+
+
+@pytest.mark.parametrize("flow", [False, True])
+@pytest.mark.parametrize("shape", [(3, 4, 6, 5), (2, 4, 260, 256)])
+def test_replace_launch_with_folded_coefficients_equals_lp_coeffs(lib, flow, shape):
+    """LP_PH_COEFFS: the replace launch writes the coefficient table itself.  Table bitwise equal to lp_coeffs',
+    x_t / x_in bitwise equal to the two-launch form (both vector widths; tiny rows: fewer groups than table lanes)."""
+    import ctypes
+    import torch
+    from lanpaint_amd import _cabi
+    torch.manual_seed(1)
+    rows, n_el = shape[0], int(np.prod(shape))
+    x, y, noise = (torch.randn(shape, device="cuda") for _ in range(3))
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    sig = torch.linspace(0.3, 0.9, rows, device="cuda") if flow else torch.linspace(0.5, 7.0, rows, device="cuda")
+    if flow:
+        abt = (1 - sig) ** 2 / ((1 - sig) ** 2 + sig ** 2)
+        ve, tm = sig / (1 - sig), sig.clone()
+    else:
+        abt, ve, tm = 1 / (1 + sig ** 2), sig.clone(), sig.clone()
+    h = _cabi.LpHyper()
+    h.lambda_, h.beta, h.step_size, h.min_step_frac, h.is_flow, h.one_plus_lambda = 5.0, 1.3, 0.2, 0.1, int(flow), 6.0
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for fold in (False, True):
+        coef = torch.full((rows, _cabi.LP_COEF_STRIDE), float("nan"), device="cuda")
+        x_t, x_in = torch.empty(shape, device="cuda"), torch.empty(shape, device="cuda")
+        d = _cabi.LpStepDesc()
+        d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
+        d.flags = _cabi.LP_FL_FLOW if flow else 0
+        d.replace_kind = _cabi.LP_REPLACE_FLOW if flow else _cabi.LP_REPLACE_VE
+        d.lambda_, d.one_plus_lambda, d.beta, d.step_size, d.min_step_frac, d.noise_scale = 5.0, 6.0, 1.3, 0.2, 0.1, 1.0
+        d.coef, d.x, d.noise, d.y, d.mask = coef.data_ptr(), x.data_ptr(), noise.data_ptr(), y.data_ptr(), mask.data_ptr()
+        d.x_t, d.x_in = x_t.data_ptr(), x_in.data_ptr()
+        d.phases = _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT
+        if fold:
+            d.phases |= _cabi.LP_PH_COEFFS
+            d.t_ve, d.t_abt, d.t_rsig, d.t_model = ve.data_ptr(), abt.data_ptr(), sig.data_ptr(), tm.data_ptr()
+            d.t_ve_stride = d.t_abt_stride = d.t_rsig_stride = d.t_model_stride = 1
+            d.coef_out = coef.data_ptr()
+        else:
+            _cabi.check(lib.lp_coeffs(ctypes.byref(h), ve.data_ptr(), 1, abt.data_ptr(), 1, sig.data_ptr(), 1, None, 0,
+                                      tm.data_ptr(), 1, rows, coef.data_ptr(), st), "lp_coeffs")
+        _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+        torch.cuda.synchronize()
+        used = [c for c in range(_cabi.LP_COEF_STRIDE) if c < 32 or c == _cabi.LP_C_TMODEL]
+        outs.append((coef[:, used].cpu(), x_t.cpu(), x_in.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # the fold is only valid as REPLACE | EMIT | COEFFS of a row-table launch, with its inputs present
+    d.t_abt = None
+    assert lib.lp_step(ctypes.byref(d), st) < 0
