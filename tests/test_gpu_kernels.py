@@ -361,3 +361,64 @@ def test_replace_launch_with_folded_coefficients_equals_lp_coeffs(lib, flow, sha
     # the fold is only valid as REPLACE | EMIT | COEFFS of a row-table launch, with its inputs present
     d.t_abt = None
     assert lib.lp_step(ctypes.byref(d), st) < 0
+
+
+def test_replay_call_sequences_the_launches_and_reports_errors(lib):
+    """lp_replay_call = [lp_coeffs] ; lp_step(replace) ; [hipGraphLaunch] ; lp_finalize in one FFI trip: same results
+    as the separate entry points (here without a graph: graph_exec = NULL), first failing step's code returned."""
+    import ctypes
+    import torch
+    from lanpaint_amd import _cabi
+    torch.manual_seed(2)
+    shape = (2, 4, 16, 12)
+    rows, n_el = shape[0], int(np.prod(shape))
+    x, y, noise, model_out = (torch.randn(shape, device="cuda") for _ in range(4))
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    sig = torch.tensor([2.0, 0.7], device="cuda")
+    abt = 1 / (1 + sig ** 2)
+    h = _cabi.LpHyper()
+    h.lambda_, h.beta, h.step_size, h.min_step_frac, h.is_flow, h.one_plus_lambda = 5.0, 1.0, 0.2, 0.0, 0, 6.0
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(one_call):
+        coef = torch.zeros((rows, _cabi.LP_COEF_STRIDE), device="cuda")
+        x_t, x_in, out, x_back = (torch.empty(shape, device="cuda") for _ in range(4))
+        d = _cabi.LpStepDesc()
+        d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
+        d.replace_kind, d.phases = _cabi.LP_REPLACE_VE, _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT
+        d.lambda_, d.one_plus_lambda, d.beta, d.step_size, d.noise_scale = 5.0, 6.0, 1.0, 0.2, 1.0
+        d.coef, d.x, d.noise, d.y, d.mask = coef.data_ptr(), x.data_ptr(), noise.data_ptr(), y.data_ptr(), mask.data_ptr()
+        d.x_t, d.x_in = x_t.data_ptr(), x_in.data_ptr()
+        f = _cabi.LpFinalDesc()
+        f.n_el, f.model_out, f.y, f.mask = n_el, model_out.data_ptr(), y.data_ptr(), mask.data_ptr()
+        f.x_src, f.x_dst, f.out = x_in.data_ptr(), x_back.data_ptr(), out.data_ptr()
+        if one_call:
+            c = _cabi.LpCallDesc()
+            c.hyper, c.replace, c.final = ctypes.pointer(h), ctypes.pointer(d), ctypes.pointer(f)
+            c.ve_sigma, c.abt, c.replace_sigma, c.t_model = sig.data_ptr(), abt.data_ptr(), sig.data_ptr(), sig.data_ptr()
+            c.ve_stride = c.abt_stride = c.rs_stride = c.t_stride = 1
+            c.rows, c.coef_table, c.graph_exec = rows, coef.data_ptr(), None
+            _cabi.check(lib.lp_replay_call(ctypes.byref(c), st), "lp_replay_call")
+        else:
+            _cabi.check(lib.lp_coeffs(ctypes.byref(h), sig.data_ptr(), 1, abt.data_ptr(), 1, sig.data_ptr(), 1, None, 0,
+                                      sig.data_ptr(), 1, rows, coef.data_ptr(), st), "lp_coeffs")
+            _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+            _cabi.check(lib.lp_finalize(ctypes.byref(f), st), "lp_finalize")
+        torch.cuda.synchronize()
+        return [t.cpu() for t in (coef, x_t, x_in, out, x_back)], (d, f)
+
+    a, _ = run(False)
+    b, (d, f) = run(True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.isfinite(b[3]).all()
+    c = _cabi.LpCallDesc()
+    assert lib.lp_replay_call(ctypes.byref(c), st) < 0                      # nothing set
+    assert lib.lp_replay_call(None, st) < 0
+    d.x = None                                                              # the replace step must fail ...
+    c.replace, c.final = ctypes.pointer(d), ctypes.pointer(f)
+    marker = torch.full((4,), 7.0, device="cuda")
+    f.out = marker.data_ptr()
+    assert lib.lp_replay_call(ctypes.byref(c), st) < 0
+    torch.cuda.synchronize()
+    assert torch.equal(marker.cpu(), torch.full((4,), 7.0))                 # ... before lp_finalize is reached
