@@ -50,6 +50,11 @@ def _compact_mask(latent_mask, shape, device):
         return bits, LP_FL_MASK_BITS
     u8 = getattr(latent_mask, "_lp_u8", None)
     if u8 is not None and u8.dtype == torch.uint8 and u8.shape == shape and u8.is_contiguous() and u8.device == device:
+        # an attached byte mask is the caller's word that the mask is binary: pack it once (the hot kernels take
+        # fp32 or bits; LP_FL_MASK_U8 only runs through the run-time-everything kernel) and keep the bits on the tensor
+        if latent_mask.is_cuda and latent_mask.dtype == torch.float32 and latent_mask.is_contiguous():
+            pack_mask(latent_mask, check=False)
+            return latent_mask._lp_bits, LP_FL_MASK_BITS
         return u8, LP_FL_MASK_U8
     return None, 0
 
@@ -72,7 +77,9 @@ def pack_mask(latent_mask: torch.Tensor, *, denoise_mask: bool = False, check: b
                                               torch.cuda.current_stream(src.device).cuda_stream), "lp_pack_mask")
     if flag is not None and int(flag.item()):
         raise ValueError("pack_mask: the mask has values other than 0 and 1; soft masks cannot be bit-packed")
-    out = (1 - (src > 0.5).to(torch.float32)) if denoise_mask else src
+    out = (1 - (src > 0.5).to(torch.float32)) if denoise_mask else latent_mask
+    if out.dtype != torch.float32 or not out.is_contiguous():
+        out = src
     out._lp_bits = bits
     return out
 

@@ -422,3 +422,29 @@ def test_replay_call_sequences_the_launches_and_reports_errors(lib):
     assert lib.lp_replay_call(ctypes.byref(c), st) < 0
     torch.cuda.synchronize()
     assert torch.equal(marker.cpu(), torch.full((4,), 7.0))                 # ... before lp_finalize is reached
+
+
+def test_uint8_mask_flag_through_the_c_abi(lib):
+    """LP_FL_MASK_U8 (kept for direct C-ABI users; the engine packs such masks to bits): the run-time kernel gives
+    bitwise the results of the fp32-mask hot kernels, replace and steady step."""
+    import ctypes
+    import torch
+    import bench
+    from lanpaint_amd import _cabi
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for phase in (_cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT, _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT):
+        res = []
+        for fmt in ("f32", "u8"):
+            bench.MASK_FORMAT = fmt
+            try:
+                d, keep, _n = bench.standalone_step(_cabi, "c1_sd15", dev, phase)
+            finally:
+                bench.MASK_FORMAT = "bits"
+            assert bool(d.flags & _cabi.LP_FL_MASK_U8) == (fmt == "u8")
+            _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+            torch.cuda.synchronize()
+            bufs = keep[0]
+            res.append([bufs[k].clone().cpu() for k in ("x_t", "C", "x_in")])
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
