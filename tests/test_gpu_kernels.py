@@ -448,3 +448,36 @@ def test_uint8_mask_flag_through_the_c_abi(lib):
             res.append([bufs[k].clone().cpu() for k in ("x_t", "C", "x_in")])
         for a, b in zip(*res):
             assert torch.equal(a, b)
+
+
+def test_image_encode_decode_nodes_on_the_kernels(lib):
+    """LanPaint_ImageEncode snaps the mask with lp_reshape_mask (== torch's nearest-exact on the GPU, bit for bit);
+    LanPaint_ImageDecode merges with lp_mask_blend (== the oracle's merge_video_with_mask).  Host tensors in and
+    out, as ComfyUI hands them to nodes."""
+    import torch
+    import torch.nn.functional as F
+    from lanpaint_amd import nodes
+    from oracle import lanpaint_oracle as orc
+
+    class VAE:
+        def encode(self, image):
+            b, h, w, _c = image.shape
+            return torch.zeros((b, 4, (h + 7) // 8, (w + 7) // 8))
+
+        def decode(self, z):
+            g = torch.Generator().manual_seed(1)
+            return torch.rand((z.shape[0], z.shape[-2] * 8, z.shape[-1] * 8, 3), generator=g)
+
+    g = torch.Generator().manual_seed(0)
+    image = torch.rand((1, 124, 203, 3), generator=g)
+    mask = (torch.rand((124, 203), generator=g) < 0.4).float()
+    latent, = nodes.LanPaint_ImageEncode().encode(image, VAE(), mask=mask)
+    want = F.interpolate(mask.cuda()[None, None], size=(16, 26), mode="nearest-exact")[0, 0].cpu()
+    assert latent["noise_mask"].device.type == "cpu" and tuple(latent["noise_mask"].shape) == (1, 1, 16, 26)
+    assert torch.equal(latent["noise_mask"][0, 0], want)
+    out, = nodes.LanPaint_ImageDecode().decode(latent, VAE(), image=image, mask=mask, blend_overlap=9)
+    assert out.device.type == "cpu" and tuple(out.shape) == tuple(image.shape)
+    dec = VAE().decode(latent["samples"])
+    dec = F.interpolate(dec.movedim(-1, 1), size=(124, 203), mode="bilinear", align_corners=False).movedim(1, -1)
+    ref = orc.merge_video_with_mask(image.numpy(), dec.numpy(), mask.numpy(), 9)
+    np.testing.assert_allclose(out.numpy(), ref, atol=3e-6)

@@ -72,7 +72,14 @@ def test_retired_params_hidden_and_widgets_kept(nodes):
                  "Inpainting_mode"):
         assert name in req
     assert set(nodes.NODE_CLASS_MAPPINGS) == {"LanPaint_KSampler", "LanPaint_KSamplerAdvanced", "LanPaint_SamplerCustom",
-                                              "LanPaint_SamplerCustomAdvanced", "LanPaint_MaskBlend"}
+                                              "LanPaint_SamplerCustomAdvanced", "LanPaint_MaskBlend",
+                                              "LanPaint_ImageEncode", "LanPaint_ImageDecode"}
+    assert set(nodes.NODE_DISPLAY_NAME_MAPPINGS) == set(nodes.NODE_CLASS_MAPPINGS)
+    enc, dec = nodes.NODE_CLASS_MAPPINGS["LanPaint_ImageEncode"], nodes.NODE_CLASS_MAPPINGS["LanPaint_ImageDecode"]
+    assert enc.FUNCTION == "encode" and enc.RETURN_TYPES == ("LATENT",) and set(enc.INPUT_TYPES()["optional"]) == {"mask"}
+    assert dec.FUNCTION == "decode" and dec.RETURN_TYPES == ("IMAGE",)
+    assert dec.INPUT_TYPES()["optional"]["blend_overlap"][1] == dict(
+        dec.INPUT_TYPES()["optional"]["blend_overlap"][1], default=9, min=1, max=51, step=2)
     mb = nodes.NODE_CLASS_MAPPINGS["LanPaint_MaskBlend"]
     assert mb.FUNCTION == "blend_images" and mb.INPUT_TYPES()["required"]["blend_overlap"][1]["max"] == 51
     assert nodes.LanPaint_KSampler.INPUT_TYPES()["required"]["LanPaint_NumSteps"][1]["default"] == 5
@@ -175,3 +182,36 @@ def test_sampling_function_returns_fused_heads_or_eager_tuple(nodes, monkeypatch
     nodes.sampling_function_LanPaint(None, x, torch.tensor([1.0]), "neg", "pos", 1.0, 1.0,
                                      model_options={"disable_cfg1_optimization": True})
     assert seen["conds"] == ["pos", "neg"]
+
+
+def test_image_encode_decode_nodes_plain_paths_need_no_gpu(nodes):
+    """Without a mask both nodes are a plain VAE call (reference nodes.py:1261-1266, 1323-1330); wrong latent rank
+    raises like the reference."""
+    import pytest
+    import torch
+
+    class VAE:
+        def __init__(self, rank=4):
+            self.rank = rank
+
+        def encode(self, image):
+            b, h, w, _c = image.shape
+            z = torch.zeros((b, 4, h // 8, w // 8))
+            return z if self.rank == 4 else (z.unsqueeze(2) if self.rank == 5 else z[0])
+
+        def decode(self, z):
+            return torch.ones((z.shape[0], z.shape[-2] * 8, z.shape[-1] * 8, 3))
+
+    img = torch.rand(1, 64, 48, 3)
+    latent, = nodes.LanPaint_ImageEncode().encode(img, VAE())
+    assert set(latent) == {"samples"} and tuple(latent["samples"].shape) == (1, 4, 8, 6)
+    with pytest.raises(ValueError, match="4D or 5D"):
+        nodes.LanPaint_ImageEncode().encode(img, VAE(rank=3))
+    same, = nodes.LanPaint_ImageEncode().encode(img, VAE(), mask=torch.ones(8, 6))      # already at the latent size
+    assert tuple(same["noise_mask"].shape) == (1, 1, 8, 6)
+    vid, = nodes.LanPaint_ImageEncode().encode(img, VAE(rank=5), mask=torch.ones(1, 8, 6))
+    assert tuple(vid["noise_mask"].shape) == (1, 1, 1, 8, 6)
+    out, = nodes.LanPaint_ImageDecode().decode(latent, VAE())
+    assert tuple(out.shape) == (1, 64, 48, 3)
+    resized, = nodes.LanPaint_ImageDecode().decode(latent, VAE(), image=torch.rand(1, 60, 50, 3))
+    assert tuple(resized.shape) == (1, 60, 50, 3)
