@@ -589,7 +589,9 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=0.3,
                     help="untimed set-up (graph capture, lazy init, clock ramp) before the warm-up steps")
     ap.add_argument("--workload", default="c2_sdxl", choices=sorted(WORKLOADS))
-    ap.add_argument("--rng", default="philox", choices=["philox", "torch"])
+    ap.add_argument("--rng", default="philox", choices=["philox", "torch", "torch-eager"],
+                    help="philox: independent in-kernel stream; torch: the device generator's randn stream reproduced "
+                         "inside the kernel (the engine's default); torch-eager: torch.randn_like tensors, one launch per draw")
     ap.add_argument("--graph", type=int, default=1, help="1: replay each sigma call as one hipGraph (default); 0: eager launches")
     ap.add_argument("--mask-format", default="bits", choices=["bits", "u8", "f32"],
                     help="how the (binary) latent mask is streamed by the kernels: bit-packed once per job by "

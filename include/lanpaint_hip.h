@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 7
+#define LP_ABI_VERSION 8
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -117,6 +117,10 @@ typedef struct lp_hyper {
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 
+/* in-kernel noise generators */
+#define LP_RNG_PHILOX 0   /* Philox2x32-10 per element, one Box-Muller pair per launch (independent stream)  */
+#define LP_RNG_TORCH  1   /* the device's torch.randn stream, reproduced exactly                             */
+
 /* replace-step source (lanpaint.py:84-94) */
 #define LP_REPLACE_KNOWN    0   /* `known` = model_sampling.noise_scaling(...) computed by the caller */
 #define LP_REPLACE_VE       1   /* y + n*sigma                                                        */
@@ -152,8 +156,10 @@ typedef struct lp_step_desc {
     const float* xi_post;      /* host-supplied N(0,1) for POST_* (NULL => Philox)        */
     const float* xi_pre;       /* host-supplied N(0,1) for PRE_HALF (NULL => Philox)      */
     uint64_t     rng_seed;     /* Philox key                                              */
-    uint64_t     rng_offset;   /* Philox launch sequence number (unique per launch)       */
-    const uint64_t* rng_offset_ptr; /* optional device u64 added to rng_offset (graph replay) */
+    uint64_t     rng_offset;   /* LP_RNG_PHILOX: launch sequence number (unique per launch);
+                                  LP_RNG_TORCH: torch philox offset of this launch's first draw */
+    const uint64_t* rng_offset_ptr; /* optional device u64[2] (graph replay): [0] is added to rng_offset;
+                                  LP_RNG_TORCH also takes the seed from [1]              */
     const float* abt_el;       /* LP_FL_PER_ELEMENT: per-element abt                      */
     const float* ve_el;        /*                    per-element VE sigma                 */
     const float* rsig_el;      /*                    per-element replace sigma            */
@@ -165,6 +171,19 @@ typedef struct lp_step_desc {
     const float* t_model;      /* [rows] backbone time argument -> slot LP_C_TMODEL       */
     float*       coef_out;     /* [rows][LP_COEF_STRIDE]                                  */
     int32_t      t_ve_stride, t_abt_stride, t_rsig_stride, t_model_stride;   /* 0 = broadcast row 0 */
+    /* In-kernel noise generator (xi_post / xi_pre NULL).  LP_RNG_TORCH reproduces, bit for bit, the values
+     * `torch.randn_like(x_t)` would return on this device for generator state (rng_seed, offset): ATen's
+     * Philox4x32-10 thread / offset mapping (DistributionTemplates.h) over rocRAND's own normal4.  Draw order
+     * inside one launch: the POST draw, then the PRE draw (offset + rng_inc) -- the reference's order
+     * (lanpaint.py:277,280,283).  rng_bg = block * grid of ATen's launch for n_el elements, rng_inc = the
+     * generator-offset increment of one such call.                                                        */
+    int32_t      rng_kind;     /* LP_RNG_PHILOX (0) | LP_RNG_TORCH (1)                     */
+    uint32_t     rng_bg;
+    uint32_t     rng_inc;
+    /* LP_PH_COEFFS launches of a replayed graph publish the caller's generator state for the captured launches:
+     * rng_state_out[0] = rng_state_val[0] (offset base), [1] = rng_state_val[1] (seed); NULL = nothing.      */
+    uint64_t*    rng_state_out;
+    uint64_t     rng_state_val[2];
 } lp_step_desc;
 
 typedef struct lp_final_desc {
@@ -257,6 +276,9 @@ int lp_finalize(const lp_final_desc* desc, void* stream);
  * block per latent element keyed on (seed, element, launch offset), Box-Muller; slot 0 =
  * cosine branch (POST stream), 1 = sine branch (PRE stream).  Lets tests reproduce the
  * in-kernel noise exactly.  Replaces torch.randn_like (lanpaint.py:252).               */
+/* Fill `out` with what torch.randn(n_el, device=...) returns for generator state (seed, offset) on this device
+ * (test hook for LP_RNG_TORCH; bg as in lp_step_desc.rng_bg).                                            */
+int lp_torch_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t bg, void* stream);
 int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream);
 
 /* K4  inner early-stop metric (earlystop.py:32-55).

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -34,6 +34,7 @@ def mask_bits_bytes(n_el: int) -> int:
     """LP_MASK_BITS_BYTES of the header."""
     return ((int(n_el) + 63) // 64) * 8
 LP_REPLACE_KNOWN, LP_REPLACE_VE, LP_REPLACE_FLOW = 0, 1, 2
+LP_RNG_PHILOX, LP_RNG_TORCH = 0, 1
 
 
 class LpHyper(C.Structure):
@@ -55,6 +56,8 @@ class LpStepDesc(C.Structure):
         ("t_ve", C.c_void_p), ("t_abt", C.c_void_p), ("t_rsig", C.c_void_p), ("t_model", C.c_void_p),
         ("coef_out", C.c_void_p), ("t_ve_stride", C.c_int32), ("t_abt_stride", C.c_int32),
         ("t_rsig_stride", C.c_int32), ("t_model_stride", C.c_int32),
+        ("rng_kind", C.c_int32), ("rng_bg", C.c_uint32), ("rng_inc", C.c_uint32),
+        ("rng_state_out", C.c_void_p), ("rng_state_val", C.c_uint64 * 2),
     ]
 
 
@@ -103,6 +106,7 @@ EXPORTS = {
     "lp_step_timed": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.c_void_p]),
     "lp_step_timed_burst": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.POINTER(C.c_void_p), C.c_int32]),
     "lp_timer_elapsed_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "lp_torch_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "lp_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "lp_boundary_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "lp_wmse_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

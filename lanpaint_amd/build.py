@@ -35,7 +35,10 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -ffp-contract=on: a*b+c fuses only inside one source expression (never across statements).  Needed for
+    # LP_RNG_TORCH to reproduce torch.randn bit for bit (csrc/lp_common.h); it also makes the arithmetic of every
+    # kernel independent of what the optimiser happens to fuse.
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:

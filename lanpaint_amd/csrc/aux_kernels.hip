@@ -396,4 +396,22 @@ int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bi
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------
+// LP_RNG_TORCH test hook: the whole torch.randn(n) tensor from the per-element function the step kernel uses
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lp_torch_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                              uint64_t offset, uint32_t bg) {
+    const int64_t li = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (li < n) out[li] = torch_normal(static_cast<uint64_t>(li), seed, offset, bg);
+}
+
+int torch_normal_dispatch(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t bg, hipStream_t stream) {
+    if (!out || n <= 0 || bg == 0 || (offset & 3ull)) return LP_E_INVALID;
+    const int64_t bx = (n + 255) / 256;
+    if (bx > 0x7fffffff) return LP_E_INVALID;
+    hipLaunchKernelGGL(lp_torch_normal_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, out, n, seed, offset,
+                       bg);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
 }  // namespace lp

@@ -19,6 +19,7 @@ int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, ui
 int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream);
 int wmse_dispatch(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
                   double* scratch, int scratch_blocks, hipStream_t stream);
+int torch_normal_dispatch(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t bg, hipStream_t stream);
 int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, hipStream_t stream);
 int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int sw, float* dst, int db, int dc, int df,
                           int dh, int dw, int taps, int binarize, hipStream_t stream);
@@ -104,6 +105,10 @@ int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* tim
         if (rc != LP_OK) return rc;
     }
     return LP_OK;
+}
+
+int lp_torch_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t bg, void* stream) {
+    return lp::torch_normal_dispatch(out, n_el, seed, offset, bg, as_stream(stream));
 }
 
 int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream) {

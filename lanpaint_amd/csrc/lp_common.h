@@ -4,6 +4,12 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+// rocRAND's device code is what torch's own kernels inline for torch.randn (LP_RNG_TORCH).  The library is built
+// with -ffp-contract=on (lanpaint_amd/build.py): torch's build contracts a*b+c only inside one expression, and
+// under hipcc's default "fast" the Box-Muller results differ in the last bit in ~15 % of the draws -- measured on
+// the MI355X against torch.randn, 0 mismatches with "on" (a file-scope pragma around this include is not enough).
+#include <rocrand/rocrand_kernel.h>
+
 #include "lanpaint_hip.h"
 
 namespace lp {
@@ -49,6 +55,25 @@ __device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_
     const float t = u01(c1);
     z_post = r * __builtin_amdgcn_cosf(t);
     z_pre = r * __builtin_amdgcn_sinf(t);
+}
+
+// ---- LP_RNG_TORCH: the value torch.randn_like(t).view(-1)[li] takes for generator state (seed, offset) ------
+// ATen (native/cuda/DistributionTemplates.h, distribution_elementwise_grid_stride_kernel with unroll 4): thread
+// idx = li % bg initialises Philox4x32-10 with (seed, subsequence = idx, offset), its k-th normal4 call serves
+// the elements li = idx + bg * (4 k + ii), ii = 0..3, and normal_() stores rand * std + mean with std 1, mean 0.
+__device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64_t offset, uint32_t bg) {
+#pragma clang fp contract(on)
+    const uint32_t idx = static_cast<uint32_t>(li % bg);
+    const uint64_t q = li / bg;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, idx, offset + 4ull * (q >> 2), &st);
+    const uint4 c = rocrand4(&st);
+    // rocrand_normal4 = Box-Muller on (c.x, c.y) and on (c.z, c.w); only the pair this element's value comes
+    // from is transformed (the other three values belong to elements bg, 2 bg, 3 bg away)
+    const uint32_t ii = static_cast<uint32_t>(q) & 3u;
+    const float2 r = rocrand_device::detail::box_muller(ii < 2 ? c.x : c.z, ii < 2 ? c.y : c.w);
+    const float v = (ii & 1u) ? r.y : r.x;
+    return v * 1.0f + 0.0f;
 }
 
 // ---- 16/32-bit float conversions ----------------------------------------------

@@ -125,7 +125,9 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // has to put an s_waitcnt vmcnt(0) at their join -- ahead of the remaining loads -- so the hot phase
 // combinations are instantiated per width; likewise they only take fp32 (MODE_ROW) or bit-packed (MODE_HARD)
 // masks, a uint8 mask goes through the PH = 0 kernel.
-template <int VEC, int MODE, uint32_t PH, int X0W>
+// RNG: in-kernel generator fixed at compile time in the hot variants (0 = Philox2x32 pair, 1 = torch's randn
+// stream reproduced exactly) or 2 = read d.rng_kind at run time.
+template <int VEC, int MODE, uint32_t PH, int X0W, int RNG>
 __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     constexpr bool PER_EL = MODE == MODE_PER_EL;
     constexpr bool HARD = MODE == MODE_HARD;
@@ -160,6 +162,10 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             const float step = d.step_size * fmaxf(1.0f - abt_f, d.min_step_frac);                 // lanpaint.py:81
             coeffs_lane(h, abt_f, ve_f, rs_f, tm_f, step, (threadIdx.x >> 1) & 1, threadIdx.x & 1,
                         d.coef_out + static_cast<int64_t>(row) * LP_COEF_STRIDE);
+            if (row == 0 && threadIdx.x == 0 && d.rng_state_out) {     // generator state for the replayed launches
+                d.rng_state_out[0] = d.rng_state_val[0];
+                d.rng_state_out[1] = d.rng_state_val[1];
+            }
         }
     } else {
         if constexpr (!PER_EL) rc = load_row(d.coef, row);
@@ -211,14 +217,29 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 
         // ---- Philox + Box-Muller while the loads are in flight ----------------------------
         if (need_rng) {
-            uint64_t seq = d.rng_offset;
-            if (d.rng_offset_ptr) seq += *d.rng_offset_ptr;      // device-side counter of a replayed graph
+            const bool torch_kind = RNG == 2 ? (d.rng_kind == LP_RNG_TORCH) : (RNG == 1);
+            uint64_t seq = d.rng_offset, seed = d.rng_seed;
+            if (d.rng_offset_ptr) {                              // device-side state of a replayed graph
+                seq += d.rng_offset_ptr[0];
+                if (torch_kind) seed = d.rng_offset_ptr[1];
+            }
+            if (torch_kind) {
+                // torch.randn_like(x_t) twice, in the reference's order: the POST draw, then the PRE draw
+                const bool draw_post = post && !host_post, draw_pre = (ph & LP_PH_PRE_HALF) && !host_pre;
+                const uint64_t off_pre = seq + (draw_post ? d.rng_inc : 0u);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                float za, zb;
-                normal_pair(static_cast<uint64_t>(i + k), seq, d.rng_seed, za, zb);
-                if (!host_post) xi_a[k] = za;
-                if (!host_pre) xi_b[k] = zb;
+                for (int k = 0; k < VEC; ++k) {
+                    if (draw_post) xi_a[k] = torch_normal(static_cast<uint64_t>(i + k), seed, seq, d.rng_bg);
+                    if (draw_pre) xi_b[k] = torch_normal(static_cast<uint64_t>(i + k), seed, off_pre, d.rng_bg);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float za, zb;
+                    normal_pair(static_cast<uint64_t>(i + k), seq, seed, za, zb);
+                    if (!host_post) xi_a[k] = za;
+                    if (!host_pre) xi_b[k] = zb;
+                }
             }
         }
 
@@ -399,7 +420,7 @@ static const Tune& tune() {
     return t;
 }
 
-template <int VEC, int MODE, uint32_t PH, int X0W = 0>
+template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     const Tune& t = tune();
     const int64_t groups = d.el_per_row / VEC;
@@ -412,10 +433,10 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     if (bx > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
     if (timer) {
-        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W>), grid, dim3(block), 0, stream, timer->start,
+        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG>), grid, dim3(block), 0, stream, timer->start,
                               timer->stop, 0, d);
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W>), grid, dim3(block), 0, stream, d);
+        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG>), grid, dim3(block), 0, stream, d);
     }
     return hipGetLastError();
 }
@@ -434,7 +455,10 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     if (d.phases == (R | E | LP_PH_COEFFS))                                          // ... + the coefficient table
         return hard ? launch<VEC, MODE_HARD, R | E | LP_PH_COEFFS>(d, stream, timer)
                     : launch<VEC, MODE_ROW, R | E | LP_PH_COEFFS>(d, stream, timer);
-#define LP_HOT(MODE_, PH_) (x0_half ? launch<VEC, MODE_, PH_, 2>(d, stream, timer) : launch<VEC, MODE_, PH_, 4>(d, stream, timer))
+    const bool rng_torch = d.rng_kind == LP_RNG_TORCH;
+#define LP_HOT(MODE_, PH_)                                                                                   \
+    (x0_half ? (rng_torch ? launch<VEC, MODE_, PH_, 2, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 2, 0>(d, stream, timer)) \
+             : (rng_torch ? launch<VEC, MODE_, PH_, 4, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 4, 0>(d, stream, timer)))
     if (hard) {
         switch (d.phases) {
             case S | P | E: return LP_HOT(MODE_HARD, S | P | E);   // steady state
@@ -467,6 +491,8 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
         return LP_E_INVALID;
     const uint32_t ph = d.phases;
     if (ph == 0 || (ph & ~0x3fu)) return LP_E_INVALID;
+    if (d.rng_kind != LP_RNG_PHILOX && d.rng_kind != LP_RNG_TORCH) return LP_E_INVALID;
+    if (d.rng_kind == LP_RNG_TORCH && (d.rng_bg == 0 || (d.rng_inc & 3u) || d.rng_inc == 0)) return LP_E_INVALID;
     if (ph & LP_PH_COEFFS) {       // only as the fused replace launch of a row-table call
         if (ph != (LP_PH_REPLACE | LP_PH_EMIT | LP_PH_COEFFS) || (d.flags & LP_FL_PER_ELEMENT)) return LP_E_INVALID;
         if (!d.t_abt || !d.coef_out || (!(d.flags & LP_FL_FLOW) && !d.t_ve)) return LP_E_INVALID;

@@ -185,8 +185,10 @@ class LanPaint:
         self.early_stop_hook = EarlyStopHook
 
         self.rng = rng if rng is not None else os.environ.get("LANPAINT_AMD_RNG", "torch")
-        if not callable(self.rng) and self.rng not in ("torch", "philox"):
-            raise ValueError(f"rng must be 'torch', 'philox' or a callable, got {self.rng!r}")
+        if not callable(self.rng) and self.rng not in ("torch", "torch-eager", "philox"):
+            raise ValueError(f"rng must be 'torch', 'torch-eager', 'philox' or a callable, got {self.rng!r}")
+        self._torch_consumed = 0                 # generator offset this engine advanced itself (LP_RNG_TORCH)
+        self._graph_blocked = False              # the backbone draws from torch's generator inside the loop
         self.philox_seed = philox_seed
         self._philox_offset = 0
         self.graph = bool(int(os.environ.get("LANPAINT_AMD_GRAPH", "0"))) if graph is None else bool(graph)
@@ -294,8 +296,30 @@ class LanPaint:
         when the kernel generates it (Philox)."""
         if self.rng == "philox":
             return None
-        xi = torch.randn_like(like) if self.rng == "torch" else self.rng(like)
+        xi = self.rng(like) if callable(self.rng) else torch.randn_like(like)
         return _as_f32c(xi)
+
+    # ---- rng="torch": the device generator's randn stream, produced inside the step kernel -------------------
+    @staticmethod
+    def _generator(device):
+        torch.cuda.init()
+        return torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+
+    _policy_cache = {}
+
+    @classmethod
+    def _randn_policy(cls, device, numel):
+        """(block * grid, generator-offset increment) of ATen's launch for one randn of `numel` fp32 elements
+        (calc_execution_policy in native/cuda/DistributionTemplates.h: 256-thread blocks, grid capped at
+        SMs * (maxThreadsPerSM / 256), unroll 4)."""
+        key = (device.index, numel)
+        hit = cls._policy_cache.get(key)
+        if hit is None:
+            p = torch.cuda.get_device_properties(device)
+            grid = min(p.multi_processor_count * (p.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+            bg = 256 * grid
+            hit = cls._policy_cache[key] = (bg, ((numel - 1) // (bg * 4) + 1) * 4)
+        return hit
 
     def _fill_hyper(self, flow):
         h = self._hyper
@@ -405,7 +429,7 @@ class LanPaint:
                 self._overridden("prepare_step_size"), self.IS_FLUX, self.IS_FLOW, self.model_dtype)
 
     def _graph_eligible(self, x, model_options, sigma, current_times):
-        if not self.graph or callable(self.rng) or self._noise_regenerated:
+        if not self.graph or self._graph_blocked or callable(self.rng) or self._noise_regenerated:
             return False         # (regenerated noise is a fresh tensor per call: nothing stable to bake into a graph)
         rows = x.shape[0] if x.ndim else 1
         if any(t.numel() not in (1, rows) for t in (sigma, *current_times)):
@@ -434,6 +458,8 @@ class LanPaint:
         cap = self._graphs.get(key)
         if cap is None:
             cap = self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+            if cap is None:          # not capturable after all (see _capture): the eager path
+                return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
             while len(self._graphs) > self.MAX_GRAPHS:       # bound the static memory held by stale captures
                 self._graphs.popitem(last=False)
         else:
@@ -452,6 +478,10 @@ class LanPaint:
         self._last_cap = None
         st = self._prologue(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=cap.ws)
         cap.graph.replay()
+        if self.rng == "torch":        # the replayed launches consumed this much of the generator's stream
+            gen = self._generator(x.device)
+            gen.set_offset(gen.get_offset() + cap.launches)
+            self._torch_consumed += cap.launches
         return self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None)
 
     def _replay_fast(self, cap, x, sigma, current_times):
@@ -467,6 +497,12 @@ class LanPaint:
         # the replace launch also rebuilds the coefficient table from this call's sigma / times (LP_PH_COEFFS)
         k0.t_ve, k0.t_abt, k0.t_rsig, k0.t_model = ve.data_ptr(), abt.data_ptr(), sigma.data_ptr(), t_src.data_ptr()
         f.x_dst, f.out = k0.x, out.data_ptr()
+        if self.rng == "torch":        # generator state in (published by the replace launch), state out
+            gen = self._generator(x.device)
+            off = gen.get_offset()
+            k0.rng_state_val[0], k0.rng_state_val[1] = off, gen.initial_seed()
+            gen.set_offset(off + cap.launches)
+            self._torch_consumed += cap.launches
         if cap.raw_exec is not None:
             _cabi.check(lib.lp_replay_call(ctypes.byref(cap.call), stream), "lp_replay_call")
             return out
@@ -475,17 +511,26 @@ class LanPaint:
         _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
         return out
 
+    def _rng_state(self, dev):
+        """Device u64[2] read by captured launches.  rng="philox": [0] = launch-sequence base, ONE per device and
+        bumped by every replay so the streams of different captures never overlap.  rng="torch": (generator
+        offset, seed) published by the replace launch of each call."""
+        state = self._rng_counters.get(dev)
+        if state is None:
+            state = self._rng_counters[dev] = torch.zeros(2, dtype=torch.int64, device=dev)
+        return state
+
     def _capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
         dev = x.device
-        counter = self._rng_counters.get(dev)      # ONE Philox launch-sequence base per device, shared by
-        if counter is None:                        # every captured call so their streams never overlap
-            counter = self._rng_counters[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+        counter = self._rng_state(dev)
         cap = _CapturedCall(counter)
         cap.ws = _Workspace(x.detach().to(torch.float32).contiguous(), static_io=True, model_dtype=self.model_dtype)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         it0 = self.iterations_run
         rng_state = torch.cuda.get_rng_state(dev)   # warm-up + capture must not consume the user's torch stream
+        gen = self._generator(dev)
+        off0, own0 = gen.get_offset(), self._torch_consumed
         with torch.cuda.stream(side):              # one complete eager call on the side stream: lazy inits
             xw = x.detach().clone()
             st = self._prologue(xw, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
@@ -497,7 +542,14 @@ class LanPaint:
         torch.cuda.synchronize(dev)
         # did the warm-up (backbone included) draw from torch's generator?  Then only torch's own replay() keeps
         # the captured Philox offsets moving and the graph must not be launched behind its back.
-        torch_rng_used = not torch.equal(torch.cuda.get_rng_state(dev), rng_state)
+        torch_rng_used = (gen.get_offset() - off0) != (self._torch_consumed - own0)
+        if torch_rng_used and self.rng == "torch":
+            # the engine's in-kernel draws and the backbone's own draws would have to interleave inside the graph
+            # exactly as they do eagerly: not representable with one published offset -> this engine stays eager
+            torch.cuda.set_rng_state(rng_state, dev)
+            self.iterations_run = it0
+            self._graph_blocked = True
+            return None
         self.iterations_run = it0
         self._capturing, self._cap_offset = counter, 0
         try:
@@ -523,7 +575,7 @@ class LanPaint:
         cap.f_desc = f
         cap.fast = bool(dense_ok and st.k0_desc is not None and st.replace_kind_static and st.xc is st.input_x)
         if cap.fast:
-            if self.rng == "philox" and not torch_rng_used and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0":
+            if self.rng in ("philox", "torch") and not torch_rng_used and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0":
                 try:
                     cap.raw_exec = int(cap.graph.raw_cuda_graph_exec()) or None
                 except Exception:
@@ -663,6 +715,12 @@ class LanPaint:
         d.xi_post = d.xi_pre = None
         d.rng_offset_ptr = None
         d.rng_seed = int(self.philox_seed if self.philox_seed is not None else (seed or 0)) & 0xFFFFFFFFFFFFFFFF
+        d.rng_state_out = None
+        if ws.static_io and self.rng == "torch" and not per_el:
+            # a replayed loop takes its offsets relative to the generator state this launch publishes
+            gen = self._generator(xc.device)
+            d.rng_state_out = self._rng_state(xc.device).data_ptr()
+            d.rng_state_val[0], d.rng_state_val[1] = gen.get_offset(), gen.initial_seed()
         d.flags = base_flags | self._emit(st, n_steps == 0)
         d.phases = LP_PH_REPLACE | LP_PH_EMIT | (0 if per_el else _cabi.LP_PH_COEFFS)
         self._launch_step(stream)
@@ -766,12 +824,31 @@ class LanPaint:
         PRE half-step of iteration i+1 (lanpaint.py:277,280,283)."""
         if self.rng == "philox":
             d.xi_post = d.xi_pre = None
+            d.rng_kind = _cabi.LP_RNG_PHILOX
             if self._capturing is not None:      # replayed launches: base comes from the device counter
                 d.rng_offset, d.rng_offset_ptr = self._cap_offset, self._capturing.data_ptr()
                 self._cap_offset += 1
             else:
                 d.rng_offset, d.rng_offset_ptr = (1 << 48) + self._philox_offset, None   # disjoint from replayed ones
                 self._philox_offset += 1
+            self._xi_alive = None
+            return
+        if self.rng == "torch":
+            # the values torch.randn_like(x_t) would return, generated inside the kernel: same generator state in,
+            # same values, same state out (the generator's offset is advanced by what the draws consume)
+            d.xi_post = d.xi_pre = None
+            d.rng_kind = _cabi.LP_RNG_TORCH
+            d.rng_bg, d.rng_inc = self._randn_policy(like.device, like.numel())
+            used = (int(bool(want_post)) + int(bool(want_pre))) * d.rng_inc
+            if self._capturing is not None:      # replayed launches: offsets relative to the state the replace publishes
+                d.rng_offset, d.rng_offset_ptr = self._cap_offset, self._capturing.data_ptr()
+                self._cap_offset += used
+            else:
+                gen = self._generator(like.device)
+                off = gen.get_offset()
+                d.rng_seed, d.rng_offset, d.rng_offset_ptr = gen.initial_seed(), off, None
+                gen.set_offset(off + used)
+                self._torch_consumed += used
             self._xi_alive = None
             return
         xa = self._draw(like) if want_post else None

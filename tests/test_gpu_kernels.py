@@ -481,3 +481,32 @@ def test_image_encode_decode_nodes_on_the_kernels(lib):
     dec = F.interpolate(dec.movedim(-1, 1), size=(124, 203), mode="bilinear", align_corners=False).movedim(1, -1)
     ref = orc.merge_video_with_mask(image.numpy(), dec.numpy(), mask.numpy(), 9)
     np.testing.assert_allclose(out.numpy(), ref, atol=3e-6)
+
+
+@pytest.mark.parametrize("n", [1, 5, 255, 256, 257, 1000, 4 * 128 * 128, 16 * 21 * 60 * 104, 4 * 16 * 21 * 60 * 104 + 3])
+def test_torch_normal_reproduces_torch_randn_bit_for_bit(lib, n):
+    """LP_RNG_TORCH's per-element generator == torch.randn on this device: same (seed, offset) in, the same bits out,
+    and the generator-offset increment the engine books per draw == what torch itself consumes."""
+    import torch
+    from lanpaint_amd import LanPaint
+    dev = torch.device("cuda", 0)
+    gen = LanPaint._generator(dev)
+    bg, inc = LanPaint._randn_policy(dev, n)
+    torch.manual_seed(4321 + n)
+    st = torch.cuda.current_stream().cuda_stream
+    for _rep in range(3):                       # consecutive draws: the offset moves on
+        seed, off = gen.initial_seed(), gen.get_offset()
+        ref = torch.randn(n, device=dev)
+        assert gen.get_offset() - off == inc
+        out = torch.empty(n, device=dev)
+        _cabi_check = __import__("lanpaint_amd")._cabi.check
+        _cabi_check(lib.lp_torch_normal(out.data_ptr(), n, seed, off, bg, st), "lp_torch_normal")
+        assert torch.equal(out, ref)
+    x = torch.zeros((2, 3, 5, 7), device=dev)
+    seed, off = gen.initial_seed(), gen.get_offset()
+    ref = torch.randn_like(x)
+    out = torch.empty_like(x)
+    bg, _ = LanPaint._randn_policy(dev, x.numel())
+    assert lib.lp_torch_normal(out.data_ptr(), x.numel(), seed, off, bg, st) == 0
+    assert torch.equal(out, ref)
+    assert lib.lp_torch_normal(out.data_ptr(), x.numel(), seed, off + 1, bg, st) < 0      # offsets come in fours

@@ -459,3 +459,72 @@ def test_kernel_instantiation_matrix_is_consistent(shape, flow):
     for dtype, tol in ((torch.bfloat16, 6e-2), (torch.float16, 8e-3)):
         for fused in (False, True):
             assert float((ref[(dtype, fused)][0] - f32[0]).abs().max()) <= tol * scale, (dtype, fused)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 24, 20), (2, 4, 258, 262)], ids=["vec1", "vec4"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "early_stop"])
+def test_in_kernel_torch_stream_equals_randn_like_tensors(shape, mode):
+    """rng="torch" generates the reference's noise (torch.randn_like(x_t), POST draw then PRE draw) inside the step
+    kernel.  Against rng="torch-eager" (the same draws as explicit tensors): bitwise the same x / out over several
+    sigma calls, and the device generator ends in the same state -- so whatever draws from it next (an ancestral
+    sampler's noise) is unchanged too."""
+    import torch
+    from lanpaint_amd import LanPaint
+    torch.manual_seed(0)
+    y = torch.randn(shape, device="cuda")
+    noise = torch.randn(shape, device="cuda")
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    sigmas = [torch.tensor([3.0, 2.0], device="cuda"), torch.tensor([1.2, 0.8], device="cuda"),
+              torch.tensor([0.5, 0.3], device="cuda")]
+    kw = dict(graph=True) if mode == "graph" else dict(EarlyStopThreshold=1e-7, EarlyStopPatience=1) if mode == "early_stop" else {}
+    res = {}
+    for rng in ("torch-eager", "torch"):
+        eng = LanPaint(MODELS["linear_tuple"](flow=False), 4, 15.0, 5.0, 1.0, 0.2, rng=rng, **kw)
+        torch.manual_seed(77)
+        x = (y + noise * 3.0).clone()
+        outs = []
+        for rep in range(2):                    # second pass: replays (graph mode), generator keeps moving
+            for sig in sigmas:
+                abt = 1 / (1 + sig ** 2)
+                times = (sig.clone(), abt, torch.sqrt(1 - abt) / (torch.sqrt(1 - abt) + torch.sqrt(abt)))
+                out = eng(x, y, noise, sig, mask, times, {}, 0)
+                between = torch.randn(3, device="cuda")          # somebody else draws between the calls
+                outs.append((x.clone(), out.clone(), between))
+        res[rng] = (outs, torch.cuda.default_generators[0].get_offset(), eng.iterations_run)
+    a, b = res["torch-eager"], res["torch"]
+    assert a[1] == b[1] and a[2] == b[2]
+    for (xa, oa, ba), (xb, ob, bb) in zip(a[0], b[0]):
+        assert torch.equal(xa, xb) and torch.equal(oa, ob) and torch.equal(ba, bb)
+
+
+def test_in_kernel_torch_stream_steps_aside_when_the_backbone_draws_inside_the_graph():
+    """A backbone that consumes torch's generator inside the loop cannot be replayed with one published offset:
+    the engine stays eager for it (and still matches the explicit-tensor path bit for bit)."""
+    import torch
+    from lanpaint_amd import LanPaint
+    base = MODELS["linear_tuple"]
+
+    class Noisy(base):
+        def __call__(self, x, t, model_options=None, seed=None):
+            a, b = super().__call__(x, t)
+            return a + 1e-3 * torch.randn_like(a), b
+
+    shape = (1, 4, 16, 16)
+    torch.manual_seed(0)
+    y, noise = torch.randn(shape, device="cuda"), torch.randn(shape, device="cuda")
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    sig = torch.tensor([2.0], device="cuda")
+    abt = 1 / (1 + sig ** 2)
+    times = (sig.clone(), abt, torch.sqrt(1 - abt) / (torch.sqrt(1 - abt) + torch.sqrt(abt)))
+    res = []
+    for rng, graph in (("torch-eager", False), ("torch", True)):
+        eng = LanPaint(Noisy(flow=False), 3, 15.0, 5.0, 1.0, 0.2, rng=rng, graph=graph)
+        torch.manual_seed(5)
+        x = (y + noise * 2.0).clone()
+        outs = [eng(x, y, noise, sig, mask, times, {}, 0).clone() for _ in range(3)]
+        res.append((x.clone(), outs, torch.cuda.default_generators[0].get_offset()))
+        if graph:
+            assert eng._graph_blocked and not eng._graphs
+    assert torch.equal(res[0][0], res[1][0]) and res[0][2] == res[1][2]
+    for u, v in zip(res[0][1], res[1][1]):
+        assert torch.equal(u, v)
