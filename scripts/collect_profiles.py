@@ -19,7 +19,7 @@ N_EL = {"c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c5": ("c5_wan",
 def steady_mean(path):
     """mean-per-dispatch (KB) of the steady lp_step kernel (PH = 28) in a --pmc summary."""
     for line in open(path):
-        m = re.match(r"\| `lp::lp_step_kernel<(\d), \w+, 28u(?:, \d)?>.*?` \| (\w+) \| (\d+) \| ([0-9.]+) \|", line)
+        m = re.match(r"\| `lp::lp_step_kernel<(\d), \w+, 28u(?:, \d)*>.*?` \| (\w+) \| (\d+) \| ([0-9.]+) \|", line)
         if m:
             return int(m.group(1)), float(m.group(4)), int(m.group(3))
     return None
@@ -46,7 +46,7 @@ def main():
         if not fe or not wr:
             continue
         tb = int(round((2 * fe[1] + wr[1]) * 1024))
-        traffic[wl] = {"kernel": f"lp::lp_step_kernel<VEC={fe[0]},MODE_HARD,POST_STEADY|PRE_HALF|EMIT,X0W=4>", "FETCH_SIZE_KB": fe[1], "WRITE_SIZE_KB": wr[1],
+        traffic[wl] = {"kernel": f"lp::lp_step_kernel<VEC={fe[0]},MODE_HARD,POST_STEADY|PRE_HALF|EMIT,X0W=4,RNG=philox>", "FETCH_SIZE_KB": fe[1], "WRITE_SIZE_KB": wr[1],
                        "dispatches": fe[2], "traffic_bytes_per_launch": tb, "algorithmic_bytes_per_launch": 36 * n_el,
                        "traffic_over_algorithmic": round(tb / (36 * n_el), 4)}
     json.dump(traffic, open(os.path.join(DST, f"r{rnd}_pmc_traffic.json"), "w"), indent=1)
