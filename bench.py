@@ -476,6 +476,33 @@ def extra_lines(args, dev):
     from lanpaint_amd import nodes as lpn
     out = {}
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    # ---- the headline workload with the engine's DEFAULT noise source (rng="torch": the reference's own
+    # torch.randn_like stream, generated inside the kernel) when the headline ran with another one
+    if args.rng != "torch":
+        try:
+            shape, flow, n_sig, n_think = WORKLOADS[args.workload]
+            sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
+            x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed, dev, tt)
+            mask = attach_mask_format(mask, args.mask_format)
+            sig_list = [torch.full((shape[0],), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+            times_list = [times_from_sigma(s, flow) for s in sig_list]
+            ratios = euler_ratios(sig_list, len(shape))
+            eng = LanPaint(StubBackbone(flow), n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
+                           IS_FLOW=flow, rng="torch", graph=bool(args.graph))
+            for _ in range(5):
+                schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+            torch.cuda.synchronize()
+            it0, t0, reps = eng.iterations_run, time.perf_counter(), max(5, args.steps // 2)
+            for _ in range(reps):
+                schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["reference_noise_stream"] = {
+                "value": (eng.iterations_run - it0) / dt, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
+                "note": f"{args.workload} as in the headline but rng='torch' (the engine default): the values "
+                        "torch.randn_like(x_t) returns for the device generator, bit for bit, generated in-kernel"}
+        except Exception as e:
+            out["reference_noise_stream"] = {"error": repr(e)}
     # ---- node-default schedule through the sampler-facing callable
     shape, flow, n_sig, n_think = WORKLOADS["c2_sdxl"]
     sig_np = karras_sigmas(n_sig)
