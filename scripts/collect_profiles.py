@@ -13,7 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profiles")
 DST = os.path.join(ROOT, "profiles")
-N_EL = {"c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c5": ("c5_wan", 2096640)}
+N_EL = {"c1": ("c1_sd15", 16384), "c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c4": ("c4_flux", 65536),
+        "c5": ("c5_wan", 2096640)}
 
 
 def steady_mean(path):

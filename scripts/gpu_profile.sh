@@ -19,7 +19,7 @@ summ /tmp/p_c5b/t_results.db > $OUT/c5_bench_kernel_trace.md 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr -d /tmp/p_pmc_c2_$ctr -o t -- python $R/bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-large-shape --extras 0 > $OUT/c2_pmc_$ctr.log 2>&1
   summ /tmp/p_pmc_c2_$ctr/t_results.db --pmc 2>&1 | grep -A200 "counter | dispatches" | grep -i "lp::\|counter" > $OUT/c2_pmc_$ctr.md
-  for wl in c3:c3_sdxl_b4 c5:c5_wan; do
+  for wl in c1:c1_sd15 c3:c3_sdxl_b4 c4:c4_flux c5:c5_wan; do
     rocprofv3 --kernel-trace --pmc $ctr -d /tmp/p_pmc_${wl%%:*}_$ctr -o t -- python $R/scripts/microbench_step.py ${wl#*:} steady 20 > $OUT/${wl%%:*}_pmc_$ctr.log 2>&1
     summ /tmp/p_pmc_${wl%%:*}_$ctr/t_results.db --pmc 2>&1 | grep -A200 "counter | dispatches" | grep -i "lp::\|counter\|Mul" > $OUT/${wl%%:*}_pmc_$ctr.md
   done
