@@ -76,6 +76,16 @@ __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64
     return v * 1.0f + 0.0f;
 }
 
+// The four values thread `idx` of ATen's kernel produces with one normal4 call: elements idx, idx + bg, idx + 2 bg,
+// idx + 3 bg of the tensor (the `Strided` lane layout).
+__device__ __forceinline__ void torch_normal4(uint32_t idx, uint64_t seed, uint64_t offset, float (&o)[4]) {
+#pragma clang fp contract(on)
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, idx, offset, &st);
+    const float4 r = rocrand_normal4(&st);
+    o[0] = r.x * 1.0f + 0.0f; o[1] = r.y * 1.0f + 0.0f; o[2] = r.z * 1.0f + 0.0f; o[3] = r.w * 1.0f + 0.0f;
+}
+
 // ---- 16/32-bit float conversions ----------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(static_cast<uint32_t>(h) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN kept quiet
@@ -98,6 +108,40 @@ __device__ __forceinline__ uint16_t f32_to_f16(float f) {
 
 // ---- vector loads / stores ------------------------------------------------------
 enum : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+
+// Where the V elements of one lane live.  Normally V consecutive elements from index i (an int64_t).  `Strided`:
+// element k at i + k * s while that is < n -- the element-to-thread map of ATen's random kernels (a thread's
+// k-th value goes block*grid elements further on), used by the LP_RNG_TORCH large-latent variant so that one
+// Philox4x32 block serves four elements as it does in torch.  Each of its accesses is a coalesced 4-byte stream.
+// Loads of a slot past the end are redirected to the last element (no branch around a load, the value is never
+// stored); only the stores are predicated.
+struct Strided {
+    int64_t e[4];      // element index per slot, clamped to n - 1
+    bool ok[4];        // slot inside the tensor
+    __device__ __forceinline__ Strided(int64_t i, int64_t s, int64_t n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t t = i + k * s;
+            ok[k] = t < n;
+            e[k] = ok[k] ? t : n - 1;
+        }
+    }
+};
+__device__ __forceinline__ int64_t elem_index(int64_t i, int k) { return i + k; }
+__device__ __forceinline__ int64_t elem_index(const Strided& x, int k) { return x.e[k]; }
+__device__ __forceinline__ bool elem_ok(const Strided& x, int k) { return x.ok[k]; }
+
+template <int V>
+__device__ __forceinline__ void load_f32(const float* __restrict__ p, const Strided& x, float (&o)[V]) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = __builtin_nontemporal_load(p + elem_index(x, k));
+}
+template <int V>
+__device__ __forceinline__ void store_f32(float* __restrict__ p, const Strided& x, const float (&v)[V]) {
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+        if (elem_ok(x, k)) __builtin_nontemporal_store(v[k], p + elem_index(x, k));
+}
 
 template <int V>
 __device__ __forceinline__ void load_f32(const float* __restrict__ p, int64_t i, float (&o)[V]) {
@@ -154,6 +198,25 @@ __device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, int
 }
 
 template <int V>
+__device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, const Strided& x, Raw<V>& r) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int64_t e = elem_index(x, k);
+        r.w[k] = (dt == DT_F32) ? __float_as_uint(static_cast<const float*>(p)[e])
+                                : static_cast<uint32_t>(static_cast<const uint16_t*>(p)[e]);
+    }
+}
+
+// strided lanes keep one storage word per element (no packing of 16-bit pairs)
+template <int V>
+__device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V], const Strided&) {
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+        o[k] = (dt == DT_F32) ? __uint_as_float(r.w[k])
+               : (dt == DT_BF16) ? bf16_to_f32(static_cast<uint16_t>(r.w[k])) : f16_to_f32(static_cast<uint16_t>(r.w[k]));
+}
+
+template <int V>
 __device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V]) {
     if (dt == DT_F32) {
 #pragma unroll
@@ -171,9 +234,14 @@ __device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V]) 
     }
 }
 
+template <int V>
+__device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V], int64_t) {
+    cvt_raw<V>(dt, r, o);
+}
+
 // Same with the storage width fixed at compile time (W = 4: fp32, W = 2: bf16 / fp16, W = 0: run-time `dt`).
-template <int V, int W>
-__device__ __forceinline__ void load_raw_w(const void* __restrict__ p, int dt, int64_t i, Raw<V>& r) {
+template <int V, int W, typename IX>
+__device__ __forceinline__ void load_raw_w(const void* __restrict__ p, int dt, const IX& i, Raw<V>& r) {
     if constexpr (W == 4) load_raw<V>(p, DT_F32, i, r);
     else if constexpr (W == 2) load_raw<V>(p, DT_BF16, i, r);        // bf16 and fp16 load alike; cvt_raw tells them apart
     else load_raw<V>(p, dt, i, r);
@@ -184,6 +252,17 @@ __device__ __forceinline__ void load_any(const void* __restrict__ p, int dt, int
     Raw<V> r;
     load_raw<V>(p, dt, i, r);
     cvt_raw<V>(dt, r, o);
+}
+
+template <int V>
+__device__ __forceinline__ void store_any(void* __restrict__ p, int dt, const Strided& x, const float (&v)[V]) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        if (!elem_ok(x, k)) continue;
+        const int64_t e = elem_index(x, k);
+        if (dt == DT_F32) static_cast<float*>(p)[e] = v[k];
+        else static_cast<uint16_t*>(p)[e] = (dt == DT_BF16) ? f32_to_bf16(v[k]) : f32_to_f16(v[k]);
+    }
 }
 
 template <int V>
@@ -224,6 +303,30 @@ __device__ __forceinline__ void load_mask_raw(const void* __restrict__ p, uint32
         load_f32<V>(static_cast<const float*>(p), i, t);
 #pragma unroll
         for (int k = 0; k < V; ++k) r.w[k] = __float_as_uint(t[k]);
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void load_mask_raw(const void* __restrict__ p, uint32_t flags, const Strided& x, Raw<V>& r) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int64_t e = elem_index(x, k);
+        r.w[k] = (flags & LP_FL_MASK_BITS) ? static_cast<const uint32_t*>(p)[e >> 5]
+                 : (flags & LP_FL_MASK_U8) ? static_cast<uint32_t>(static_cast<const uint8_t*>(p)[e])
+                                           : __float_as_uint(static_cast<const float*>(p)[e]);
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void cvt_mask(uint32_t flags, const Strided& x, const Raw<V>& r, float (&m)[V]) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        if (flags & LP_FL_MASK_BITS) {
+            m[k] = static_cast<float>((r.w[k] >> (static_cast<uint32_t>(elem_index(x, k)) & 31u)) & 1u);
+        } else {
+            m[k] = (flags & LP_FL_MASK_U8) ? static_cast<float>(r.w[k]) : __uint_as_float(r.w[k]);
+            if (flags & LP_FL_MASK_DENOISE) m[k] = 1.0f - ((m[k] > 0.5f) ? 1.0f : 0.0f);
+        }
     }
 }
 

@@ -127,7 +127,10 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // masks, a uint8 mask goes through the PH = 0 kernel.
 // RNG: in-kernel generator fixed at compile time in the hot variants (0 = Philox2x32 pair, 1 = torch's randn
 // stream reproduced exactly) or 2 = read d.rng_kind at run time.
-template <int VEC, int MODE, uint32_t PH, int X0W, int RNG>
+// ST (with VEC = 4, RNG = 1, one batch row, n_el in (bg, 4 bg]): the lane's four elements are ATen's -- idx,
+// idx + bg, idx + 2 bg, idx + 3 bg -- so ONE Philox4x32 block and its two Box-Muller pairs serve all four, as
+// in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
+template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false>
 __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     constexpr bool PER_EL = MODE == MODE_PER_EL;
     constexpr bool HARD = MODE == MODE_HARD;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     const bool given = fl & LP_FL_X0S_GIVEN;
     const bool has_corr = d.corr_el != nullptr && !given;
     const int x0dt = X0W == 4 ? static_cast<int>(DT_F32) : x0_dtype(fl), xindt = xin_dtype(fl);
-    const int64_t groups = d.el_per_row / VEC;
+    const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
     const int64_t row_base = static_cast<int64_t>(row) * d.el_per_row;
     const float lam = d.lambda, opl = d.one_plus_lambda;
 
@@ -180,7 +183,10 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= groups) return;
     {
-        const int64_t i = row_base + g * VEC;
+        const auto i = [&] {
+            if constexpr (ST) return Strided(g, static_cast<int64_t>(d.rng_bg), d.n_el);
+            else return row_base + g * VEC;
+        }();
 
         // ---- issue every load of this launch before any arithmetic ---------------------
         float m[VEC], xt[VEC], yv[VEC], cv[VEC], x0[VEC], x0b[VEC], xi_a[VEC], xi_b[VEC], corr[VEC];
@@ -227,16 +233,23 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                 // torch.randn_like(x_t) twice, in the reference's order: the POST draw, then the PRE draw
                 const bool draw_post = post && !host_post, draw_pre = (ph & LP_PH_PRE_HALF) && !host_pre;
                 const uint64_t off_pre = seq + (draw_post ? d.rng_inc : 0u);
+                if constexpr (ST) {
+                    static_assert(!ST || VEC == 4, "the strided layout is four elements per lane");
+                    if (draw_post) torch_normal4(static_cast<uint32_t>(g), seed, seq, xi_a);
+                    if (draw_pre) torch_normal4(static_cast<uint32_t>(g), seed, off_pre, xi_b);
+                } else {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (draw_post) xi_a[k] = torch_normal(static_cast<uint64_t>(i + k), seed, seq, d.rng_bg);
-                    if (draw_pre) xi_b[k] = torch_normal(static_cast<uint64_t>(i + k), seed, off_pre, d.rng_bg);
+                    for (int k = 0; k < VEC; ++k) {
+                        const uint64_t li = static_cast<uint64_t>(elem_index(i, k));
+                        if (draw_post) xi_a[k] = torch_normal(li, seed, seq, d.rng_bg);
+                        if (draw_pre) xi_b[k] = torch_normal(li, seed, off_pre, d.rng_bg);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float za, zb;
-                    normal_pair(static_cast<uint64_t>(i + k), seq, seed, za, zb);
+                    normal_pair(static_cast<uint64_t>(elem_index(i, k)), seq, seed, za, zb);
                     if (!host_post) xi_a[k] = za;
                     if (!host_pre) xi_b[k] = zb;
                 }
@@ -246,8 +259,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         // ---- decode what was loaded in a storage format --------------------------------------------
         cvt_mask<VEC>(mfl, i, m_raw, m);
         if (post) {
-            cvt_raw<VEC>(x0dt, x0_raw, x0);
-            if (!(d.x0_big == d.x0 || given)) cvt_raw<VEC>(x0dt, x0b_raw, x0b);
+            cvt_raw<VEC>(x0dt, x0_raw, x0, i);
+            if (!(d.x0_big == d.x0 || given)) cvt_raw<VEC>(x0dt, x0b_raw, x0b, i);
         }
 
         // ---- REPLACE: x = x(1-m) + known*m ; x_t = VP(x) -----------------------------------
@@ -420,10 +433,10 @@ static const Tune& tune() {
     return t;
 }
 
-template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2>
+template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2, bool ST = false>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     const Tune& t = tune();
-    const int64_t groups = d.el_per_row / VEC;
+    const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
     const int block = t.block ? t.block : 256;
     int64_t bx = (groups + block - 1) / block;
     // One group per lane, no grid-stride loop: capping the grid at 2048 blocks cost 30 % on a 33 M-element
@@ -433,10 +446,10 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     if (bx > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
     if (timer) {
-        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG>), grid, dim3(block), 0, stream, timer->start,
+        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST>), grid, dim3(block), 0, stream, timer->start,
                               timer->stop, 0, d);
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG>), grid, dim3(block), 0, stream, d);
+        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST>), grid, dim3(block), 0, stream, d);
     }
     return hipGetLastError();
 }
@@ -456,9 +469,14 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
         return hard ? launch<VEC, MODE_HARD, R | E | LP_PH_COEFFS>(d, stream, timer)
                     : launch<VEC, MODE_ROW, R | E | LP_PH_COEFFS>(d, stream, timer);
     const bool rng_torch = d.rng_kind == LP_RNG_TORCH;
+    // ATen's element-to-thread layout pays off when a Philox block really serves several elements of this tensor
+    const bool strided = VEC == 4 && rng_torch && d.rows == 1 && !d.xi_post && !d.xi_pre &&
+                         d.n_el > static_cast<int64_t>(d.rng_bg) && d.n_el <= 4 * static_cast<int64_t>(d.rng_bg) &&
+                         d.rng_inc == 4;
 #define LP_HOT(MODE_, PH_)                                                                                   \
-    (x0_half ? (rng_torch ? launch<VEC, MODE_, PH_, 2, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 2, 0>(d, stream, timer)) \
-             : (rng_torch ? launch<VEC, MODE_, PH_, 4, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 4, 0>(d, stream, timer)))
+    (strided ? (x0_half ? launch<4, MODE_, PH_, 2, 1, true>(d, stream, timer) : launch<4, MODE_, PH_, 4, 1, true>(d, stream, timer)) \
+     : x0_half ? (rng_torch ? launch<VEC, MODE_, PH_, 2, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 2, 0>(d, stream, timer)) \
+               : (rng_torch ? launch<VEC, MODE_, PH_, 4, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 4, 0>(d, stream, timer)))
     if (hard) {
         switch (d.phases) {
             case S | P | E: return LP_HOT(MODE_HARD, S | P | E);   // steady state

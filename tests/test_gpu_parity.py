@@ -461,7 +461,7 @@ def test_kernel_instantiation_matrix_is_consistent(shape, flow):
             assert float((ref[(dtype, fused)][0] - f32[0]).abs().max()) <= tol * scale, (dtype, fused)
 
 
-@pytest.mark.parametrize("shape", [(2, 4, 24, 20), (2, 4, 258, 262)], ids=["vec1", "vec4"])
+@pytest.mark.parametrize("shape", [(2, 4, 24, 20), (2, 4, 258, 262), (1, 4, 521, 301)], ids=["vec1", "vec4", "strided"])
 @pytest.mark.parametrize("mode", ["eager", "graph", "early_stop"])
 def test_in_kernel_torch_stream_equals_randn_like_tensors(shape, mode):
     """rng="torch" generates the reference's noise (torch.randn_like(x_t), POST draw then PRE draw) inside the step
@@ -469,6 +469,7 @@ def test_in_kernel_torch_stream_equals_randn_like_tensors(shape, mode):
     sigma calls, and the device generator ends in the same state -- so whatever draws from it next (an ancestral
     sampler's noise) is unchanged too."""
     import torch
+    import lanpaint_amd
     from lanpaint_amd import LanPaint
     torch.manual_seed(0)
     y = torch.randn(shape, device="cuda")
@@ -476,18 +477,20 @@ def test_in_kernel_torch_stream_equals_randn_like_tensors(shape, mode):
     mask = (torch.rand(shape, device="cuda") < 0.5).float()
     sigmas = [torch.tensor([3.0, 2.0], device="cuda"), torch.tensor([1.2, 0.8], device="cuda"),
               torch.tensor([0.5, 0.3], device="cuda")]
+    sigmas = [s_[:shape[0]] for s_ in sigmas]       # "strided": one batch row, 627 k elements > ATen's block * grid
     kw = dict(graph=True) if mode == "graph" else dict(EarlyStopThreshold=1e-7, EarlyStopPatience=1) if mode == "early_stop" else {}
     res = {}
     for rng in ("torch-eager", "torch"):
         eng = LanPaint(MODELS["linear_tuple"](flow=False), 4, 15.0, 5.0, 1.0, 0.2, rng=rng, **kw)
         torch.manual_seed(77)
         x = (y + noise * 3.0).clone()
+        mask_in = lanpaint_amd.pack_mask(mask.clone()) if shape[0] == 1 else mask      # also the hard-mask kernels
         outs = []
         for rep in range(2):                    # second pass: replays (graph mode), generator keeps moving
             for sig in sigmas:
                 abt = 1 / (1 + sig ** 2)
                 times = (sig.clone(), abt, torch.sqrt(1 - abt) / (torch.sqrt(1 - abt) + torch.sqrt(abt)))
-                out = eng(x, y, noise, sig, mask, times, {}, 0)
+                out = eng(x, y, noise, sig, mask_in, times, {}, 0)
                 between = torch.randn(3, device="cuda")          # somebody else draws between the calls
                 outs.append((x.clone(), out.clone(), between))
         res[rng] = (outs, torch.cuda.default_generators[0].get_offset(), eng.iterations_run)
