@@ -20,7 +20,7 @@ N_EL = {"c1": ("c1_sd15", 16384), "c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4",
 def steady_mean(path):
     """mean-per-dispatch (KB) of the steady lp_step kernel (PH = 28) in a --pmc summary."""
     for line in open(path):
-        m = re.match(r"\| `lp::lp_step_kernel<(\d), \w+, 28u(?:, \d)*>.*?` \| (\w+) \| (\d+) \| ([0-9.]+) \|", line)
+        m = re.match(r"\| `lp::lp_step_kernel<(\d), \w+, 28u[^>]*>.*?` \| (\w+) \| (\d+) \| ([0-9.]+) \|", line)
         if m:
             return int(m.group(1)), float(m.group(4)), int(m.group(3))
     return None
