@@ -146,16 +146,16 @@ typedef struct lp_step_desc {
     const float* known;        /* REPLACE, LP_REPLACE_KNOWN                               */
     const float* noise;        /* REPLACE, VE/FLOW kinds                                  */
     const float* y;            /* latent_image (clean known latent)                       */
-    const void*  mask;         /* fp32 (default) or u8, full latent shape                 */
+    const void*  mask;         /* fp32 (default), u8 or bit-packed (LP_FL_MASK_*), full latent shape */
     float*       x_t;          /* VP-space state, read+written                            */
     float*       C;            /* LangevinState.C, read+written                           */
     float*       x0s;          /* LangevinState.x0 out (LP_FL_WRITE_X0S) or NULL          */
     const void*  x0;           /* model output head 0                                     */
     const void*  x0_big;       /* model output head 1 (may alias x0)                      */
     void*        x_in;         /* EMIT: model-space latent for the next model call        */
-    const float* xi_post;      /* host-supplied N(0,1) for POST_* (NULL => Philox)        */
-    const float* xi_pre;       /* host-supplied N(0,1) for PRE_HALF (NULL => Philox)      */
-    uint64_t     rng_seed;     /* Philox key                                              */
+    const float* xi_post;      /* host-supplied N(0,1) for POST_* (NULL => generated in-kernel, rng_kind) */
+    const float* xi_pre;       /* host-supplied N(0,1) for PRE_HALF (NULL => generated in-kernel)         */
+    uint64_t     rng_seed;     /* generator seed / key                                    */
     uint64_t     rng_offset;   /* LP_RNG_PHILOX: launch sequence number (unique per launch);
                                   LP_RNG_TORCH: torch philox offset of this launch's first draw */
     const uint64_t* rng_offset_ptr; /* optional device u64[2] (graph replay): [0] is added to rng_offset;
