@@ -531,3 +531,19 @@ def test_in_kernel_torch_stream_steps_aside_when_the_backbone_draws_inside_the_g
     assert torch.equal(res[0][0], res[1][0]) and res[0][2] == res[1][2]
     for u, v in zip(res[0][1], res[1][1]):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("name", ["av_flat_pack", "av_flat_binary", "ve_soft_mask", "ve_earlystop", "flow_video5d", "ve_batch_rows"])
+def test_in_kernel_torch_stream_on_the_general_paths(name):
+    """rng="torch" vs rng="torch-eager" on the golden cases that take the run-time kernels (per-element AV times,
+    soft masks, semantic early stop) and on 5-D / multi-row latents: bitwise the same x / out, same generator state."""
+    import torch
+    if name not in gc.CASES:
+        pytest.skip(f"no golden case {name}")
+    res = []
+    for rng in ("torch-eager", "torch"):
+        torch.manual_seed(2024)
+        r = run_product_case(name, rng=rng)
+        res.append((r["x"], r["out"], torch.cuda.default_generators[0].get_offset(), r["engine"].iterations_run))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
