@@ -82,3 +82,47 @@ def test_large_shapes_both_kernel_widths(idx):
     rng = np.random.default_rng(idx)
     c["draws"] = [rng.standard_normal(c["shape"], dtype=np.float32) for _ in range(3)]
     _run(c)
+
+
+def _run_engine(c, rng, pack, graph, calls=2):
+    """`calls` consecutive sigma calls on the same tensors (the second one replays in graph mode)."""
+    import torch
+    import lanpaint_amd
+    from lanpaint_amd import LanPaint
+    h = c["hyper"]
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    times = tuple(tt(t) for t in times_from_sigma(c["sigma"], c["flow"]))
+    eng = LanPaint(MODELS[c["model"]](flow=c["flow"]), 5, 15.0, h["lamb"], h["beta"], h["step"], IS_FLOW=c["flow"],
+                   MinStepFrac=h["msf"], rng=rng, graph=graph)
+    mask = tt(c["mask"])
+    if pack:
+        mask = lanpaint_amd.pack_mask(mask)
+    x, y, noise, sigma = tt(c["x"]), tt(c["y"]), tt(c["noise"]), tt(c["sigma"])
+    torch.manual_seed(99)
+    outs = []
+    for _ in range(calls):
+        out = eng(x, y, noise, sigma, mask, times, {}, 0, n_steps=c["n_steps"])
+        outs.append((x.clone().cpu(), out.clone().cpu()))
+    return outs, torch.cuda.default_generators[0].get_offset()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fast_paths_equal_the_plain_path_bitwise(seed):
+    """Everything that makes the think loop fast -- bit-packed mask (hard-mask kernels), the torch noise stream
+    generated in-kernel, the coefficient table folded into the replace launch, hipGraph replay through
+    lp_replay_call -- against the plain path (fp32 mask, torch.randn_like tensors, eager launches) on random
+    configurations: bitwise the same x / out on two consecutive calls, same generator state afterwards."""
+    c = _case(3000 + seed, BIG[seed % len(BIG)] if seed % 8 == 7 else None)
+    if c["kind"] == "soft":                    # a soft mask cannot be packed: exercise the rest of the fast path
+        pack = False
+    else:
+        pack = True
+    if seed % 8 == 7:
+        c["n_steps"] = 2
+    plain, off_plain = _run_engine(c, "torch-eager", pack=False, graph=False)
+    fast, off_fast = _run_engine(c, "torch", pack=pack, graph=True)
+    what = f"shape={c['shape']} flow={c['flow']} n={c['n_steps']} mask={c['kind']} model={c['model']} {c['hyper']}"
+    assert off_plain == off_fast, what
+    for (xa, oa), (xb, ob) in zip(plain, fast):
+        assert np.array_equal(xa.numpy(), xb.numpy()), "x | " + what
+        assert np.array_equal(oa.numpy(), ob.numpy()), "out | " + what
