@@ -3,7 +3,7 @@
 combination captured in a hipGraph, replayed; reports us per launch (kernel + the dependent
 launch boundary) for the current LANPAINT_AMD_TUNE_* environment.
 
-    python scripts/microbench_step.py c2_sdxl [steady|first|last|replace] [reps]
+    python scripts/microbench_step.py c2_sdxl [steady|first|last|replace] [reps] [philox|torch]
 """
 import ctypes
 import os
@@ -30,11 +30,17 @@ def main():
     lib = _cabi.load()
     d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase])
     bufs = keep[0]
+    rng = sys.argv[4] if len(sys.argv) > 4 else "philox"
+    if rng == "torch":                          # the device generator's randn stream reproduced in-kernel
+        from lanpaint_amd import LanPaint
+        d.rng_kind = _cabi.LP_RNG_TORCH
+        d.rng_bg, d.rng_inc = LanPaint._randn_policy(dev, n_el)
+        d.rng_seed = 1234
 
     def launches(n):
         s = torch.cuda.current_stream().cuda_stream
         for k in range(n):
-            d.rng_offset = k
+            d.rng_offset = k if rng != "torch" else 2 * k * d.rng_inc
             _cabi.check(lib.lp_step(ctypes.byref(d), s))
 
     launches(5)
@@ -70,7 +76,7 @@ def main():
     bytes_ = {"steady": 36, "first": 32, "last": 36, "replace": 24}[phase] * n_el
     env = {k: v for k, v in os.environ.items() if k.startswith("LANPAINT_AMD_TUNE")}
     print(f"{wl} {phase} n_el={n_el} us/launch={us:.3f} ({bytes_ / us / 1e3:.0f} GB/s algorithmic) "
-          f"torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
+          f"rng={rng} torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
 
 
 if __name__ == "__main__":
