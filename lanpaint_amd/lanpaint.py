@@ -84,6 +84,15 @@ def pack_mask(latent_mask: torch.Tensor, *, denoise_mask: bool = False, check: b
     return out
 
 
+def aten_randn_policy(numel: int, multi_processor_count: int, max_threads_per_multi_processor: int):
+    """calc_execution_policy of ATen's random kernels for one fp32 randn of `numel` elements: 256-thread blocks, the
+    grid capped at SMs * (maxThreadsPerSM / 256), four values per thread and loop trip.  Returns (block * grid,
+    philox-offset increment of the call)."""
+    grid = min(multi_processor_count * (max_threads_per_multi_processor // 256), (numel + 255) // 256)
+    bg = 256 * grid
+    return bg, ((numel - 1) // (bg * 4) + 1) * 4
+
+
 def _noise_scaling_kind(model_sampling) -> str:
     """Which closed form the replace step may fuse (lanpaint.py:84-94).  'callback'
     keeps the reference behaviour for any model_sampling: call its noise_scaling."""
@@ -316,9 +325,8 @@ class LanPaint:
         hit = cls._policy_cache.get(key)
         if hit is None:
             p = torch.cuda.get_device_properties(device)
-            grid = min(p.multi_processor_count * (p.max_threads_per_multi_processor // 256), (numel + 255) // 256)
-            bg = 256 * grid
-            hit = cls._policy_cache[key] = (bg, ((numel - 1) // (bg * 4) + 1) * 4)
+            hit = cls._policy_cache[key] = aten_randn_policy(numel, p.multi_processor_count,
+                                                             p.max_threads_per_multi_processor)
         return hit
 
     def _fill_hyper(self, flow):

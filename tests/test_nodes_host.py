@@ -215,3 +215,16 @@ def test_image_encode_decode_nodes_plain_paths_need_no_gpu(nodes):
     assert tuple(out.shape) == (1, 64, 48, 3)
     resized, = nodes.LanPaint_ImageDecode().decode(latent, VAE(), image=torch.rand(1, 60, 50, 3))
     assert tuple(resized.shape) == (1, 60, 50, 3)
+
+
+def test_aten_randn_policy_matches_what_torch_consumed_on_the_mi355x(hip_lib):
+    """(block * grid, generator-offset increment) of one torch.randn call, as measured on the MI355X (256 CUs, 2048
+    threads per CU) while pinning LP_RNG_TORCH against torch.randn itself (tests/test_gpu_kernels.py)."""
+    from lanpaint_amd.lanpaint import aten_randn_policy
+    mi355x = (256, 2048)
+    assert aten_randn_policy(1, *mi355x) == (256, 4)
+    assert aten_randn_policy(257, *mi355x) == (512, 4)
+    assert aten_randn_policy(65536, *mi355x) == (65536, 4)                  # SDXL latent: one value per thread
+    assert aten_randn_policy(2096640, *mi355x) == (524288, 4)               # Wan latent: the grid cap, 4 values per thread
+    assert aten_randn_policy(4 * 2096640 + 3, *mi355x) == (524288, 16)
+    assert aten_randn_policy(16 * 2096640, *mi355x) == (524288, 64)
