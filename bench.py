@@ -203,6 +203,18 @@ def run_gpu(args):
 
     tmax, iters_total = lpd.reduce_throughput(elapsed, iters_local, dev)
 
+    # run-to-run spread of the same measurement: further blocks of K steps, each bracketed like the timed region
+    # (the headline `value` stays the first block -- exactly K steps, as the contract says)
+    repeat_values = []
+    for _ in range(max(0, args.repeats)):
+        barrier()
+        itr, tr = engine.iterations_run, time.perf_counter()
+        for _ in range(args.steps):
+            schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        barrier()
+        t_r, n_r = lpd.reduce_throughput(time.perf_counter() - tr, engine.iterations_run - itr, dev)
+        repeat_values.append(n_r / t_r)
+
     roofline = None
     if rank == 0:
         try:
@@ -211,12 +223,17 @@ def run_gpu(args):
         except Exception as e:
             roofline = {"error": repr(e)}
     # the secondary measurements must never cost the headline line
-    large, extras, cpu = None, {}, None
+    large, past_l3, extras, cpu = None, None, {}, None
     if rank == 0 and world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
         try:
             large = pre_large if pre_large is not None else measure_hbm_bound_shape(_cabi, dev)
         except Exception as e:
             large = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_large_shape:
+        try:      # 1.2 GB per launch: nothing of it survives in the 256 MiB Infinity Cache between launches
+            past_l3 = measure_hbm_bound_shape(_cabi, dev, workload="x_wan_b16", launches=24)
+        except Exception as e:
+            past_l3 = {"error": repr(e)}
     if rank == 0 and world == 1 and args.extras:
         try:
             extras = extra_lines(args, dev)
@@ -250,8 +267,12 @@ def run_gpu(args):
                    "latent_elements_per_gpu": n_el, "lambda": HYPER["Lambda"], "beta": HYPER["Beta"],
                    "step_size": HYPER["StepSize"]},
         "latent_rows_x_iterations_per_s": iters_total * b / tmax,
+        "repeats": ({"values": repeat_values, "median": float(np.median(repeat_values)), "min": min(repeat_values),
+                     "max": max(repeat_values), "note": f"further timed blocks of {args.steps} steps each, same bracketing"}
+                    if repeat_values else None),
         "roofline": roofline,
         "roofline_hbm_bound_shape": large,
+        "roofline_hbm_past_l3": past_l3,
         "cpu_baseline": cpu,
     }
     line.update(extras)
@@ -272,6 +293,31 @@ def pmc_traffic(workload):
         return int(entry["traffic_bytes_per_launch"]) if entry else None
     except Exception:
         return None
+
+
+def rocprof_duration(workload):
+    """Mean per-dispatch duration (us) of the steady kernel on this workload's shape as rocprofv3 --kernel-trace
+    measured it (profiles/r*_kernel_durations.json, written by scripts/collect_profiles.py from the committed
+    kernel-trace summaries).  None when no profile covers the workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_durations.json")))
+    if not files:
+        return None
+    try:
+        entry = json.load(open(files[-1])).get(workload)
+        return float(entry["mean_us"]) if entry else None
+    except Exception:
+        return None
+
+
+def steady_kernel_name(workload, rng, mask_format):
+    """The instantiation lp_step dispatches the steady-state launch of this workload to (step_kernel.hip)."""
+    n_el = int(np.prod(WORKLOADS[workload][0]))
+    vec = 4 if n_el > 512 * 1024 else 1
+    strided = rng == "torch" and vec == 4 and WORKLOADS[workload][0][0] == 1
+    return (f"lp::lp_step_kernel<{vec}, {2 if mask_format == 'bits' else 0}, 28u, 4, {1 if rng == 'torch' else 0}, "
+            f"{'true' if strided else 'false'}>  (VEC, MODE: 2 = bit-packed hard mask, PH 28 = POST_STEADY|PRE_HALF|EMIT, "
+            "fp32 backbone outputs, RNG: 0 = Philox 1 = torch stream, ATen-strided lanes)")
 
 
 def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args, busy=None):
@@ -325,16 +371,23 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
     # rocprofv3 -- is the same event pair per dispatch with the launches back to back: that one is `achieved`.
     if not busy or "error" in busy:
         busy = measure_hbm_bound_shape(_cabi, x0.device, workload=args.workload, launches=120)
-    mean_s = busy["mean_launch_us"] * 1e-6
-    achieved = bytes_per_launch / mean_s / 1e9
+    # two readings of the same per-dispatch duration: this run's event pairs and the committed rocprofv3 trace;
+    # `achieved` / `frac` use the LARGER (more conservative) of the two
+    prof_us = rocprof_duration(args.workload)
+    mean_us = max(busy["mean_launch_us"], prof_us or 0.0)
+    achieved = bytes_per_launch / (mean_us * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
+            "duration_used_us": mean_us, "event_mean_launch_us": busy["mean_launch_us"], "rocprofv3_mean_launch_us": prof_us,
+            "frac_from_event_timer": bytes_per_launch / (busy["mean_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "note": "latency-bound shape: 2.4 MB per launch is cache resident, the dispatch is launch latency "
+                    "(see roofline_hbm_bound_shape / roofline_hbm_past_l3 for the bandwidth-bound regime)"
+                    if n_el <= 512 * 1024 else None,
             "eager_replay_mean_us": float(durs.mean()) * 1e6, "eager_replay_median_us": float(np.median(durs)) * 1e6,
             "eager_replay_min_us": float(durs.min()) * 1e6, "eager_replay_launches_timed": len(durs),
             "graph_burst_us_per_launch": burst_us,
             "graph_burst_GBps": bytes_per_launch / burst_us / 1e3,
-            "kernel": "lp::lp_step_kernel<VEC,false,POST_STEADY|PRE_HALF|EMIT> (steady-state think step; "
-                      "VEC=1 up to 512K elements, VEC=4 above)",
+            "kernel": steady_kernel_name(args.workload, "philox", args.mask_format),
             "algorithmic_bytes_per_launch": bytes_per_launch, "mean_launch_us": busy["mean_launch_us"],
             "median_launch_us": busy["median_launch_us"], "min_launch_us": busy["min_launch_us"],
             "launches_timed": busy["launches_timed"],
@@ -455,14 +508,21 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
         lib.lp_timer_destroy(ctypes.c_void_p(t))
     durs = np.asarray(durs[lead:])
     bytes_per_launch = BYTES_PER_EL_STEADY * n_el
-    achieved = bytes_per_launch / float(durs.mean()) / 1e9
     shape = WORKLOADS[workload][0]
     del keep
+    event_us, prof_us = float(durs.mean()) * 1e6, rocprof_duration(workload)
+    used_us = max(event_us, prof_us or 0.0)          # the more conservative of this run's events and the committed trace
+    achieved = bytes_per_launch / (used_us * 1e-6) / 1e9
+    working_set = 9 * 4 * n_el                        # the nine fp32 streams of the steady launch
+    regime = ("past the 256 MiB Infinity Cache: every byte comes from / goes to HBM" if working_set > 2 * 256 * 2 ** 20 else
+              "fabric-side: the working set fits the 256 MiB Infinity Cache, part of the traffic is served on-die between "
+              "launches" if working_set > 32 * 2 ** 20 else "cache resident (L2): launch-latency bound")
     return {"workload": f"{workload}: latent {'x'.join(map(str, shape))}, steady-state lp_step back to back",
+            "regime": regime, "working_set_bytes": working_set,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "frac_of_measured_copy_peak_6290": achieved / 6290.0, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "traffic": pmc_traffic(workload),
-            "mean_launch_us": float(durs.mean()) * 1e6, "median_launch_us": float(np.median(durs)) * 1e6,
+            "frac_vs_6290": achieved / 6290.0, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "traffic": pmc_traffic(workload), "duration_used_us": used_us, "rocprofv3_mean_launch_us": prof_us,
+            "mean_launch_us": event_us, "median_launch_us": float(np.median(durs)) * 1e6,
             "min_launch_us": float(durs.min()) * 1e6, "launches_timed": int(durs.size)}
 
 
@@ -603,16 +663,32 @@ def cpu_baseline(workload, budget_s):
         torch.set_num_threads(saved)
     best = max(results)
     detail = "; ".join(f"{t} thread(s): {v:.1f} it/s over {p} passes in {d:.1f} s" for v, t, p, d in results)
-    return {"value": best[0], "unit": "think-iterations/s", "cores": best[1], "kind": "port",
-            "sample": f"full passes of the {workload} schedule ({n_sig} sigmas x {n_think}) with "
-                      f"oracle/lanpaint_oracle.py on torch-CPU fp32 tensors, {os.cpu_count()} host CPUs; {detail}"}
+    out = {"value": best[0], "unit": "think-iterations/s", "cores": best[1], "kind": "port",
+           "sample": f"full passes of the {workload} schedule ({n_sig} sigmas x {n_think}) with "
+                     f"oracle/lanpaint_oracle.py on torch-CPU fp32 tensors, {os.cpu_count()} host CPUs; {detail}"}
+    # the reference itself cannot travel to the GPU box; the build container timed it next to this port
+    # (scripts/cpu_ref_vs_port.py -> profiles/r*_cpu_reference_vs_port.json): quote that ratio with the number
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference_vs_port.json")))
+    if files:
+        try:
+            ref = json.load(open(files[-1]))
+            out["port_over_reference"] = ref["port_over_reference"]
+            out["reference_estimate"] = best[0] / ref["port_over_reference"]
+            out["reference_note"] = (f"unmodified reference vs this port, {ref['workload']}, 1 thread, build container "
+                                     f"({ref['cpu']}): {ref['reference_it_per_s']:.1f} vs {ref['port_it_per_s']:.1f} it/s "
+                                     f"({os.path.basename(files[-1])}); reference_estimate = value / port_over_reference")
+        except Exception:
+            pass
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (C2: 400 x 1.26 ms = 0.5 s)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="further timed blocks of --steps steps, reported as `repeats` (spread)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.3,
                     help="untimed set-up (graph capture, lazy init, clock ramp) before the warm-up steps")
     ap.add_argument("--workload", default="c2_sdxl", choices=sorted(WORKLOADS))

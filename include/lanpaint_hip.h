@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 8
+#define LP_ABI_VERSION 9
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -184,6 +184,13 @@ typedef struct lp_step_desc {
      * rng_state_out[0] = rng_state_val[0] (offset base), [1] = rng_state_val[1] (seed); NULL = nothing.      */
     uint64_t*    rng_state_out;
     uint64_t     rng_state_val[2];
+    /* Per-call I/O pointers for launches CAPTURED in a hipGraph (their kernargs are frozen at capture): the first
+     * lane of the launch stores io_table_val[0..1] to io_table_out[0..1] (NULL = nothing).  The engine's replace
+     * launch -- the one launch of a sigma call that stays outside the graph -- publishes { address of the sampler
+     * latent x (lanpaint.py:156 writes it in place), address of this call's `out` } for the captured lp_finalize
+     * (lp_final_desc.io_table), so that the caller's tensors never have to be staged through static buffers. */
+    uint64_t*    io_table_out;
+    uint64_t     io_table_val[2];
 } lp_step_desc;
 
 typedef struct lp_final_desc {
@@ -199,6 +206,10 @@ typedef struct lp_final_desc {
     float*       out;          /* out*(1-m) + y*m (lanpaint.py:154)                       */
     uint64_t*    rng_bump_ptr; /* optional: *ptr += rng_bump after the launch (graph replay) */
     uint64_t     rng_bump;
+    const uint64_t* io_table;  /* optional device u64[2] (a finalize captured in a hipGraph): x_dst and out are
+                                  read from io_table[0] / io_table[1] on the device, as the replace launch of the
+                                  same sigma call published them (lp_step_desc.io_table_out); the x_dst / out
+                                  fields are then ignored.  A zero address in slot 0 skips the write-back.      */
 } lp_final_desc;
 
 /* ---- entry points --------------------------------------------------------- */
@@ -221,7 +232,8 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
 /* One sigma call's whole enqueue sequence in ONE host call, for callers that replay the think loop as a
  * hipGraph (the loop between the replace step and the finalise, captured by the caller):
  *     [lp_coeffs(...)] ; lp_step(replace) ; hipGraphLaunch(graph_exec, stream) ; lp_finalize(final).
- * `hyper` NULL skips the separate lp_coeffs launch (the replace descriptor then carries LP_PH_COEFFS).
+ * `hyper` NULL skips the separate lp_coeffs launch (the replace descriptor then carries LP_PH_COEFFS);
+ * `final` NULL skips the lp_finalize launch (it is a node of the captured graph, lp_final_desc.io_table).
  * Host-side launch cost matters at SDXL-latent sizes (the whole call is ~40 us of GPU time): four trips through
  * an FFI cost more than the kernels they start.  `graph_exec` is a hipGraphExec_t (NULL: skip the graph launch).
  * Stops at the first failing step and returns its code.                                              */
@@ -235,7 +247,7 @@ typedef struct lp_call_desc {
     float*               coef_table;
     const lp_step_desc*  replace;       /* LP_PH_REPLACE | LP_PH_EMIT launch                    */
     void*                graph_exec;    /* hipGraphExec_t of the captured think loop, or NULL   */
-    const lp_final_desc* final;         /* lp_finalize descriptor                               */
+    const lp_final_desc* final;         /* lp_finalize descriptor, or NULL                      */
 } lp_call_desc;
 int lp_replay_call(const lp_call_desc* call, void* stream);
 
@@ -276,10 +288,10 @@ int lp_finalize(const lp_final_desc* desc, void* stream);
  * block per latent element keyed on (seed, element, launch offset), Box-Muller; slot 0 =
  * cosine branch (POST stream), 1 = sine branch (PRE stream).  Lets tests reproduce the
  * in-kernel noise exactly.  Replaces torch.randn_like (lanpaint.py:252).               */
+int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream);
 /* Fill `out` with what torch.randn(n_el, device=...) returns for generator state (seed, offset) on this device
  * (test hook for LP_RNG_TORCH; bg as in lp_step_desc.rng_bg).                                            */
 int lp_torch_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t bg, void* stream);
-int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream);
 
 /* K4  inner early-stop metric (earlystop.py:32-55).
  * lp_boundary_ring: ring[i] = (mask<=0.5) & any 4-neighbour(H,W) known, as fp32
@@ -293,14 +305,6 @@ int lp_boundary_ring(const float* mask, float* ring, int64_t planes, int32_t hei
 int lp_wmse_pair(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el,
                  double* acc, double* block_scratch, int32_t scratch_blocks, void* stream);
 
-/* K5  mask preparation (nodes.py:59-133); index math bit-for-bit with torch's nearest-exact.
- * dst[b][c][f][h][w] = max over the temporal window (video: 5 taps, -inf pad;
- * else 1 tap) of src[f_src(f+k)][h_src(h)][w_src(w)], with
- * idx_src(i) = min(int(floorf((i + 0.5f) * (float(in) / float(out)))), in-1)  (ATen's fp32 form of
- * F.interpolate nearest-exact, reproduced op for op),
- * with dst batch b reading src batch b % src_b and dst channel c reading src
- * channel c % src_c (the reference's repeat + slice).  `binarize`: 0 = copy value,
- * 1 = also apply 1 - (v > 0.5) (nodes.py:281-283).                              */
 /* Bytes of the bit-packed form of an n_el-element mask (whole 64-bit ballot words). */
 #define LP_MASK_BITS_BYTES(n_el) ((((n_el) + 63) / 64) * 8)
 
@@ -311,6 +315,14 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
  * input value is neither 0 nor 1 (soft mask: the packed form would not be equivalent).             */
 int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream);
 
+/* K5  mask preparation (nodes.py:59-133); index math bit-for-bit with torch's nearest-exact.
+ * dst[b][c][f][h][w] = max over the temporal window (video: 5 taps, -inf pad;
+ * else 1 tap) of src[f_src(f+k)][h_src(h)][w_src(w)], with
+ * idx_src(i) = min(int(floorf((i + 0.5f) * (float(in) / float(out)))), in-1)  (ATen's fp32 form of
+ * F.interpolate nearest-exact, reproduced op for op),
+ * with dst batch b reading src batch b % src_b and dst channel c reading src
+ * channel c % src_c (the reference's repeat + slice).  `binarize`: 0 = copy value,
+ * 1 = also apply 1 - (v > 0.5) (nodes.py:281-283).                              */
 int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
                     float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
                     int32_t temporal_taps, int32_t binarize, void* stream);

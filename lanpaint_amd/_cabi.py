@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -58,6 +58,7 @@ class LpStepDesc(C.Structure):
         ("t_rsig_stride", C.c_int32), ("t_model_stride", C.c_int32),
         ("rng_kind", C.c_int32), ("rng_bg", C.c_uint32), ("rng_inc", C.c_uint32),
         ("rng_state_out", C.c_void_p), ("rng_state_val", C.c_uint64 * 2),
+        ("io_table_out", C.c_void_p), ("io_table_val", C.c_uint64 * 2),
     ]
 
 
@@ -66,6 +67,7 @@ class LpFinalDesc(C.Structure):
         ("n_el", C.c_int64), ("flags", C.c_uint32), ("cfg_scale", C.c_float),
         ("model_out", C.c_void_p), ("uncond", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p), ("x_src", C.c_void_p),
         ("x_dst", C.c_void_p), ("out", C.c_void_p), ("rng_bump_ptr", C.c_void_p), ("rng_bump", C.c_uint64),
+        ("io_table", C.c_void_p),
     ]
 
 

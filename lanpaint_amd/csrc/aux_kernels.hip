@@ -118,6 +118,10 @@ __global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d)
     const int64_t groups = d.n_el / VEC;
     const int dt = x0_dtype(d.flags);
     const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;     // one group per lane
+    // a finalize replayed from a hipGraph takes the caller's two tensors of THIS call from the table the replace
+    // launch published (scalar loads, issued first; only the stores at the end of the body wait for them)
+    float* const x_dst = d.io_table ? reinterpret_cast<float*>(d.io_table[0]) : d.x_dst;
+    float* const out = d.io_table ? reinterpret_cast<float*>(d.io_table[1]) : d.out;
     if (g < groups) {
         const int64_t i = g * VEC;
         float m[VEC], mo[VEC], yv[VEC], o[VEC];
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d)
         if (d.flags & LP_FL_CFG_FUSED) load_raw<VEC>(d.uncond, dt, i, un_raw);
         load_f32<VEC>(d.y, i, yv);
         float xs[VEC];
-        if (d.x_dst) load_f32<VEC>(d.x_src, i, xs);
+        if (x_dst) load_f32<VEC>(d.x_src, i, xs);
         cvt_mask<VEC>(d.flags, i, m_raw, m);
         cvt_raw<VEC>(dt, mo_raw, mo);
         if (d.flags & LP_FL_CFG_FUSED) {
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d)
         }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o[k] = mo[k] * (1.0f - m[k]) + yv[k] * m[k];
-        store_f32<VEC>(d.out, i, o);
-        if (d.x_dst) store_f32<VEC>(d.x_dst, i, xs);
+        store_f32<VEC>(out, i, o);
+        if (x_dst) store_f32<VEC>(x_dst, i, xs);
     }
     if (d.rng_bump_ptr && blockIdx.x == 0 && threadIdx.x == 0) *d.rng_bump_ptr += d.rng_bump;
 }
@@ -149,8 +153,8 @@ static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpr
 int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
     if (!dp) return LP_E_INVALID;
     const lp_final_desc& d = *dp;
-    if (d.n_el <= 0 || !d.model_out || !d.y || !d.mask || !d.out) return LP_E_INVALID;
-    if (d.x_dst && !d.x_src) return LP_E_INVALID;
+    if (d.n_el <= 0 || !d.model_out || !d.y || !d.mask || (!d.out && !d.io_table)) return LP_E_INVALID;
+    if ((d.x_dst || d.io_table) && !d.x_src) return LP_E_INVALID;
     if ((d.flags & LP_FL_CFG_FUSED) && !d.uncond) return LP_E_INVALID;
     if ((d.flags & LP_FL_MASK_BITS) && ((d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_DENOISE)) || !aligned(d.mask, 4)))
         return LP_E_INVALID;
@@ -158,7 +162,7 @@ int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
     const bool vec4 = (d.n_el % 4 == 0) && aligned(d.model_out, half ? 8 : 16) && aligned(d.uncond, half ? 8 : 16) &&
                       aligned(d.y, 16) &&
                       aligned(d.mask, (d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_BITS)) ? 4 : 16) && aligned(d.x_src, 16) &&
-                      aligned(d.x_dst, 16) && aligned(d.out, 16);
+                      (d.io_table ? true : (aligned(d.x_dst, 16) && aligned(d.out, 16)));
     const int vec = vec4 ? 4 : 1;
     const int64_t groups = d.n_el / vec;
     const int block = groups <= 64 * 1024 ? 64 : 256;

@@ -83,7 +83,7 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
 }
 
 int lp_replay_call(const lp_call_desc* c, void* stream) {
-    if (!c || !c->replace || !c->final) return LP_E_INVALID;
+    if (!c || !c->replace) return LP_E_INVALID;
     hipStream_t s = as_stream(stream);
     int rc = LP_OK;
     if (c->hyper)       // NULL: the replace launch carries LP_PH_COEFFS and writes the table itself
@@ -93,7 +93,7 @@ int lp_replay_call(const lp_call_desc* c, void* stream) {
     rc = lp::step_dispatch(c->replace, s, nullptr);
     if (rc != LP_OK) return rc;
     if (c->graph_exec && hipGraphLaunch(static_cast<hipGraphExec_t>(c->graph_exec), s) != hipSuccess) return LP_E_LAUNCH;
-    return lp::finalize_dispatch(c->final, s);
+    return c->final ? lp::finalize_dispatch(c->final, s) : LP_OK;    // NULL: lp_finalize is a node of the graph
 }
 
 int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n) {

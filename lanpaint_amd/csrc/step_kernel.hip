@@ -174,6 +174,12 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         if constexpr (!PER_EL) rc = load_row(d.coef, row);
     }
 
+    // per-call I/O pointers for the launches of this sigma call that live in a captured graph (lp_finalize)
+    if (d.io_table_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        d.io_table_out[0] = d.io_table_val[0];
+        d.io_table_out[1] = d.io_table_val[1];
+    }
+
     const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
     const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
 

@@ -134,7 +134,7 @@ class _CallState:
     """Everything one sigma call carries from its prologue to its loop and epilogue."""
     __slots__ = ("input_x", "xc", "shape", "n_el", "rows", "flow", "ws", "stream", "sigma", "y", "m", "m_c", "m_flag", "abt",
                  "current_times", "base_flags", "keep", "t_model", "sigma_model", "compat", "n_steps", "x_final", "x_in",
-                 "xin_flag", "k0_desc", "replace_kind_static")
+                 "xin_flag", "k0_desc", "replace_kind_static", "out")
 
 
 class _CapturedCall:
@@ -154,6 +154,8 @@ class _CapturedCall:
         self.call = None         # lp_call_desc: the whole enqueue sequence of a replay in one C call
         self.raw_exec = None     # hipGraphExec_t, when launching it without torch's replay() is equivalent
         self.ident = None        # what the caller passed last time (identity pre-check of the next call)
+        self.final_in_graph = False   # lp_finalize is a node of the graph (reads x / out through the I/O table)
+        self.model_options = None     # the dict the captured backbone calls were made with (kept alive: its id is in the key)
 
 
 class LanPaint:
@@ -289,7 +291,12 @@ class LanPaint:
         return name in self.__dict__ or getattr(type(self), name) is not getattr(LanPaint, name)
 
     def _stream(self, device):
-        return torch.cuda.current_stream(device).cuda_stream
+        # the raw hipStream_t of torch's current stream (torch.cuda.current_stream() builds a Stream object: 2.2 us
+        # against 0.1 us, measured on the MI355X box -- scripts/host_cost_probe.py)
+        try:
+            return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+        except AttributeError:                      # a torch build without the private accessor
+            return torch.cuda.current_stream(device).cuda_stream
 
     def _noise_is_zero(self, noise):
         """lanpaint.py:51: `mean|noise| < 1e-8` costs the reference one host sync per sigma; the verdict is
@@ -430,7 +437,12 @@ class LanPaint:
                 and nz.dtype == f32 and nz.shape == x.shape and x.is_contiguous() and sigma.is_contiguous()
                 and ve.is_contiguous() and abt.is_contiguous() and ft.is_contiguous() and nz.is_contiguous()
                 and x.device.index == torch.cuda.current_device() and i[16] == self._override_state()
+                and i[17] == self._hyper_key() and (x.data_ptr() & 15) == 0
                 and not (isinstance(model_options, dict) and "lanpaint_semantic_stop" in model_options))
+
+    def _hyper_key(self):
+        """The public hyper-parameters a captured launch bakes in (the reference reads them on every call)."""
+        return (self.chara_lamb, self.chara_beta, self.step_size, self.min_step_frac)
 
     def _override_state(self):
         return (self._overridden("langevin_dynamics"), self._overridden("score_model"),
@@ -462,8 +474,12 @@ class LanPaint:
         # every pointer the captured launches bake in is part of the key (y and the mask; the tensors stay the caller's)
         key = (tuple(x.shape), x.device.index, int(n_steps), bool(IS_FLUX), bool(IS_FLOW), self.latent_image.data_ptr(),
                latent_mask.data_ptr(), m_c.data_ptr() if m_c is not None else 0, int(sigma.numel()),
-               tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng)
+               tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng, self._hyper_key(),
+               self.model_dtype)
         cap = self._graphs.get(key)
+        if cap is not None and cap.model_options is not model_options:
+            del self._graphs[key]        # another dict at a recycled id(): the captured backbone calls used the old one
+            cap = None
         if cap is None:
             cap = self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
             if cap is None:          # not capturable after all (see _capture): the eager path
@@ -475,12 +491,13 @@ class LanPaint:
         self.iterations_run += cap.ran
         self.last_inner_steps = cap.ran
         srcs = (x, sigma, current_times[0], current_times[1], current_times[2], self.noise)
-        if cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape:
+        if cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape \
+                and (x.data_ptr() & 15) == 0:
             if not isinstance(model_options, dict) or "lanpaint_semantic_stop" not in model_options:
                 cap.ident = (self.latent_image, latent_mask, model_options, x.shape, n_steps, seed, self.rng,
                              self.latent_image.data_ptr(), latent_mask.data_ptr(), getattr(latent_mask, "_lp_bits", None),
                              getattr(latent_mask, "_lp_u8", None), x.device, sigma.numel(), current_times[0].numel(),
-                             current_times[1].numel(), current_times[2].numel(), self._override_state())
+                             current_times[1].numel(), current_times[2].numel(), self._override_state(), self._hyper_key())
                 self._last_cap = cap
             return self._replay_fast(cap, x, sigma, current_times)
         self._last_cap = None
@@ -490,7 +507,8 @@ class LanPaint:
             gen = self._generator(x.device)
             gen.set_offset(gen.get_offset() + cap.launches)
             self._torch_consumed += cap.launches
-        return self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None)
+        return self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None,
+                              in_graph=cap.final_in_graph)
 
     def _replay_fast(self, cap, x, sigma, current_times):
         """Steady-state replay: the two launches around the graph (replace + coefficient table, lp_finalize) reuse
@@ -504,7 +522,10 @@ class LanPaint:
         k0.x, k0.noise = x.data_ptr(), self.noise.data_ptr()
         # the replace launch also rebuilds the coefficient table from this call's sigma / times (LP_PH_COEFFS)
         k0.t_ve, k0.t_abt, k0.t_rsig, k0.t_model = ve.data_ptr(), abt.data_ptr(), sigma.data_ptr(), t_src.data_ptr()
-        f.x_dst, f.out = k0.x, out.data_ptr()
+        if cap.final_in_graph:         # the captured lp_finalize reads these two through the table the replace publishes
+            k0.io_table_val[0], k0.io_table_val[1] = k0.x, out.data_ptr()
+        else:
+            f.x_dst, f.out = k0.x, out.data_ptr()
         if self.rng == "torch":        # generator state in (published by the replace launch), state out
             gen = self._generator(x.device)
             off = gen.get_offset()
@@ -516,16 +537,19 @@ class LanPaint:
             return out
         _cabi.check(lib.lp_step(ctypes.byref(k0), stream), "lp_step")
         cap.graph.replay()
-        _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
+        if not cap.final_in_graph:
+            _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
         return out
 
     def _rng_state(self, dev):
-        """Device u64[2] read by captured launches.  rng="philox": [0] = launch-sequence base, ONE per device and
+        """Device u64[4] read by captured launches.  rng="philox": [0] = launch-sequence base, ONE per device and
         bumped by every replay so the streams of different captures never overlap.  rng="torch": (generator
-        offset, seed) published by the replace launch of each call."""
+        offset, seed) published by the replace launch of each call.  [2], [3]: the I/O table of the call in flight
+        (address of the sampler latent x, address of `out`), published by the replace launch for the captured
+        lp_finalize."""
         state = self._rng_counters.get(dev)
         if state is None:
-            state = self._rng_counters[dev] = torch.zeros(2, dtype=torch.int64, device=dev)
+            state = self._rng_counters[dev] = torch.zeros(4, dtype=torch.int64, device=dev)
         return state
 
     def _capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
@@ -563,8 +587,18 @@ class LanPaint:
         try:
             # thread_local: a live RCCL communicator's watchdog thread issues HIP calls of its own;
             # in the default "global" mode those would invalidate this thread's capture
+            f = _cabi.LpFinalDesc()
             with torch.cuda.graph(cap.graph, stream=side, capture_error_mode="thread_local"):
                 cap.final = self._think_and_final_model(st, model_options, seed)
+                dense_ok = self._fill_final_desc(f, st, cap.final, st.out)
+                if self.rng == "philox":
+                    f.rng_bump_ptr, f.rng_bump = counter.data_ptr(), self._cap_offset
+                if dense_ok and st.out is not None:
+                    # the finalise is the last node of the graph: it takes the caller's x and this call's `out`
+                    # from the table the (un-captured) replace launch of the same call publishes
+                    f.io_table = counter.data_ptr() + 16
+                    _cabi.check(self._lib.lp_finalize(ctypes.byref(f), self._stream(dev)), "lp_finalize")
+                    cap.final_in_graph = True
         finally:
             self._capturing = None
         cap.launches = self._cap_offset
@@ -576,11 +610,8 @@ class LanPaint:
         cap.rows, cap.flow = st.rows, st.flow
         cap.hyper = _cabi.LpHyper.from_buffer_copy(self._hyper)
         cap.k0_desc = st.k0_desc
-        f = _cabi.LpFinalDesc()
-        dense_ok = self._fill_final_desc(f, st, cap.final, torch.empty(0))
-        if self.rng == "philox":
-            f.rng_bump_ptr, f.rng_bump = counter.data_ptr(), cap.launches
         cap.f_desc = f
+        cap.model_options = model_options
         cap.fast = bool(dense_ok and st.k0_desc is not None and st.replace_kind_static and st.xc is st.input_x)
         if cap.fast:
             if self.rng in ("philox", "torch") and not torch_rng_used and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0":
@@ -589,7 +620,8 @@ class LanPaint:
                 except Exception:
                     cap.raw_exec = None
             c = cap.call = _cabi.LpCallDesc()          # hyper = NULL: no separate lp_coeffs launch, the replace does it
-            c.replace, c.final = ctypes.pointer(cap.k0_desc), ctypes.pointer(f)
+            c.replace = ctypes.pointer(cap.k0_desc)
+            c.final = None if cap.final_in_graph else ctypes.pointer(f)
             c.rows, c.coef_table, c.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.raw_exec
         self._graphs[key] = cap
         return cap
@@ -615,6 +647,9 @@ class LanPaint:
         st.xc = xc = _as_f32c(x)
         st.shape, st.n_el, st.rows = shape, n_el, rows = xc.shape, xc.numel(), xc.shape[0]
         st.ws = ws = ws if ws is not None else self._workspace(xc)
+        if ws.static_io and (xc.data_ptr() & 15):
+            # a captured lp_finalize writes x through the I/O table with the vector width fixed at capture time
+            st.xc = xc = xc.clone()
         st.stream = stream = self._stream(xc.device)
         st.sigma = sigma
         st.y = y = _as_f32c(self.latent_image if self.latent_image.shape == shape else self.latent_image.expand(shape))
@@ -731,9 +766,16 @@ class LanPaint:
             d.rng_state_val[0], d.rng_state_val[1] = gen.get_offset(), gen.initial_seed()
         d.flags = base_flags | self._emit(st, n_steps == 0)
         d.phases = LP_PH_REPLACE | LP_PH_EMIT | (0 if per_el else _cabi.LP_PH_COEFFS)
+        st.out = None
+        if ws.static_io and not per_el:
+            # a replayed call: its lp_finalize may be a node of the graph; this launch tells it where x and out live
+            st.out = torch.empty_like(xc)
+            d.io_table_out = self._rng_state(xc.device).data_ptr() + 16
+            d.io_table_val[0], d.io_table_val[1] = xc.data_ptr(), st.out.data_ptr()
         self._launch_step(stream)
         st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
         st.k0_desc = _cabi.LpStepDesc.from_buffer_copy(d) if ws.static_io else None
+        d.io_table_out = None          # the think-loop launches share this descriptor
         return st
 
     def _emit(self, st, final):
@@ -811,17 +853,18 @@ class LanPaint:
         f.model_out, f.y = out_model.data_ptr(), st.y.data_ptr()
         f.mask = st.m_c.data_ptr() if st.m_c is not None else st.m.data_ptr()
         f.x_src, f.x_dst, f.out = st.x_final.data_ptr(), st.xc.data_ptr(), out.data_ptr()
-        f.rng_bump_ptr, f.rng_bump = None, 0
+        f.rng_bump_ptr, f.rng_bump, f.io_table = None, 0, None
         self._final_alive = (out_model, uncond)
         return not converted
 
-    def _epilogue(self, st, final, rng_bump=None):
+    def _epilogue(self, st, final, rng_bump=None, in_graph=False):
         f, xc = self._fdesc, st.xc
-        out = torch.empty_like(xc)
-        self._fill_final_desc(f, st, final, out)
-        if rng_bump is not None:       # replayed Philox launches read a device-side sequence counter: advance it
-            f.rng_bump_ptr, f.rng_bump = rng_bump[0].data_ptr(), int(rng_bump[1])
-        _cabi.check(self._lib.lp_finalize(ctypes.byref(f), st.stream), "lp_finalize")
+        out = st.out if st.out is not None else torch.empty_like(xc)
+        if not in_graph:               # (in_graph: the replayed graph ended with its own lp_finalize, fed by the I/O table)
+            self._fill_final_desc(f, st, final, out)
+            if rng_bump is not None:   # replayed Philox launches read a device-side sequence counter: advance it
+                f.rng_bump_ptr, f.rng_bump = rng_bump[0].data_ptr(), int(rng_bump[1])
+            _cabi.check(self._lib.lp_finalize(ctypes.byref(f), st.stream), "lp_finalize")
         if xc is not st.input_x:
             st.input_x.copy_(xc)
         return out if out.dtype == st.input_x.dtype else out.to(st.input_x.dtype)

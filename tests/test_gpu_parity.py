@@ -222,6 +222,68 @@ def test_graph_replay_philox_draws_fresh_noise_each_replay():
     assert abs(np.std(xg) - np.std(xe)) < 0.25 * np.std(xe)
 
 
+def test_graph_replay_follows_hyperparameter_changes_like_the_reference():
+    """The reference reads Lambda / Beta / StepSize / MinStepFrac on every call (lanpaint.py:81,183,316): changing
+    them between sigma calls must take effect under graph replay too (they are part of the graph key)."""
+    import torch
+    from lanpaint_amd import LanPaint
+    dev, shape = "cuda", (1, 4, 16, 16)
+    g = np.random.default_rng(3)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    y, noise = tt(g.standard_normal(shape, dtype=np.float32)), tt(g.standard_normal(shape, dtype=np.float32))
+    mask = tt(gc.box_mask(shape))
+    s = torch.full((1,), 1.3, device=dev)
+    times = gc.times_from_sigma(s, False)
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(11)
+        eng = LanPaint(MODELS["linear_tuple"](), 3, 15.0, 5.0, 1.0, 0.2, rng="torch", graph=graph)
+        outs = []
+        for lamb, step, beta, msf in ((5.0, 0.2, 1.0, 0.0), (5.0, 0.2, 1.0, 0.0), (2.0, 0.2, 1.0, 0.0), (2.0, 0.1, 1.0, 0.0),
+                                      (2.0, 0.1, 0.5, 0.0), (2.0, 0.1, 0.5, 0.7), (5.0, 0.2, 1.0, 0.0)):
+            eng.chara_lamb, eng.step_size, eng.chara_beta, eng.min_step_frac = lamb, step, beta, msf
+            x = y + noise * 1.3
+            outs.append((eng(x, y, noise, s, mask, times, None, 0).cpu().numpy(), x.cpu().numpy()))
+        res[graph] = outs
+        if graph:
+            assert len(eng._graphs) == 5          # one capture per distinct hyper-parameter set
+    for (oe, xe), (og, xg) in zip(res[False], res[True]):
+        np.testing.assert_array_equal(oe, og)
+        np.testing.assert_array_equal(xe, xg)
+    assert not np.array_equal(res[True][1][0], res[True][2][0])
+
+
+def test_graph_replay_outputs_are_fresh_tensors_that_stay_valid():
+    """Multi-step samplers keep earlier `denoised` tensors (dpmpp_2m: old_denoised): every replay returns its own
+    tensor, written through the I/O table by the captured lp_finalize, and x may move between calls."""
+    import torch
+    from lanpaint_amd import LanPaint
+    dev, shape = "cuda", (2, 4, 24, 24)
+    g = np.random.default_rng(4)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    y, noise = tt(g.standard_normal(shape, dtype=np.float32)), tt(g.standard_normal(shape, dtype=np.float32))
+    mask = tt(gc.box_mask(shape))
+    s = torch.full((2,), 0.9, device=dev)
+    times = gc.times_from_sigma(s, False)
+    runs = {}
+    for graph in (False, True):
+        torch.manual_seed(5)
+        eng = LanPaint(MODELS["linear_tuple"](), 2, 15.0, 5.0, 1.0, 0.2, rng="torch", graph=graph)
+        kept, xs = [], []
+        for k in range(5):
+            x = (y + noise * 0.9 + 0.01 * k).clone()           # a new tensor (new address) every call
+            kept.append(eng(x, y, noise, s, mask, times, None, 0))
+            xs.append(x)
+        torch.cuda.synchronize()
+        assert len({t.data_ptr() for t in kept}) == 5
+        runs[graph] = ([t.cpu().numpy() for t in kept], [t.cpu().numpy() for t in xs])
+        if graph:
+            cap = next(iter(eng._graphs.values()))
+            assert cap.final_in_graph and cap.fast
+    for a, b in zip(runs[False][0] + runs[False][1], runs[True][0] + runs[True][1]):
+        np.testing.assert_array_equal(a, b)
+
+
 # ------------------------------------------------------------------ CFG combination fused into the step kernel
 @pytest.mark.parametrize("name,dtype", [("ve_basic", "float32"), ("flow_batch", "float32"), ("ve_odd_numel", "float32"),
                                         ("ve_basic", "bfloat16")])
