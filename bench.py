@@ -600,7 +600,8 @@ def extra_lines(args, dev):
         "value": iters / dt, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
         "iterations_per_step": iters // reps,
         "note": "C2 through KSamplerX0Inpaint, MinStepFrac=1.0, EarlyStop=1 (n_eff = round(5(1-abt)), last sigma 0); "
-                "includes the one host read per sigma the n_eff rule needs"}
+                "the n_eff rule needs sigma's position from the device once per sigma: read from a pinned-host mailbox, "
+                "with the replace step of the call enqueued before the host waits (begin_call / finish_call)"}
     # ---- dummy UNet backbone on the SD1.5 shape
     try:
         from tests.dummy_unet import DummyUNetBackbone

@@ -233,7 +233,9 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
  * hipGraph (the loop between the replace step and the finalise, captured by the caller):
  *     [lp_coeffs(...)] ; lp_step(replace) ; hipGraphLaunch(graph_exec, stream) ; lp_finalize(final).
  * `hyper` NULL skips the separate lp_coeffs launch (the replace descriptor then carries LP_PH_COEFFS);
- * `final` NULL skips the lp_finalize launch (it is a node of the captured graph, lp_final_desc.io_table).
+ * `final` NULL skips the lp_finalize launch (it is a node of the captured graph, lp_final_desc.io_table);
+ * `replace` NULL skips the replace launch (the caller enqueued it earlier: KSamplerX0Inpaint starts a sigma call
+ * before it knows the inner-step count and picks the graph afterwards).
  * Host-side launch cost matters at SDXL-latent sizes (the whole call is ~40 us of GPU time): four trips through
  * an FFI cost more than the kernels they start.  `graph_exec` is a hipGraphExec_t (NULL: skip the graph launch).
  * Stops at the first failing step and returns its code.                                              */
@@ -245,7 +247,7 @@ typedef struct lp_call_desc {
     const float*         t_model;       int32_t t_stride;
     int32_t              rows;
     float*               coef_table;
-    const lp_step_desc*  replace;       /* LP_PH_REPLACE | LP_PH_EMIT launch                    */
+    const lp_step_desc*  replace;       /* LP_PH_REPLACE | LP_PH_EMIT launch, or NULL           */
     void*                graph_exec;    /* hipGraphExec_t of the captured think loop, or NULL   */
     const lp_final_desc* final;         /* lp_finalize descriptor, or NULL                      */
 } lp_call_desc;
@@ -259,6 +261,12 @@ int lp_replay_call(const lp_call_desc* call, void* stream);
  * closest to mean(sigma) (first minimum), mean(1 - abt) }.                                        */
 int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
                    float* times_out, float* scalars_out, void* stream);
+/* Same launch with a mailbox: `scalars_out` may be device-visible PINNED HOST memory; after the two scalars the
+ * kernel stores `seq` to `seq_out` with a system-scope release, so a host thread polling *seq_out learns the two
+ * numbers ~2 us after the kernel ran instead of through a blocking device->host copy (the one host dependency of
+ * the per-sigma inner-step rule, nodes.py:286-299: sigma exists only on the device, in stream order).       */
+int lp_sigma_times_mailbox(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
+                           float* times_out, float* scalars_out, int32_t* seq_out, int32_t seq, void* stream);
 
 /* K0 / K_first / K2  the fused step (phases select the work).
  * Replaces: lanpaint.py:94-99 (REPLACE), :159-184 + :212-220 (score split + Coef_C),

@@ -100,6 +100,8 @@ EXPORTS = {
     "lp_coeffs": (C.c_int, [C.POINTER(LpHyper), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                             C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lp_sigma_times": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lp_sigma_times_mailbox": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int32, C.c_void_p]),
     "lp_step": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p]),
     "lp_finalize": (C.c_int, [C.POINTER(LpFinalDesc), C.c_void_p]),
     "lp_mask_blend": (C.c_int, [C.POINTER(LpBlendDesc), C.c_void_p]),

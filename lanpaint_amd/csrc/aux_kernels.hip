@@ -41,7 +41,7 @@ __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int v
 // ---------------------------------------------------------------------------------
 __global__ void lp_sigma_times_kernel(const float* __restrict__ sigma, int rows, const float* __restrict__ schedule,
                                       int schedule_len, int is_flow, float* __restrict__ times,
-                                      float* __restrict__ scalars) {
+                                      float* __restrict__ scalars, int32_t* __restrict__ seq_out, int32_t seq) {
     // plain operators under `fp contract(off)`: every * + - / below is rounded on its own, like the
     // reference's eager tensor ops (HIP's __fmul_rn/__fadd_rn are inline wrappers whose bodies keep the
     // default contract(fast) flags and DO get fused into an FMA after inlining -- measured: 1 ulp off)
@@ -89,13 +89,17 @@ __global__ void lp_sigma_times_kernel(const float* __restrict__ sigma, int rows,
     }
     scalars[0] = static_cast<float>(best);
     scalars[1] = sum_oma / static_cast<float>(rows);
+    if (seq_out) {       // mailbox in pinned host memory: the sequence number lands after the two scalars
+        __threadfence_system();
+        __hip_atomic_store(seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow,
-                         float* times, float* scalars, hipStream_t stream) {
+                         float* times, float* scalars, int32_t* seq_out, int32_t seq, hipStream_t stream) {
     if (!sigma || !schedule || !times || !scalars || rows <= 0 || schedule_len <= 0) return LP_E_INVALID;
     hipLaunchKernelGGL(lp_sigma_times_kernel, dim3(1), dim3(64), 0, stream, sigma, rows, schedule, schedule_len, is_flow,
-                       times, scalars);
+                       times, scalars, seq_out, seq);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 

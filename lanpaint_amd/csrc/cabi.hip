@@ -13,7 +13,7 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
                     int t_stride, int rows, float* table, hipStream_t stream);
 int finalize_dispatch(const lp_final_desc* d, hipStream_t stream);
 int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow, float* times,
-                         float* scalars, hipStream_t stream);
+                         float* scalars, int32_t* seq_out, int32_t seq, hipStream_t stream);
 int blend_dispatch(const lp_blend_desc* d, hipStream_t stream);
 int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream);
 int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream);
@@ -51,7 +51,15 @@ int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const
 
 int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
                    float* times_out, float* scalars_out, void* stream) {
-    return lp::sigma_times_dispatch(sigma, rows, schedule, schedule_len, is_flow, times_out, scalars_out, as_stream(stream));
+    return lp::sigma_times_dispatch(sigma, rows, schedule, schedule_len, is_flow, times_out, scalars_out, nullptr, 0,
+                                    as_stream(stream));
+}
+
+int lp_sigma_times_mailbox(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
+                           float* times_out, float* scalars_out, int32_t* seq_out, int32_t seq, void* stream) {
+    if (!seq_out) return LP_E_INVALID;
+    return lp::sigma_times_dispatch(sigma, rows, schedule, schedule_len, is_flow, times_out, scalars_out, seq_out, seq,
+                                    as_stream(stream));
 }
 
 int lp_step(const lp_step_desc* desc, void* stream) { return lp::step_dispatch(desc, as_stream(stream), nullptr); }
@@ -83,14 +91,14 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
 }
 
 int lp_replay_call(const lp_call_desc* c, void* stream) {
-    if (!c || !c->replace) return LP_E_INVALID;
+    if (!c || (!c->replace && !c->graph_exec && !c->final)) return LP_E_INVALID;    // nothing to enqueue
     hipStream_t s = as_stream(stream);
     int rc = LP_OK;
     if (c->hyper)       // NULL: the replace launch carries LP_PH_COEFFS and writes the table itself
         rc = lp::coeffs_dispatch(c->hyper, c->ve_sigma, c->ve_stride, c->abt, c->abt_stride, c->replace_sigma,
                                  c->rs_stride, nullptr, 0, c->t_model, c->t_stride, c->rows, c->coef_table, s);
     if (rc != LP_OK) return rc;
-    rc = lp::step_dispatch(c->replace, s, nullptr);
+    if (c->replace) rc = lp::step_dispatch(c->replace, s, nullptr);
     if (rc != LP_OK) return rc;
     if (c->graph_exec && hipGraphLaunch(static_cast<hipGraphExec_t>(c->graph_exec), s) != hipSuccess) return LP_E_LAUNCH;
     return c->final ? lp::finalize_dispatch(c->final, s) : LP_OK;    // NULL: lp_finalize is a node of the graph

@@ -155,6 +155,8 @@ class _CapturedCall:
         self.raw_exec = None     # hipGraphExec_t, when launching it without torch's replay() is equivalent
         self.ident = None        # what the caller passed last time (identity pre-check of the next call)
         self.final_in_graph = False   # lp_finalize is a node of the graph (reads x / out through the I/O table)
+        self.key = None               # its key in the engine's graph table (siblings differ in the step count only)
+        self.tail = None              # lp_call_desc that launches the graph alone (the replace went ahead, begin_call)
         self.model_options = None     # the dict the captured backbone calls were made with (kept alive: its id is in the key)
 
 
@@ -207,6 +209,7 @@ class LanPaint:
             raise ValueError(f"model_dtype must be None, float32, bfloat16 or float16, got {model_dtype}")
         self.model_dtype = None if model_dtype == torch.float32 else model_dtype
         self._graphs = OrderedDict()             # key -> _CapturedCall, LRU-bounded (MAX_GRAPHS)
+        self._static_ws = {}                     # (shape, device, model dtype) -> workspace shared by the captures of that shape
         self._last_cap = None                    # the capture the previous call replayed (identity pre-check)
         self._rng_counters = {}                  # device -> u64 counter read by captured Philox launches
         self._capturing = None                   # device u64 Philox counter while capturing
@@ -417,6 +420,61 @@ class LanPaint:
                            self.IS_FLOW)
         return run(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX, self.IS_FLOW)
 
+    # ------------------------------------------------------------------ split-phase call (KSamplerX0Inpaint)
+    def begin_call(self, x, latent_image, noise, sigma, latent_mask, current_times, model_options, seed):
+        """First half of `__call__` for a caller that does not know `n_steps` yet: enqueue what does not depend on it
+        -- the replace step, the VP rescale, the coefficient table, the I/O table -- and return a token for
+        `finish_call(token, n_steps)`; None when the call is not a steady-state graph replay (then use `__call__`).
+        KSamplerX0Inpaint needs the device to tell it sigma's position in the schedule (nodes.py:286-299) before it
+        can fix the inner-step count; with the head of the call already queued the GPU goes on working while the host
+        picks the graph."""
+        cap = self._last_cap
+        if cap is None or cap.tail is None or self.model_dtype is not None or not x.is_cuda:
+            return None
+        self.img_dim_size = len(x.shape)
+        self.latent_image, self.noise = latent_image, noise
+        self.audio_indicator = self.current_times_audio = self.audio_correction = None
+        self._noise_regenerated = self._noise_is_zero(noise)
+        if not self._same_call(cap, x, sigma, latent_mask, current_times, cap.ident[4], model_options, seed):
+            return None
+        lib, stream = self._lib, self._stream(x.device)
+        ve, abt = current_times[0], current_times[1]
+        out = torch.empty_like(x)
+        k0 = cap.k0_desc
+        k0.x, k0.noise = x.data_ptr(), noise.data_ptr()
+        k0.t_ve, k0.t_abt, k0.t_rsig = ve.data_ptr(), abt.data_ptr(), sigma.data_ptr()
+        k0.t_model = (current_times[2] if cap.flow else ve).data_ptr()
+        k0.io_table_val[0], k0.io_table_val[1] = k0.x, out.data_ptr()
+        off = 0
+        if self.rng == "torch":        # publish the generator state; finish_call advances it by what its graph draws
+            gen = self._generator(x.device)
+            off = gen.get_offset()
+            k0.rng_state_val[0], k0.rng_state_val[1] = off, gen.initial_seed()
+        _cabi.check(lib.lp_step(ctypes.byref(k0), stream), "lp_step")
+        return (cap, x, out, sigma, latent_mask, current_times, model_options, seed, off, stream)
+
+    def finish_call(self, token, n_steps):
+        """Second half: replay the think loop + final backbone call + finalise captured for `n_steps`."""
+        cap0, x, out, sigma, latent_mask, current_times, model_options, seed, off, stream = token
+        if n_steps is None:
+            n_steps = self.n_steps
+        cap = cap0
+        if cap0.ident[4] != n_steps:
+            cap = self._graphs.get(cap0.key[:2] + (int(n_steps),) + cap0.key[3:])
+            if cap is None or cap.tail is None or cap.model_options is not model_options or cap.ws is not cap0.ws:
+                # no capture for this count yet: the ordinary path captures it (and re-enqueues the replace step,
+                # which reads the same untouched x and publishes the same generator state)
+                return self(x, self.latent_image, self.noise, sigma, latent_mask, current_times, model_options, seed,
+                            n_steps=n_steps)
+            self._graphs.move_to_end(cap.key)
+        if self.rng == "torch" and cap.launches:
+            self._generator(x.device).set_offset(off + cap.launches)
+            self._torch_consumed += cap.launches
+        self.iterations_run += cap.ran
+        self.last_inner_steps = cap.ran
+        _cabi.check(self._lib.lp_replay_call(ctypes.byref(cap.tail), stream), "lp_replay_call")
+        return out
+
     # ------------------------------------------------------------------ hipGraph replay of one sigma call
     def _same_call(self, cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed):
         """Identity pre-check of the steady state (a sampler calls the engine once per sigma with the same
@@ -556,7 +614,16 @@ class LanPaint:
         dev = x.device
         counter = self._rng_state(dev)
         cap = _CapturedCall(counter)
-        cap.ws = _Workspace(x.detach().to(torch.float32).contiguous(), static_io=True, model_dtype=self.model_dtype)
+        # captures that differ only in the step count (KSamplerX0Inpaint's n_eff ramp) share ONE workspace: sigma
+        # calls are serialised on the stream, and the n_steps-independent replace launch can then be enqueued
+        # before the count is known (begin_call / finish_call)
+        ws_key = (tuple(x.shape), dev.index, self.model_dtype)
+        cap.ws = self._static_ws.get(ws_key)
+        if cap.ws is None:
+            if len(self._static_ws) >= self.MAX_GRAPHS:
+                self._static_ws.pop(next(iter(self._static_ws)))
+            cap.ws = self._static_ws[ws_key] = _Workspace(x.detach().to(torch.float32).contiguous(), static_io=True,
+                                                          model_dtype=self.model_dtype)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         it0 = self.iterations_run
@@ -623,6 +690,10 @@ class LanPaint:
             c.replace = ctypes.pointer(cap.k0_desc)
             c.final = None if cap.final_in_graph else ctypes.pointer(f)
             c.rows, c.coef_table, c.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.raw_exec
+            if cap.raw_exec is not None and cap.final_in_graph:
+                t = cap.tail = _cabi.LpCallDesc()      # the graph alone: its replace launch went ahead (begin_call)
+                t.rows, t.coef_table, t.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.raw_exec
+        cap.key = key
         self._graphs[key] = cap
         return cap
 

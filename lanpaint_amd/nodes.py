@@ -264,6 +264,29 @@ class KSamplerX0Inpaint:
         self.audio_indicator = None
         self.audio_shifts = None
         self._mask_cache = None          # (weakref(denoise_mask), version, latent_mask): binarised once per run
+        self._mailbox = None             # pinned host float32[4]: lp_sigma_times writes {step index, mean(1-abt), seq}
+        self._seq = 0
+
+    def _mailbox_views(self):
+        """The pinned host words the device writes the two scalars of the inner-step rule into (fine-grained host
+        memory: visible to a polling host thread right after the kernel's system-scope release)."""
+        if self._mailbox is None:
+            mb = torch.zeros(4, dtype=torch.float32).pin_memory()
+            self._mailbox = (mb, mb.numpy(), mb.view(torch.int32).numpy())
+        return self._mailbox
+
+    def _wait_mailbox(self, seq, device):
+        """Spin on the sequence word (the kernel needs a few us once the GPU reaches it); with a long backlog in
+        front of it -- a real backbone -- stop burning the core and block on the stream instead."""
+        _mb, f32, i32 = self._mailbox
+        for _ in range(20000):
+            if i32[2] == seq:
+                break
+        else:
+            torch.cuda.current_stream(device).synchronize()
+            if i32[2] != seq:
+                raise RuntimeError("lp_sigma_times mailbox was not written (sequence %d, found %d)" % (seq, int(i32[2])))
+        return float(f32[0]), float(f32[1])
 
     def _latent_mask(self, denoise_mask):
         """nodes.py:281-283, computed once per mask tensor OBJECT + version (weak reference: a
@@ -282,19 +305,22 @@ class KSamplerX0Inpaint:
         model_type = self.inner_model.inner_model.model_type
         IS_FLUX = model_type == ModelType.FLUX
         IS_FLOW = model_type in FLOW_MODEL_TYPES
-        fused_scalars = None
+        fused_seq = None
         if (sigma.is_cuda and sigma.dtype == torch.float32 and sigma.ndim == 1 and self.sigmas.is_cuda
                 and self.sigmas.dtype == torch.float32 and self.sigmas.device == sigma.device):
-            # one launch: the three time tensors AND the two scalars of the inner-step rule (lp_sigma_times)
+            # one launch: the three time tensors AND the two scalars of the inner-step rule, the latter straight into
+            # pinned host memory (lp_sigma_times_mailbox) -- no blocking device->host copy
             sig_c, sched = sigma.contiguous(), self.sigmas.contiguous()
             rows = sig_c.shape[0]
-            buf = torch.empty((3 * rows + 2,), dtype=torch.float32, device=sigma.device)
+            buf = torch.empty((3 * rows,), dtype=torch.float32, device=sigma.device)
+            mb = self._mailbox_views()[0]
+            self._seq = fused_seq = (self._seq % 0x7ffffff0) + 1
             with torch.cuda.device(sigma.device):
-                _cabi.check(_cabi.load().lp_sigma_times(
+                _cabi.check(_cabi.load().lp_sigma_times_mailbox(
                     sig_c.data_ptr(), rows, sched.data_ptr(), sched.numel(), int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
-                    buf[3 * rows:].data_ptr(), torch.cuda.current_stream(sigma.device).cuda_stream), "lp_sigma_times")
+                    mb.data_ptr(), mb.data_ptr() + 8, fused_seq, torch._C._cuda_getCurrentRawStream(sigma.device.index)),
+                    "lp_sigma_times_mailbox")
             VE_Sigma, abt, Flow_t = buf[:rows], buf[rows:2 * rows], buf[2 * rows:3 * rows]
-            fused_scalars = buf[3 * rows:]
         elif IS_FLUX or IS_FLOW:                                            # nodes.py:242-245
             Flow_t = sigma
             abt = (1 - Flow_t) ** 2 / ((1 - Flow_t) ** 2 + Flow_t ** 2)
@@ -321,10 +347,18 @@ class KSamplerX0Inpaint:
                     sigma, denoise_mask, extra_options={"model": self.inner_model, "sigmas": self.sigmas})
             latent_mask = self._latent_mask(denoise_mask)
             current_times = (VE_Sigma, abt, Flow_t)
-            # nodes.py:286-299.  Same device arithmetic as the reference; its two host syncs
-            # (argmin -> int compare, float(mean)) are fetched with ONE device->host read.
-            if fused_scalars is not None:
-                step_f, frac = fused_scalars.tolist()
+            # nodes.py:286-299.  Same device arithmetic as the reference; its two host syncs (argmin -> int
+            # compare, float(mean)) become one poll of the mailbox -- and the part of the sigma call that does not
+            # depend on the answer (replace step, coefficient table) is enqueued BEFORE the host waits for it, so
+            # the GPU still has work when the answer arrives (engine.begin_call / finish_call).
+            token = None
+            pm = self.PaintMethod
+            if fused_seq is not None:
+                if current_times_audio is None and audio_correction is None and self.audio_indicator is None \
+                        and hasattr(pm, "begin_call"):
+                    token = pm.begin_call(x, self.latent_image, self.noise, sigma, latent_mask, current_times,
+                                          model_options, seed)
+                step_f, frac = self._wait_mailbox(fused_seq, sigma.device)
             else:
                 current_step = torch.argmin(torch.abs(self.sigmas - torch.mean(sigma)))
                 step_f, frac = torch.stack([current_step.to(torch.float32), (1.0 - abt).mean().to(torch.float32)]).tolist()
@@ -334,9 +368,12 @@ class KSamplerX0Inpaint:
                 n_eff = 0
             else:
                 n_eff = min_step_frac_effective_steps(n_eff, frac, getattr(self, "LanPaint_min_step_frac", 1.0))
-            out = self.PaintMethod(x, self.latent_image, self.noise, sigma, latent_mask, current_times, model_options,
-                                   seed, n_steps=n_eff, current_times_audio=current_times_audio,
-                                   audio_indicator=self.audio_indicator, audio_correction=audio_correction)
+            if token is not None:
+                out = pm.finish_call(token, n_eff)
+            else:
+                out = pm(x, self.latent_image, self.noise, sigma, latent_mask, current_times, model_options,
+                         seed, n_steps=n_eff, current_times_audio=current_times_audio,
+                         audio_indicator=self.audio_indicator, audio_correction=audio_correction)
         else:
             out, _ = self.inner_model(x, sigma, model_options=model_options, seed=seed)
 

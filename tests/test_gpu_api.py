@@ -377,6 +377,68 @@ def test_ksampler_x0_inpaint_matches_oracle(flow):
     assert torch.equal(out, 0.9 * x)
 
 
+@pytest.mark.parametrize("flow", [False, True])
+def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow):
+    """The replayed node path (replace step enqueued before the host knows n_eff, mailbox read, graph picked
+    afterwards: engine.begin_call / finish_call) against eager launches: same n_eff sequence as the reference's rule
+    (nodes.py:286-299) and bitwise equal trajectories under a torch seed, over repeated passes of a schedule whose
+    n_eff ramps through every value."""
+    import torch
+    from lanpaint_amd import LanPaint
+    from lanpaint_amd import nodes
+    shape, n_think = (2, 4, 16, 16), 5
+    sig = gc.flow_sigmas(12) if flow else gc.karras_sigmas(12, 0.05, 12.0)
+    rng = np.random.default_rng(21)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    denoise_mask = (rng.random(shape) > 0.4).astype(np.float32)
+    x0 = (sig[0] * noise + (1 - sig[0]) * y) if flow else (y + noise * sig[0])
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+
+    class M(_DummyModel):
+        def __call__(self, x, sigma, model_options=None, seed=None):
+            self.calls += 1
+            return 0.9 * x, 0.8 * x
+
+    res = {}
+    for graph in (False, True):
+        model = M(_FlowSampling() if flow else _DummySampling())
+        model.model_type = nodes.ModelType.FLOW if flow else "EPS"
+        k = nodes.KSamplerX0Inpaint(model, tt(sig))
+        k.latent_image, k.noise = tt(y), tt(noise)
+        k.PaintMethod = LanPaint(model, n_think, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, MinStepFrac=1.0, rng="torch", graph=graph)
+        k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 1.0
+        dm, mo = tt(denoise_mask), {}
+        torch.manual_seed(77)
+        outs, n_effs, split = [], [], 0
+        for rep in range(3):                            # pass 0 captures, passes 1-2 replay through begin/finish
+            x = tt(x0)
+            for i in range(len(sig) - 1):
+                s = torch.full((shape[0],), float(sig[i]), dtype=torch.float32, device=DEV)
+                before = k.PaintMethod.iterations_run
+                tok_cap = k.PaintMethod._last_cap
+                den = k(x, s, dm, model_options=mo, seed=0)
+                n_effs.append(k.PaintMethod.iterations_run - before)
+                split += int(graph and tok_cap is not None and tok_cap.tail is not None)
+                outs.append(den)
+                x = torch.lerp(den, x, float(sig[i + 1] / sig[i]))
+        torch.cuda.synchronize()
+        res[graph] = ([o.cpu().numpy() for o in outs], x.cpu().numpy(), n_effs, model.calls, split,
+                      torch.cuda.get_rng_state(DEV).clone())
+    expect = []
+    for i in range(len(sig) - 1):
+        s = np.full((shape[0],), sig[i], dtype=np.float32)
+        expect.append(orc.effective_inner_steps(n_think, sig, float(sig[i]), float(orc.times_from_sigma(s, flow)[1].mean()), 1, 1.0))
+    assert res[False][2] == res[True][2] == expect * 3
+    assert len(set(expect)) >= 5 and 0 in expect and n_think in expect   # the ramp exercises (nearly) every graph variant
+    assert res[True][4] >= 2 * (len(sig) - 1)                            # the replays went through the split-phase path
+    assert res[True][3] < res[False][3]          # the Python backbone only ran while capturing
+    for a, b in zip(res[False][0], res[True][0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[False][1], res[True][1])
+    assert torch.equal(res[False][5], res[True][5])                      # the generator ends where eager leaves it
+
+
 # ---- argument forms the reference accepts through plain torch broadcasting -------------------------------
 def test_broadcastable_mask_scalar_sigma_and_half_latents():
     import torch
