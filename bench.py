@@ -103,13 +103,46 @@ class StubBackbone:
         return heads[0], heads[1]
 
 
+def temporal_known_frames(latent_frames):
+    """SURVEY.md 8d, C5: an 81-frame video whose second half (pixel frames >= P // 2) is inpainted, brought to the
+    latent grid as reshape_mask's video path does (nodes.py:100-122): nearest-exact frame index (ATen's fp32 formula)
+    and a 5-tap temporal union of the inpaint region.  Returns the number of leading latent frames that stay known."""
+    f = int(latent_frames)
+    p = 4 * (f - 1) + 1
+    scale = np.float32(p) / np.float32(f)
+    src = np.minimum(np.floor((np.arange(f, dtype=np.float32) + np.float32(0.5)) * scale).astype(np.int64), p - 1)
+    inpaint = src >= p // 2
+    union = np.array([inpaint[max(0, t - 2): t + 3].any() for t in range(f)])
+    return int(np.argmax(union)) if union.any() else f
+
+
+def make_mask(shape, kind=None):
+    """latent_mask (1 = known).  box: 50 % box over the last axis; temporal: the leading latent frames
+    known (video latents, C5); blob: a centred disc of inpainting covering ~38 % of every plane."""
+    kind = kind or ("temporal" if len(shape) == 5 else "box")
+    mask = np.zeros(shape, dtype=np.float32)
+    if kind == "box":
+        mask[..., : shape[-1] // 2] = 1.0
+    elif kind == "temporal":
+        mask[:, :, : temporal_known_frames(shape[2])] = 1.0
+    elif kind == "blob":
+        h, w = shape[-2], shape[-1]
+        yy, xx = np.mgrid[0:h, 0:w]
+        mask[...] = (((yy - h / 2) ** 2 + (xx - w / 2) ** 2) > (0.35 * min(h, w)) ** 2).astype(np.float32)
+    else:
+        raise ValueError(kind)
+    return mask
+
+
+MASK_KIND = None              # set from --mask; None = the workload's default (box for image latents, temporal for video)
+
+
 def make_inputs(shape, flow, sigma0, seed, device, xp):
     g = np.random.default_rng(seed)
     y = g.standard_normal(shape, dtype=np.float32)
     noise = g.standard_normal(shape, dtype=np.float32)
     x = (sigma0 * noise + (1 - sigma0) * y) if flow else (y + noise * sigma0)
-    mask = np.zeros(shape, dtype=np.float32)
-    mask[..., : shape[-1] // 2] = 1.0          # 50 % box, 1 = known
+    mask = make_mask(shape, MASK_KIND)
     return tuple(xp(a.astype(np.float32)) for a in (x, y, noise, mask))
 
 
@@ -167,6 +200,16 @@ def run_gpu(args):
         job = lpd.broadcast_job({"mask": mask, "y": y} if rank == 0 else None, src=0, device=dev)
         mask, y = job["mask"], job["y"]
         x0 = (float(sig_np[0]) * noise + (1 - float(sig_np[0])) * y) if flow else (y + noise * float(sig_np[0]))
+    if len(shape) == 5 and (args.mask or "temporal") == "temporal" and rank == 0:
+        # job set-up as a workflow does it: the pixel-resolution video mask goes through reshape_mask's video path
+        # (lp_reshape_mask: nearest-exact + 5-tap temporal union) and must give the latent mask used here
+        from lanpaint_amd import nodes as lpn
+        frames = 4 * (shape[2] - 1) + 1
+        pix = torch.zeros((frames, shape[3] * 8, shape[4] * 8), device=dev)
+        pix[frames // 2:] = 1.0                                    # ComfyUI denoise mask: 1 = inpaint
+        lat = lpn.reshape_mask(pix, (1,) + tuple(shape[1:]), video_inpainting=True)
+        assert torch.equal(1.0 - (lat > 0.5).float(), mask[:1]), "reshape_mask disagrees with the analytic temporal mask"
+        del pix, lat
     mask = attach_mask_format(mask, args.mask_format)          # once per job, outside the timed region
     b = shape[0]
     sig_list = [torch.full((b,), float(s), dtype=torch.float32, device=dev) for s in sig_np]
@@ -251,6 +294,10 @@ def run_gpu(args):
     if rank != 0:
         return
     n_el = int(np.prod(shape))
+    kind = args.mask or ("temporal" if len(shape) == 5 else "box")
+    mask_desc = {"box": "50% box mask", "blob": "centred disc mask",
+                 "temporal": f"temporal mask (second half of the video inpainted: latent frames >= "
+                             f"{temporal_known_frames(shape[2]) if len(shape) == 5 else 0} after the 5-tap union)"}[kind]
     line = {
         "metric": "langevin_think_iterations_per_sec",
         "value": iters_total / tmax,
@@ -260,7 +307,7 @@ def run_gpu(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: latent {'x'.join(map(str, shape))} per GPU, {n_sig} sigmas x "
-                               f"{n_think} think iterations, 50% box mask, stub backbone x->(0.9x,0.8x), "
+                               f"{n_think} think iterations, {mask_desc}, stub backbone x->(0.9x,0.8x), "
                                f"{'flow' if flow else 'VE/Karras'} schedule",
                    "rng": args.rng, "mask_format": args.mask_format, "launch": "hipGraph replay per sigma call" if args.graph else "eager launches",
                    "replicas": args.gpus, "iterations_per_step": n_sig * n_think,
@@ -417,8 +464,7 @@ def standalone_step(_cabi, workload, dev, phase=None):
     n_el, rows = int(np.prod(shape)), shape[0]
     g = torch.Generator(device=dev).manual_seed(0)
     bufs = {k: torch.randn(shape, device=dev, generator=g) for k in ("x", "y", "noise", "x_t", "C", "x0", "x0b", "x_in")}
-    mask = torch.zeros(shape, device=dev)
-    mask[..., : shape[-1] // 2] = 1.0
+    mask = torch.from_numpy(make_mask(shape, MASK_KIND)).to(dev)
     h = _cabi.LpHyper()
     h.lambda_, h.beta, h.step_size, h.min_step_frac = HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"], 0.0
     h.is_flow, h.one_plus_lambda = int(flow), 1.0 + HYPER["Lambda"]
@@ -432,7 +478,7 @@ def standalone_step(_cabi, workload, dev, phase=None):
     d.n_el, d.el_per_row, d.rows = n_el, n_el // rows, rows
     d.phases = phase or (_cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT)
     mask = attach_mask_format(mask, MASK_FORMAT)
-    d.flags = _cabi.LP_FL_FLOW if flow else 0
+    d.flags = (_cabi.LP_FL_FLOW if flow else 0) | (_cabi.LP_FL_NO_REGION_SKIP if os.environ.get("LANPAINT_AMD_NO_REGION_SKIP") else 0)
     d.replace_kind, d.lambda_, d.one_plus_lambda, d.beta = _cabi.LP_REPLACE_VE, h.lambda_, h.one_plus_lambda, h.beta
     d.step_size, d.noise_scale = h.step_size, 1.0
     d.coef, d.x, d.noise, d.y, d.mask = (coef.data_ptr(), bufs["x"].data_ptr(), bufs["noise"].data_ptr(),
@@ -700,6 +746,8 @@ def main():
     ap.add_argument("--mask-format", default="bits", choices=["bits", "u8", "f32"],
                     help="how the (binary) latent mask is streamed by the kernels: bit-packed once per job by "
                          "lanpaint_amd.pack_mask (what KSamplerX0Inpaint does), one byte, or the reference's fp32")
+    ap.add_argument("--mask", default=None, choices=["box", "temporal", "blob"],
+                    help="synthetic mask; default: 50 %% box for image latents, second half of the video inpainted for video latents")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -708,8 +756,8 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")
     ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")
     args = ap.parse_args()
-    global MASK_FORMAT
-    MASK_FORMAT = args.mask_format
+    global MASK_FORMAT, MASK_KIND
+    MASK_FORMAT, MASK_KIND = args.mask_format, args.mask
     run_gpu(args)
 
 

@@ -114,6 +114,8 @@ typedef struct lp_hyper {
                                           bit (i & 31) of 32-bit word (i >> 5), as lp_pack_mask writes it;
                                           0.125 B/element instead of 4.  Not combinable with MASK_DENOISE /
                                           MASK_U8; binary masks only (SURVEY 8b `mask_kind`)            */
+#define LP_FL_NO_REGION_SKIP (1u << 12) /* stream x0, x0_big and y for every element even where the bit-packed mask makes
+                                          one of them unused for a whole wave (measurement / A-B switch)       */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 

@@ -410,7 +410,7 @@ int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bi
 __global__ __launch_bounds__(256) void lp_torch_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
                                                               uint64_t offset, uint32_t bg) {
     const int64_t li = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (li < n) out[li] = torch_normal(static_cast<uint64_t>(li), seed, offset, bg);
+    if (li < n) out[li] = torch_normal(static_cast<uint64_t>(li), seed, offset, bg, n <= static_cast<int64_t>(bg));
 }
 
 int torch_normal_dispatch(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t bg, hipStream_t stream) {

@@ -61,16 +61,43 @@ __device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_
 // ATen (native/cuda/DistributionTemplates.h, distribution_elementwise_grid_stride_kernel with unroll 4): thread
 // idx = li % bg initialises Philox4x32-10 with (seed, subsequence = idx, offset), its k-th normal4 call serves
 // the elements li = idx + bg * (4 k + ii), ii = 0..3, and normal_() stores rand * std + mean with std 1, mean 0.
-__device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64_t offset, uint32_t bg) {
+// Philox4x32-10 as in Random123 / rocRAND's philox4x32_10_engine (same constants, same output order): the counter
+// is (offset / 4 [64 bit], subsequence [64 bit]), the key the seed.  Written out so that a launch evaluates exactly
+// one block per call (rocrand_init + rocrand4 carry state bookkeeping the compiler does not always drop).
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t subseq, uint64_t seed) {
+    uint32_t c0 = static_cast<uint32_t>(ctr), c1 = static_cast<uint32_t>(ctr >> 32);
+    uint32_t c2 = static_cast<uint32_t>(subseq), c3 = static_cast<uint32_t>(subseq >> 32);
+    uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// Which Philox block and which of its four normals element li of the tensor takes.  n_el <= bg (every image-sized
+// latent: bg is n_el rounded up to 256 while the grid is uncapped) means one ATen thread per element -- no 64-bit
+// division; past the grid cap bg is 256 * 2048 on this chip, a power of two.
+__device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64_t offset, uint32_t bg, bool small) {
 #pragma clang fp contract(on)
-    const uint32_t idx = static_cast<uint32_t>(li % bg);
-    const uint64_t q = li / bg;
-    rocrand_state_philox4x32_10 st;
-    rocrand_init(seed, idx, offset + 4ull * (q >> 2), &st);
-    const uint4 c = rocrand4(&st);
+    uint32_t idx, q;
+    if (small) {
+        idx = static_cast<uint32_t>(li);
+        q = 0u;
+    } else if ((bg & (bg - 1u)) == 0u) {
+        idx = static_cast<uint32_t>(li) & (bg - 1u);
+        q = static_cast<uint32_t>(li >> (31 - __builtin_clz(bg)));
+    } else {
+        idx = static_cast<uint32_t>(li % bg);
+        q = static_cast<uint32_t>(li / bg);
+    }
+    const uint4 c = philox4x32_10((offset >> 2) + (q >> 2), idx, seed);
     // rocrand_normal4 = Box-Muller on (c.x, c.y) and on (c.z, c.w); only the pair this element's value comes
     // from is transformed (the other three values belong to elements bg, 2 bg, 3 bg away)
-    const uint32_t ii = static_cast<uint32_t>(q) & 3u;
+    const uint32_t ii = q & 3u;
     const float2 r = rocrand_device::detail::box_muller(ii < 2 ? c.x : c.z, ii < 2 ? c.y : c.w);
     const float v = (ii & 1u) ? r.y : r.x;
     return v * 1.0f + 0.0f;
@@ -80,10 +107,9 @@ __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64
 // idx + 3 bg of the tensor (the `Strided` lane layout).
 __device__ __forceinline__ void torch_normal4(uint32_t idx, uint64_t seed, uint64_t offset, float (&o)[4]) {
 #pragma clang fp contract(on)
-    rocrand_state_philox4x32_10 st;
-    rocrand_init(seed, idx, offset, &st);
-    const float4 r = rocrand_normal4(&st);
-    o[0] = r.x * 1.0f + 0.0f; o[1] = r.y * 1.0f + 0.0f; o[2] = r.z * 1.0f + 0.0f; o[3] = r.w * 1.0f + 0.0f;
+    const uint4 c = philox4x32_10(offset >> 2, idx, seed);
+    const float2 a = rocrand_device::detail::box_muller(c.x, c.y), b = rocrand_device::detail::box_muller(c.z, c.w);
+    o[0] = a.x * 1.0f + 0.0f; o[1] = a.y * 1.0f + 0.0f; o[2] = b.x * 1.0f + 0.0f; o[3] = b.y * 1.0f + 0.0f;
 }
 
 // ---- 16/32-bit float conversions ----------------------------------------------

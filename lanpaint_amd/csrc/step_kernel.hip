@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         // HARD: bit-packed by dispatch; hot MODE_ROW variants: fp32 (uint8 masks are routed to PH = 0)
         const uint32_t mfl = HARD ? static_cast<uint32_t>(LP_FL_MASK_BITS) : (PH != 0 ? (fl & ~LP_FL_MASK_U8) : fl);
         load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
+        // Region-aware streams (bit-packed mask, streaming sizes): an inpaint element needs head 0 only, a known one
+        // needs head 1 and y only (lanpaint.py:182-184 with m in {0,1}).  Skipping a stream per LANE saves nothing (the
+        // wave still touches the cache lines); skipping it for the whole WAVE does: 256 consecutive elements whose
+        // mask bits are all 0 drop x0_BIG and y (36 -> 28 B/element), all 1 drop x0 (-> 32 B).  The decision is a
+        // ballot over the mask word, i.e. wave-uniform (scalar branches); the mask load is the oldest in flight, so
+        // only it is waited for -- x_t and C are issued before the decision, the conditional streams right after it.
+        // Mixed waves (mask edges, fine-grained masks) take every stream as before.
+        constexpr bool RA = HARD && VEC == 4 && !ST && (PH & kPost) != 0;
+        bool need_x0 = true, need_known = true;
         if constexpr (PER_EL) {
             load_f32<VEC>(d.abt_el, i, abt_e);
             if (!flow) load_f32<VEC>(d.ve_el, i, ve_e);
@@ -218,10 +227,17 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             load_f32<VEC>(d.x_t, i, xt);
         }
         if ((ph & LP_PH_POST_STEADY) || ((ph & LP_PH_PRE_HALF) && !post)) load_f32<VEC>(d.C, i, cv);
+        if constexpr (RA) {
+            if (!given && d.x0_big != d.x0 && !(fl & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP)) && !has_corr) {
+                const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;   // this lane's 4 mask bits
+                need_known = __ballot(nib != 0u) != 0ull;
+                need_x0 = __ballot(nib != 0xFu) != 0ull;
+            }
+        }
         if (post) {
-            load_raw_w<VEC, X0W>(d.x0, x0dt, i, x0_raw);
-            if (!(d.x0_big == d.x0 || given)) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i, x0b_raw);
-            if (!given) load_f32<VEC>(d.y, i, yv);
+            if (need_x0) load_raw_w<VEC, X0W>(d.x0, x0dt, i, x0_raw);
+            if (!(d.x0_big == d.x0 || given) && need_known) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i, x0b_raw);
+            if (!given && need_known) load_f32<VEC>(d.y, i, yv);
             if (host_post) load_f32<VEC>(d.xi_post, i, xi_a);
             if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
         }
@@ -244,11 +260,12 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                     if (draw_post) torch_normal4(static_cast<uint32_t>(g), seed, seq, xi_a);
                     if (draw_pre) torch_normal4(static_cast<uint32_t>(g), seed, off_pre, xi_b);
                 } else {
+                    const bool small = d.n_el <= static_cast<int64_t>(d.rng_bg);     // one ATen thread per element
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         const uint64_t li = static_cast<uint64_t>(elem_index(i, k));
-                        if (draw_post) xi_a[k] = torch_normal(li, seed, seq, d.rng_bg);
-                        if (draw_pre) xi_b[k] = torch_normal(li, seed, off_pre, d.rng_bg);
+                        if (draw_post) xi_a[k] = torch_normal(li, seed, seq, d.rng_bg, small);
+                        if (draw_pre) xi_b[k] = torch_normal(li, seed, off_pre, d.rng_bg, small);
                     }
                 }
             } else {

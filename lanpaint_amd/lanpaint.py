@@ -339,6 +339,40 @@ class LanPaint:
                                                              p.max_threads_per_multi_processor)
         return hit
 
+    _torch_stream_ok = {}
+
+    @classmethod
+    def _check_torch_stream(cls, device):
+        """One-time self-check per device: LP_RNG_TORCH claims to reproduce torch.randn bit for bit, which rests on
+        ATen's launch policy, rocRAND's Box-Muller and the fp-contraction mode of both builds.  Compare the kernel's
+        generator (lp_torch_normal) with torch.randn on one small tensor (one ATen thread per element) and one past
+        the grid cap (several elements per thread); the device generator is put back where it was.  False -> the
+        engine falls back to explicit torch.randn_like draws ("torch-eager": same values, separate launches)."""
+        ok = cls._torch_stream_ok.get(device.index)
+        if ok is None:
+            lib = _cabi.load()
+            state = torch.cuda.get_rng_state(device)
+            gen = cls._generator(device)
+            ok = True
+            try:
+                with torch.cuda.device(device):
+                    for n in (4099, 1 << 20):
+                        off, seed = gen.get_offset(), gen.initial_seed()
+                        ref = torch.randn(n, device=device)
+                        mine = torch.empty_like(ref)
+                        bg, _inc = cls._randn_policy(device, n)
+                        _cabi.check(lib.lp_torch_normal(mine.data_ptr(), n, seed, off, bg,
+                                                        torch.cuda.current_stream(device).cuda_stream), "lp_torch_normal")
+                        ok = ok and bool(torch.equal(ref, mine))
+            finally:
+                torch.cuda.set_rng_state(state, device)
+            cls._torch_stream_ok[device.index] = ok
+            if not ok:
+                import warnings
+                warnings.warn("lanpaint_amd: the in-kernel reproduction of torch.randn's stream does not match this torch / "
+                              "ROCm build; rng='torch' falls back to explicit torch.randn_like draws (rng='torch-eager')")
+        return ok
+
     def _fill_hyper(self, flow):
         h = self._hyper
         h.lambda_, h.beta, h.step_size = float(self.chara_lamb), float(self.chara_beta), float(self.step_size)
@@ -397,6 +431,8 @@ class LanPaint:
         if not x.is_cuda:
             raise RuntimeError("lanpaint_amd.LanPaint runs on a HIP device only (got a %s tensor); "
                                "there is no CPU fallback" % x.device.type)
+        if self.rng == "torch" and not self._check_torch_stream(x.device):
+            self.rng = "torch-eager"
         self.img_dim_size = len(x.shape)
         self.latent_image = latent_image
         self.noise = noise

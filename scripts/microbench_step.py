@@ -3,7 +3,8 @@
 combination captured in a hipGraph, replayed; reports us per launch (kernel + the dependent
 launch boundary) for the current LANPAINT_AMD_TUNE_* environment.
 
-    python scripts/microbench_step.py c2_sdxl [steady|first|last|replace] [reps] [philox|torch]
+    python scripts/microbench_step.py c2_sdxl [steady|first|last|replace] [reps] [philox|torch] [box|temporal|blob]
+(LANPAINT_AMD_NO_REGION_SKIP=1 streams every operand regardless of the mask.)
 """
 import ctypes
 import os
@@ -28,6 +29,7 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     dev = torch.device("cuda", 0)
     lib = _cabi.load()
+    bench.MASK_KIND = sys.argv[5] if len(sys.argv) > 5 else None
     d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase])
     bufs = keep[0]
     rng = sys.argv[4] if len(sys.argv) > 4 else "philox"
@@ -76,7 +78,7 @@ def main():
     bytes_ = {"steady": 36, "first": 32, "last": 36, "replace": 24}[phase] * n_el
     env = {k: v for k, v in os.environ.items() if k.startswith("LANPAINT_AMD_TUNE")}
     print(f"{wl} {phase} n_el={n_el} us/launch={us:.3f} ({bytes_ / us / 1e3:.0f} GB/s algorithmic) "
-          f"rng={rng} torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
+          f"rng={rng} mask={bench.MASK_KIND or 'default'} region_skip={0 if os.environ.get('LANPAINT_AMD_NO_REGION_SKIP') else 1} torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
 
 
 if __name__ == "__main__":

@@ -510,3 +510,40 @@ def test_torch_normal_reproduces_torch_randn_bit_for_bit(lib, n):
     assert lib.lp_torch_normal(out.data_ptr(), x.numel(), seed, off, bg, st) == 0
     assert torch.equal(out, ref)
     assert lib.lp_torch_normal(out.data_ptr(), x.numel(), seed, off + 1, bg, st) < 0      # offsets come in fours
+
+
+@pytest.mark.parametrize("kind", ["temporal", "box", "blob"])
+@pytest.mark.parametrize("phase", ["steady", "first", "last"])
+def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase):
+    """Bit-packed mask, streaming size (VEC = 4): waves whose 256 mask bits are all 0 / all 1 skip the streams their
+    region does not read (x0_BIG + y / x0).  Same launch with LP_FL_NO_REGION_SKIP: bitwise equal x_t, C, x_in --
+    on a mask of large uniform regions (temporal), one with mixed waves only (box: 52-element runs) and a disc."""
+    import torch
+    import bench
+    from lanpaint_amd import _cabi
+    dev = torch.device("cuda", 0)
+    ph = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
+          "first": _cabi.LP_PH_POST_FIRST | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
+          "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT}[phase]
+    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
+    bench.MASK_KIND, bench.MASK_FORMAT = kind, "bits"
+    try:
+        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph)
+    finally:
+        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    bufs = keep[0]
+    st = torch.cuda.current_stream().cuda_stream
+    x_t0, c0 = bufs["x_t"].clone(), bufs["C"].clone()
+    res = []
+    for extra in (0, _cabi.LP_FL_NO_REGION_SKIP):
+        bufs["x_t"].copy_(x_t0)
+        bufs["C"].copy_(c0)
+        bufs["x_in"].zero_()
+        d.flags = (d.flags & ~_cabi.LP_FL_NO_REGION_SKIP) | extra
+        d.rng_offset = 7
+        _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+        torch.cuda.synchronize()
+        res.append([bufs[k].clone() for k in ("x_t", "C", "x_in")])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][0], x_t0) and torch.isfinite(res[0][0]).all()
