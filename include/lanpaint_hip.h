@@ -116,8 +116,50 @@ typedef struct lp_hyper {
                                           MASK_U8; binary masks only (SURVEY 8b `mask_kind`)            */
 #define LP_FL_NO_REGION_SKIP (1u << 12) /* stream x0, x0_big and y for every element even where the bit-packed mask makes
                                           one of them unused for a whole wave (measurement / A-B switch)       */
+#define LP_FL_ES            (1u << 13) /* the POST phase of this launch also evaluates the inner early-stop rule ON THE DEVICE
+                                          (earlystop.py:238-336): per-block partial sums of the weighted MSEs (x0s against the
+                                          previous x0s and against the drift anchor; iteration 0: x_t after against x_t before),
+                                          reduced in a fixed order by the last block to finish, which applies the threshold /
+                                          patience / drift-anchor logic, updates lp_es_state and posts the trace record to
+                                          `es_host`.  Row-table launches only (not LP_FL_PER_ELEMENT), run-time phase kernel. */
+#define LP_FL_ES_GATED      (1u << 14) /* with LP_FL_ES, a launch of a loop the host does not watch (hipGraph replay): once
+                                          lp_es_state.stopped is set the launch only re-emits x_in from the committed x_t;
+                                          otherwise PRE_HALF is TENTATIVE -- x_t is stored in its post-iteration state, the
+                                          half-step only feeds x_in -- and a POST_STEADY launch first redoes that half-step
+                                          from the same noise (in-kernel generators only), so stopping after iteration i
+                                          leaves exactly the reference's state after i iterations.                        */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
+
+/* Device-side state of the inner early stop (one per engine and device; lp_step_desc.es).  Reset by the launch
+ * that carries `es_reset` (the replace launch of a sigma call), updated by the deciding block of every
+ * LP_FL_ES launch.  x0s_buf: three rotating buffers for LangevinState.x0 -- the stopper compares the current one
+ * with the previous one and with the drift anchor (earlystop.py:283-306), so the buffer being written is always
+ * the one that is neither.                                                                                      */
+typedef struct lp_es_state {
+    int32_t  stopped;         /* 1 once patience_counter >= patience_eff (earlystop.py:313)              */
+    int32_t  counter;         /* patience_counter                                                       */
+    int32_t  n_ran;           /* iterations whose result is committed in x_t / C                        */
+    int32_t  cur_slot;        /* x0s_buf index of the last committed iteration's x0s, -1 = none yet     */
+    int32_t  anchor_slot;     /* x0s_buf index of the drift anchor, -1 = none                           */
+    int32_t  write_slot;      /* x0s_buf index the next POST writes                                     */
+    uint32_t ticket;          /* blocks of the launch in flight that have deposited their partial sums  */
+    int32_t  enabled;         /* threshold_eff > 0 (earlystop.py:111-113); the zero-inpaint-weight test
+                                 (:115-117) is applied when the sums are known                          */
+    int64_t  seq_base;        /* mailbox sequence base of the call in flight (set at reset)             */
+    double   threshold_eff;   /* threshold * clamp01(4 abt (1 - abt)), abt = mean over rows             */
+    double   abt_val;
+    float*   x0s_buf[3];
+} lp_es_state;
+
+/* Mailbox (`es_host`, pinned host or device memory, doubles): [0] sequence word (int64 bits, stored last with a
+ * system-scope release): seq_base + i + 1 after the decision of iteration i, seq_base + LP_ES_SEQ_DONE after the
+ * last launch of a gated loop; [1] n_ran, [2] stopped, [3] enabled, [4] threshold_eff, [5] abt_val;
+ * [LP_ES_TRACE0 + 8 i ..]: record of iteration i = { dist, dist_inpaint, dist_ring, dist_drift (NaN = not
+ * evaluated), patience_counter, stopped, 0, 0 }.                                                       */
+#define LP_ES_SEQ_DONE   0x10000
+#define LP_ES_TRACE0     8
+#define LP_ES_MAILBOX_DOUBLES(n_steps) (LP_ES_TRACE0 + 8 * (n_steps))
 
 /* in-kernel noise generators */
 #define LP_RNG_PHILOX 0   /* Philox2x32-10 per element, one Box-Muller pair per launch (independent stream)  */
@@ -193,6 +235,17 @@ typedef struct lp_step_desc {
      * (lp_final_desc.io_table), so that the caller's tensors never have to be staged through static buffers. */
     uint64_t*    io_table_out;
     uint64_t     io_table_val[2];
+    /* Inner early stop on the device (LP_FL_ES; earlystop.py:58-336 with the default metric).                 */
+    lp_es_state* es;             /* device state; also given to the launch that resets it                     */
+    const float* es_ring;        /* mask-edge ring weight (lp_boundary_ring; 4-D latents), or NULL           */
+    double*      es_partials;    /* device scratch: 8 doubles per block of the launch                        */
+    double*      es_host;        /* mailbox, LP_ES_MAILBOX_DOUBLES(es_n_steps) doubles                       */
+    double       es_threshold;   /* threshold before the abt scaling (earlystop.py:78-81)                    */
+    int64_t      es_seq_base;    /* es_reset: sequence base of this call                                     */
+    int32_t      es_patience_eff;/* max(1, patience) + 1 (earlystop.py:103)                                  */
+    int32_t      es_index;       /* iteration i this launch's POST belongs to                                */
+    int32_t      es_n_steps;     /* iterations of the loop (the last launch of a gated loop posts "done")    */
+    int32_t      es_reset;       /* 1: this launch (a replace launch) initialises *es for a new call         */
 } lp_step_desc;
 
 typedef struct lp_final_desc {

@@ -28,6 +28,7 @@ LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT, 
 LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
 LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED, LP_FL_MASK_BITS, LP_FL_NO_REGION_SKIP = 256, 512, 1024, 2048, 4096
+LP_FL_ES, LP_FL_ES_GATED = 1 << 13, 1 << 14
 
 
 def mask_bits_bytes(n_el: int) -> int:
@@ -59,7 +60,19 @@ class LpStepDesc(C.Structure):
         ("rng_kind", C.c_int32), ("rng_bg", C.c_uint32), ("rng_inc", C.c_uint32),
         ("rng_state_out", C.c_void_p), ("rng_state_val", C.c_uint64 * 2),
         ("io_table_out", C.c_void_p), ("io_table_val", C.c_uint64 * 2),
+        ("es", C.c_void_p), ("es_ring", C.c_void_p), ("es_partials", C.c_void_p), ("es_host", C.c_void_p),
+        ("es_threshold", C.c_double), ("es_seq_base", C.c_int64), ("es_patience_eff", C.c_int32), ("es_index", C.c_int32),
+        ("es_n_steps", C.c_int32), ("es_reset", C.c_int32),
     ]
+
+
+class LpEsState(C.Structure):
+    _fields_ = [("stopped", C.c_int32), ("counter", C.c_int32), ("n_ran", C.c_int32), ("cur_slot", C.c_int32),
+                ("anchor_slot", C.c_int32), ("write_slot", C.c_int32), ("ticket", C.c_uint32), ("enabled", C.c_int32),
+                ("seq_base", C.c_int64), ("threshold_eff", C.c_double), ("abt_val", C.c_double), ("x0s_buf", C.c_void_p * 3)]
+
+
+LP_ES_SEQ_DONE, LP_ES_TRACE0 = 0x10000, 8
 
 
 class LpFinalDesc(C.Structure):

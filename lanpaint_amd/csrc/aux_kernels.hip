@@ -256,12 +256,6 @@ int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, in
 // K4b: { sum(w1 d^2), sum(w1), sum(w2 d^2), sum(w2) }, d = a-b, w1 = 1-mask, w2 = ring.
 // fp32 per-thread partials, double from the wave reduction upward, fixed order.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void lp_wmse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               const float* __restrict__ mask,
                                                               const float* __restrict__ ring, int64_t n_el,

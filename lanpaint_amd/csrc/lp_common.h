@@ -440,6 +440,13 @@ __device__ inline void coeffs_lane(const lp_hyper& h, float abt_f, float ve_f, f
     }
 }
 
+// fixed-order wave reduction in double (deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
 __host__ __device__ inline int x0_dtype(uint32_t flags) {
     return (flags & LP_FL_X0_BF16) ? DT_BF16 : (flags & LP_FL_X0_F16) ? DT_F16 : DT_F32;
 }

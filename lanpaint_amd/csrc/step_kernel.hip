@@ -112,6 +112,97 @@ __device__ __forceinline__ float ou_general(float x, float tau, float a, float c
     return mean + xi * sqrtf(fmaxf(var, 0.0f));
 }
 
+// ---- inner early stop on the device (earlystop.py:58-336, default metric) ----------------------------------
+constexpr int kEsSums = 6;    // { sum w1 dA^2, sum w1, sum w2 dA^2, sum w2, sum w1 dB^2, sum w2 dB^2 }
+
+__device__ __forceinline__ double clamp01(double v) { return v <= 0.0 ? 0.0 : (v >= 1.0 ? 1.0 : v); }
+
+// New sigma call: patience counter, anchor and buffer rotation start over; the abt-scaled threshold
+// (earlystop.py:21-29,105-113) is formed here from the same per-row abt the coefficient table is built from.
+// (inlined, and only into the kernels that can carry a reset: a real call would make every instantiation pay the
+// callee's register budget -- measured: 20 -> 108 VGPRs on the hot VEC = 1 kernel)
+__device__ __forceinline__ void es_reset_state(const lp_step_desc& d, bool fold) {
+    lp_es_state* es = d.es;
+    const int n = fold ? (d.t_abt_stride ? d.rows : 1) : d.rows;
+    float sum = 0.0f;
+    for (int r = 0; r < n; ++r)
+        sum = sum + (fold ? d.t_abt[static_cast<int64_t>(r) * d.t_abt_stride]
+                          : d.coef[static_cast<int64_t>(r) * LP_COEF_STRIDE + LP_C_ABT]);
+    const double abt_val = static_cast<double>(sum / static_cast<float>(n));        // float(torch.mean(abt).item())
+    const double a = clamp01(abt_val);
+    const double thr_eff = d.es_threshold * clamp01(4.0 * a * (1.0 - a));
+    es->stopped = 0; es->counter = 0; es->n_ran = 0;
+    es->cur_slot = -1; es->anchor_slot = -1; es->write_slot = 0;
+    es->ticket = 0u;
+    es->enabled = thr_eff > 0.0 ? 1 : 0;
+    es->seq_base = d.es_seq_base;
+    es->threshold_eff = thr_eff;
+    es->abt_val = abt_val;
+}
+
+__device__ __forceinline__ void es_post_seq(double* host, int64_t seq) {
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<int64_t*>(host), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The stop rule of one iteration (earlystop.py:279-313) from the six sums; one thread.
+__device__ __forceinline__ void es_decide(const lp_step_desc& d, const double (&s)[kEsSums], bool have_prev, bool have_anchor) {
+    lp_es_state* es = d.es;
+    double* host = d.es_host;
+    const bool has_ring = d.es_ring != nullptr;
+    const double nan = __builtin_nan("");
+    double dist_in = s[0] / (s[1] + 1e-12), dist_ring = nan, dist_drift = nan;
+    double dist = dist_in;
+    if (have_prev && has_ring) {
+        dist_ring = s[2] / (s[3] + 1e-12);
+        dist = dist_in > dist_ring ? dist_in : dist_ring;
+    }
+    const int i = d.es_index;
+    const bool enabled = es->enabled != 0 && s[1] >= 1e-6;          // earlystop.py:111-117
+    int counter = es->counter, anchor = es->anchor_slot, stopped = 0;
+    const int cur = es->write_slot;                                  // this iteration's x0s
+    if (enabled) {
+        const double thr = es->threshold_eff;
+        if (dist <= thr) {                                           // drift guard, :295-306
+            if (anchor < 0) {
+                anchor = cur;
+            } else if (have_anchor) {
+                const double di = s[4] / (s[1] + 1e-12);
+                const double dr = has_ring ? s[5] / (s[3] + 1e-12) : nan;
+                dist_drift = has_ring ? (di > dr ? di : dr) : di;
+                dist = dist > dist_drift ? dist : dist_drift;
+            }
+        } else {
+            anchor = -1;
+        }
+        if (dist <= thr) {
+            counter += 1;
+        } else {
+            counter = 0;
+            anchor = -1;
+        }
+        stopped = counter >= d.es_patience_eff ? 1 : 0;
+    }
+    es->counter = counter;
+    es->anchor_slot = anchor;
+    es->cur_slot = cur;
+    int w = 0;
+    while (w == cur || w == anchor) ++w;                             // the buffer that is neither
+    es->write_slot = w;
+    es->n_ran = i + 1;
+    es->stopped = stopped;
+    es->ticket = 0u;
+    if (host) {
+        double* rec = host + LP_ES_TRACE0 + 8 * i;
+        rec[0] = dist; rec[1] = dist_in; rec[2] = dist_ring; rec[3] = dist_drift;
+        rec[4] = static_cast<double>(counter); rec[5] = static_cast<double>(stopped); rec[6] = 0.0; rec[7] = 0.0;
+        host[1] = static_cast<double>(i + 1); host[2] = static_cast<double>(stopped);
+        host[3] = enabled ? 1.0 : 0.0; host[4] = es->threshold_eff; host[5] = es->abt_val;
+        const bool last = (d.flags & LP_FL_ES_GATED) && i + 1 == d.es_n_steps;
+        es_post_seq(host, es->seq_base + (last ? LP_ES_SEQ_DONE : i + 1));
+    }
+}
+
 constexpr uint32_t kPost = LP_PH_POST_FIRST | LP_PH_POST_STEADY;
 constexpr uint32_t kTouchXt = LP_PH_REPLACE | kPost | LP_PH_PRE_HALF;
 
@@ -130,13 +221,26 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // ST (with VEC = 4, RNG = 1, one batch row, n_el in (bg, 4 bg]): the lane's four elements are ATen's -- idx,
 // idx + bg, idx + 2 bg, idx + 3 bg -- so ONE Philox4x32 block and its two Box-Muller pairs serve all four, as
 // in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
-template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false>
+// ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES); run-time phase kernel only.
+template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, bool ES = false>
 __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     constexpr bool PER_EL = MODE == MODE_PER_EL;
     constexpr bool HARD = MODE == MODE_HARD;
+    static_assert(!ES || (PH == 0 && !ST && !PER_EL), "early stop runs in the run-time phase kernel, row-table modes");
     const int row = blockIdx.y;
-    const uint32_t ph = PH ? PH : d.phases;          // compile-time for the hot combinations
     const uint32_t fl = d.flags;
+    uint32_t ph_rt = PH ? PH : d.phases;             // compile-time for the hot combinations
+    bool es_gated = false, es_idle = false;
+    int es_prev = -1, es_anchor = -1, es_write = 0;
+    if constexpr (ES) {                              // wave-uniform scalar loads of the device-side stop state
+        es_gated = (fl & LP_FL_ES_GATED) != 0;
+        es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot;
+        if (es_gated && d.es->stopped != 0) {        // the loop has stopped: only re-emit x_in from the committed x_t
+            es_idle = true;
+            ph_rt = LP_PH_EMIT;
+        }
+    }
+    const uint32_t ph = ph_rt;
     const bool flow = fl & LP_FL_FLOW;
     const bool post = ph & kPost;
     const bool given = fl & LP_FL_X0S_GIVEN;
@@ -179,6 +283,9 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         d.io_table_out[0] = d.io_table_val[0];
         d.io_table_out[1] = d.io_table_val[1];
     }
+    if constexpr (PH == 0 || (PH & LP_PH_REPLACE) != 0) {
+        if (d.es_reset && d.es && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) es_reset_state(d, fold_coeffs);
+    }
 
     const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
     const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
@@ -186,8 +293,14 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     // one group per lane and no grid-stride loop: the launch covers the row (see launch()), which keeps every
     // address in this straight-line body a kernarg pointer + one offset and lets the scalar loads (coefficient
     // row, replayed-graph RNG counter) fly together with the vector loads instead of ahead of a loop
-    const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
+    const int64_t g_raw = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // ES: every lane stays for the block reduction; a lane past the end recomputes the last group and stores nothing
+    const bool active = g_raw < groups;
+    if constexpr (!ES) {
+        if (!active) return;
+    }
+    const int64_t g = active ? g_raw : groups - 1;
+    float es_p[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
         const auto i = [&] {
             if constexpr (ST) return Strided(g, static_cast<int64_t>(d.rng_bg), d.n_el);
@@ -242,6 +355,16 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
         }
         if ((ph & LP_PH_PRE_HALF) && host_pre) load_f32<VEC>(d.xi_pre, i, xi_b);
+        // early stop: the previous x0s, the drift anchor and the ring weight the metric compares against
+        float x0p[VEC], anc[VEC], rg[VEC], xi_r[VEC];
+        const bool es_redo = ES && es_gated && (ph & LP_PH_POST_STEADY);    // redo the tentative half-step of the last launch
+        if constexpr (ES) {
+            if (post) {
+                if (es_prev >= 0) load_f32<VEC>(d.es->x0s_buf[es_prev], i, x0p);
+                if (es_anchor >= 0) load_f32<VEC>(d.es->x0s_buf[es_anchor], i, anc);
+                if (d.es_ring) load_f32<VEC>(d.es_ring, i, rg);
+            }
+        }
 
         // ---- Philox + Box-Muller while the loads are in flight ----------------------------
         if (need_rng) {
@@ -266,6 +389,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                         const uint64_t li = static_cast<uint64_t>(elem_index(i, k));
                         if (draw_post) xi_a[k] = torch_normal(li, seed, seq, d.rng_bg, small);
                         if (draw_pre) xi_b[k] = torch_normal(li, seed, off_pre, d.rng_bg, small);
+                        if (es_redo) xi_r[k] = torch_normal(li, seed, seq - d.rng_inc, d.rng_bg, small);   // the last launch's PRE draw
                     }
                 }
             } else {
@@ -275,6 +399,10 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                     normal_pair(static_cast<uint64_t>(elem_index(i, k)), seq, seed, za, zb);
                     if (!host_post) xi_a[k] = za;
                     if (!host_pre) xi_b[k] = zb;
+                    if (es_redo) {                              // the sine branch of the last launch's pair
+                        normal_pair(static_cast<uint64_t>(elem_index(i, k)), seq - 1, seed, za, zb);
+                        xi_r[k] = zb;
+                    }
                 }
             }
         }
@@ -309,9 +437,43 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             }
         }
 
+        // OU(x, dt/2, C) of lanpaint.py:280 for element k (table path or the reference's own formulas)
+        auto half_step = [&](float x, float c, float xi, int k) -> float {
+            const float mk = m[k];
+            const bool table = HARD || (!PER_EL && ((mk == 0.0f) || (mk == 1.0f)));
+            if (table) {
+                if (rc.valid != 0.0f) {
+                    const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
+                    return fmaf(q.e_half, x, fmaf(q.k_half, c, q.std_half * xi));
+                }
+                return x;
+            }
+            if constexpr (!HARD) {
+                ElemCoef e;
+                if constexpr (PER_EL) {
+                    e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size, d.min_step_frac);
+                } else {
+                    e = elem_from_row(rc, mk);
+                }
+                if (e.valid) return ou_general(x, e.dt / 2.0f, e.a, c, e.d, xi);
+            }
+            return x;
+        };
+
+        float x0s[VEC], xb[VEC];
+        if constexpr (ES) {
+            if (es_redo) {          // the half-step the previous launch only emitted (same x_t, C and noise: same bits)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xt[k] = half_step(xt[k], cv[k], xi_r[k], k);
+            }
+            if (ph & LP_PH_POST_FIRST) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xb[k] = xt[k];     // x_t_before of iteration 0 (earlystop.py:288)
+            }
+        }
+
         // ---- POST: score split -> x0s, C' ; drift correction ; OU ----------------------------
         if (post) {
-            float x0s[VEC];
             if (d.x0_big == d.x0 || given) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) x0b[k] = x0[k];
@@ -387,35 +549,47 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                     }
                 }
             }
-            if (fl & LP_FL_WRITE_X0S) store_f32<VEC>(d.x0s, i, x0s);
-        }
-
-        // ---- PRE_HALF: first half-step of the next iteration (uses the new C) ------------------
-        if (ph & LP_PH_PRE_HALF) {
+            if ((fl & LP_FL_WRITE_X0S) && active) store_f32<VEC>(d.x0s, i, x0s);
+            if constexpr (ES) {
+                if (active) {
+                    store_f32<VEC>(d.es->x0s_buf[es_write], i, x0s);
+                    // weighted squared differences (earlystop.py:52-55): w1 = 1 - mask, w2 = ring
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const float mk = m[k];
-                const bool table = HARD || (!PER_EL && ((mk == 0.0f) || (mk == 1.0f)));
-                if (table) {
-                    if (rc.valid != 0.0f) {
-                        const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
-                        xt[k] = fmaf(q.e_half, xt[k], fmaf(q.k_half, cv[k], q.std_half * xi_b[k]));
+                    for (int k = 0; k < VEC; ++k) {
+                        const float w1 = 1.0f - m[k];
+                        const float w2 = d.es_ring ? rg[k] : 0.0f;
+                        const float da = es_prev >= 0 ? x0s[k] - x0p[k] : xt[k] - xb[k];
+                        const float da2 = da * da;
+                        es_p[0] += da2 * w1;
+                        es_p[1] += w1;
+                        es_p[2] += da2 * w2;
+                        es_p[3] += w2;
+                        if (es_anchor >= 0) {
+                            const float db = x0s[k] - anc[k];
+                            const float db2 = db * db;
+                            es_p[4] += db2 * w1;
+                            es_p[5] += db2 * w2;
+                        }
                     }
-                } else if constexpr (!HARD) {
-                    ElemCoef e;
-                    if constexpr (PER_EL) {
-                        e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size,
-                                            d.min_step_frac);
-                    } else {
-                        e = elem_from_row(rc, mk);
-                    }
-                    if (e.valid) xt[k] = ou_general(xt[k], e.dt / 2.0f, e.a, cv[k], e.d, xi_b[k]);
                 }
             }
         }
 
-        if (post) store_f32<VEC>(d.C, i, cv);
-        if (ph & kTouchXt) store_f32<VEC>(d.x_t, i, xt);
+        // ---- PRE_HALF: first half-step of the next iteration (uses the new C) ------------------
+        // (gated early-stop loop: tentative -- it only feeds the emit, x_t keeps the post-iteration state)
+        float xe[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) xe[k] = xt[k];
+        if (ph & LP_PH_PRE_HALF) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                xe[k] = half_step(xt[k], cv[k], xi_b[k], k);
+                if (!(ES && es_gated)) xt[k] = xe[k];
+            }
+        }
+
+        if (post && active) store_f32<VEC>(d.C, i, cv);
+        if ((ph & kTouchXt) && active) store_f32<VEC>(d.x_t, i, xt);
 
         // ---- EMIT: model-space latent for the next backbone call --------------------------------
         if (ph & LP_PH_EMIT) {
@@ -428,10 +602,58 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                 } else {
                     sc = rc.scale;
                 }
-                xo[k] = flow ? xt[k] / sc : xt[k] * sc;
+                xo[k] = flow ? xe[k] / sc : xe[k] * sc;
             }
-            store_any<VEC>(d.x_in, xindt, i, xo);
+            if (active) store_any<VEC>(d.x_in, xindt, i, xo);
         }
+    }
+
+    // ---- early stop: block partials -> last block reduces in a fixed order and applies the rule ---------------
+    if constexpr (ES) {
+        if (es_idle) {           // stopped loop: nothing to decide; its last launch tells the host the call is done
+            if (d.es_host && d.es_index + 1 == d.es_n_steps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+                es_post_seq(d.es_host, d.es->seq_base + LP_ES_SEQ_DONE);
+            return;
+        }
+        if (!post) return;
+        __shared__ double es_part[4][kEsSums];
+        __shared__ double es_red[256];
+        __shared__ int es_last;
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+        for (int k = 0; k < kEsSums; ++k) {
+            const double v = wave_sum(static_cast<double>(es_p[k]));
+            if (lane == 0) es_part[wave][k] = v;
+        }
+        __syncthreads();
+        const unsigned nblocks = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+        if (threadIdx.x < kEsSums) {
+            double v = 0.0;
+            for (unsigned w = 0; w < blockDim.x / kWave; ++w) v += es_part[w][threadIdx.x];
+            d.es_partials[static_cast<size_t>(blk) * 8 + threadIdx.x] = v;
+        }
+        __threadfence();                                         // partials visible device-wide before the ticket
+        __syncthreads();
+        if (threadIdx.x == 0) es_last = (atomicAdd(&d.es->ticket, 1u) == nblocks - 1u) ? 1 : 0;
+        __syncthreads();
+        if (!es_last) return;
+        __threadfence();
+        double tot[kEsSums];
+#pragma unroll
+        for (int k = 0; k < kEsSums; ++k) {                     // thread t: blocks t, t + 256, ...; then a fixed tree
+            double v = 0.0;
+            for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x)
+                v += __builtin_nontemporal_load(d.es_partials + static_cast<size_t>(b) * 8 + k);
+            es_red[threadIdx.x] = v;
+            __syncthreads();
+            for (unsigned sft = blockDim.x / 2; sft > 0; sft >>= 1) {
+                if (threadIdx.x < sft) es_red[threadIdx.x] += es_red[threadIdx.x + sft];
+                __syncthreads();
+            }
+            tot[k] = es_red[0];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) es_decide(d, tot, es_prev >= 0, es_anchor >= 0);
     }
 }
 
@@ -456,7 +678,7 @@ static const Tune& tune() {
     return t;
 }
 
-template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2, bool ST = false>
+template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2, bool ST = false, bool ES = false>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     const Tune& t = tune();
     const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
@@ -469,10 +691,10 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     if (bx > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
     if (timer) {
-        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST>), grid, dim3(block), 0, stream, timer->start,
+        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, timer->start,
                               timer->stop, 0, d);
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST>), grid, dim3(block), 0, stream, d);
+        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, d);
     }
     return hipGetLastError();
 }
@@ -485,6 +707,9 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     // a bit-packed mask is hard by construction; the audio correction needs the general branch
     const bool hard = (d.flags & LP_FL_MASK_BITS) && d.corr_el == nullptr;
     const bool x0_half = x0_dtype(d.flags) != DT_F32;
+    if (d.flags & LP_FL_ES)                                  // inner early stop evaluated on the device: run-time phase kernel
+        return hard ? launch<VEC, MODE_HARD, 0, 0, 2, false, true>(d, stream, timer)
+                    : launch<VEC, MODE_ROW, 0, 0, 2, false, true>(d, stream, timer);
     if (d.flags & LP_FL_MASK_U8) return launch<VEC, MODE_ROW, 0>(d, stream, timer);   // legacy format: run-time everything
     if (d.phases == (R | E))                                                         // replace step: no x0 at all
         return hard ? launch<VEC, MODE_HARD, R | E>(d, stream, timer) : launch<VEC, MODE_ROW, R | E>(d, stream, timer);
@@ -562,6 +787,14 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     }
     if ((ph & LP_PH_PRE_HALF) && !d.C) return LP_E_INVALID;
     if ((ph & LP_PH_EMIT) && !d.x_in) return LP_E_INVALID;
+    if (d.es_reset && !d.es) return LP_E_INVALID;
+    if (d.flags & LP_FL_ES) {
+        if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
+        if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator
+        if (tune().block && tune().block != 256) return LP_E_UNSUPPORTED;
+    } else if (d.flags & LP_FL_ES_GATED) {
+        return LP_E_INVALID;
+    }
 
     const size_t half_al = 8, f_al = 16;
     const bool x0_half = x0_dtype(d.flags) != DT_F32, xin_half = xin_dtype(d.flags) != DT_F32;

@@ -29,7 +29,7 @@ from functools import partial
 import torch
 
 from . import _cabi
-from ._cabi import (LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_BITS, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
+from ._cabi import (LP_FL_ES, LP_FL_ES_GATED, LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_BITS, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
                     LP_PH_EMIT, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_REPLACE, LP_REPLACE_FLOW,
                     LP_REPLACE_KNOWN, LP_REPLACE_VE)
 from .earlystop import LanPaintEarlyStopper
@@ -130,11 +130,69 @@ class _Workspace:
         return self.shape == tuple(like.shape) and self.device == like.device
 
 
+class _DeviceStop:
+    """Buffers of the inner early stop evaluated on the device (LP_FL_ES): the lp_es_state, three rotating x0s
+    buffers, the per-block partial sums and the pinned-host mailbox the deciding block posts its trace records to."""
+
+    def __init__(self, like: torch.Tensor, n_steps: int):
+        dev = like.device
+        self.shape, self.device, self.n_cap = tuple(like.shape), dev, max(8, int(n_steps))
+        self.x0s = [torch.empty_like(like) for _ in range(3)]
+        init = _cabi.LpEsState()
+        init.cur_slot = init.anchor_slot = -1
+        for k in range(3):
+            init.x0s_buf[k] = self.x0s[k].data_ptr()
+        raw = torch.frombuffer(bytearray(bytes(init)), dtype=torch.uint8)
+        self.state = torch.empty(raw.numel(), dtype=torch.uint8, device=dev)
+        self.state.copy_(raw)
+        rows = like.shape[0]
+        blocks = ((like.numel() // rows + 255) // 256) * rows
+        self.partials = torch.empty(blocks * 8, dtype=torch.float64, device=dev)
+        self.mailbox = torch.zeros(_cabi.LP_ES_TRACE0 + 8 * self.n_cap, dtype=torch.float64).pin_memory()
+        self.f64 = self.mailbox.numpy()
+        self.i64 = self.mailbox.view(torch.int64).numpy()
+        self.seq_base = 0
+        self.ring = None            # (weakref(mask), version, ring tensor | None)
+
+    def matches(self, like, n_steps):
+        return self.shape == tuple(like.shape) and self.device == like.device and n_steps <= self.n_cap
+
+    def next_seq(self):
+        self.seq_base += 2 * _cabi.LP_ES_SEQ_DONE
+        return self.seq_base
+
+    def ring_for(self, key, mask):
+        """Mask-edge ring weight (earlystop.py:32-49; 4-D latents only) of the dense fp32 `mask`, computed once per
+        mask tensor object `key` and version."""
+        c = self.ring
+        if c is None or c[0]() is not key or c[1] != key._version:
+            ring = None
+            if mask.dim() == 4:
+                ring = torch.empty_like(mask)
+                b, ch, h, w = mask.shape
+                with torch.cuda.device(mask.device):
+                    _cabi.check(_cabi.load().lp_boundary_ring(mask.data_ptr(), ring.data_ptr(), b * ch, h, w,
+                                                              torch.cuda.current_stream(mask.device).cuda_stream),
+                                "lp_boundary_ring")
+            self.ring = c = (weakref.ref(key), key._version, ring)
+        return c[2]
+
+    def wait(self, seq, device):
+        """Block until the mailbox sequence word reaches `seq` (spin briefly, then sleep on the stream)."""
+        i64 = self.i64
+        for _ in range(20000):
+            if i64[0] >= seq:
+                return
+        torch.cuda.current_stream(device).synchronize()
+        if i64[0] < seq:
+            raise RuntimeError("early-stop mailbox was not written (expected sequence %d, found %d)" % (seq, int(i64[0])))
+
+
 class _CallState:
     """Everything one sigma call carries from its prologue to its loop and epilogue."""
     __slots__ = ("input_x", "xc", "shape", "n_el", "rows", "flow", "ws", "stream", "sigma", "y", "m", "m_c", "m_flag", "abt",
                  "current_times", "base_flags", "keep", "t_model", "sigma_model", "compat", "n_steps", "x_final", "x_in",
-                 "xin_flag", "k0_desc", "replace_kind_static", "out")
+                 "xin_flag", "k0_desc", "replace_kind_static", "out", "es")
 
 
 class _CapturedCall:
@@ -155,6 +213,8 @@ class _CapturedCall:
         self.raw_exec = None     # hipGraphExec_t, when launching it without torch's replay() is equivalent
         self.ident = None        # what the caller passed last time (identity pre-check of the next call)
         self.final_in_graph = False   # lp_finalize is a node of the graph (reads x / out through the I/O table)
+        self.es = None                # early stop evaluated on the device inside the graph (LP_FL_ES_GATED): options + buffers
+        self.n_steps = 0
         self.key = None               # its key in the engine's graph table (siblings differ in the step count only)
         self.tail = None              # lp_call_desc that launches the graph alone (the replace went ahead, begin_call)
         self.model_options = None     # the dict the captured backbone calls were made with (kept alive: its id is in the key)
@@ -166,7 +226,7 @@ class LanPaint:
     # ------------------------------------------------------------------ construction
     def __init__(self, Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX=False, IS_FLOW=False,
                  EarlyStopThreshold=0.0, EarlyStopPatience=1, EarlyStopHook=None, MinStepFrac=0.0,
-                 *, rng=None, philox_seed=None, graph=None, model_dtype=None):
+                 *, rng=None, philox_seed=None, graph=None, model_dtype=None, early_stop_group=None):
         """Positional signature == reference lanpaint.py:8.  Keyword-only extras:
         rng: "torch" (default; xi = torch.randn_like in the reference's draw order, so a
              seeded run consumes the device generator exactly like the reference),
@@ -182,7 +242,10 @@ class LanPaint:
              Env LANPAINT_AMD_GRAPH=1 turns it on by default.
         model_dtype: torch.bfloat16 / torch.float16 -> the latent handed to the backbone inside the
              think loop is emitted in that dtype by the kernel (no separate cast pass); the state,
-             the written-back x and the arithmetic stay fp32."""
+             the written-back x and the arithmetic stay fp32.
+        early_stop_group: True / a ProcessGroup when ONE batch is sharded over ranks and the inner early stop must
+             take the single-process decision (its metric is defined over the whole batch, earlystop.py:52-55):
+             the partial sums are all-reduced each iteration (host-side stopper)."""
         self.n_steps = NSteps
         self.chara_lamb = Lambda
         self.IS_FLUX = IS_FLUX
@@ -221,8 +284,88 @@ class LanPaint:
         self._hyper = _cabi.LpHyper()
         self._noise_check = None                 # (weakref(noise), version, verdict)
         self._noise_regenerated = False
-        self.iterations_run = 0                  # think iterations executed (it/s accounting)
+        self._iterations_run = 0                 # think iterations executed (it/s accounting)
         self.last_inner_steps = 0
+        self.early_stop_group = early_stop_group
+        self._ds = None                          # _DeviceStop: buffers of the early stop evaluated on the device
+        self._es_opts = None                     # host-side early-stop options of the call in flight
+        self._es_pending = None                  # a replayed loop whose iteration count the device has yet to report
+
+    @property
+    def iterations_run(self):
+        """Think iterations executed so far.  A replayed loop with the inner early stop decides its length on the
+        device; reading the count waits for that report."""
+        self._es_resolve()
+        return self._iterations_run
+
+    @iterations_run.setter
+    def iterations_run(self, v):
+        self._iterations_run = v
+
+    # ------------------------------------------------------------------ inner early stop, host side
+    def _es_options(self, model_options):
+        """The part of LanPaintEarlyStopper.from_options that needs no device data (earlystop.py:63-103): threshold,
+        patience (with the legacy min_steps floor), distance_fn, trace list.  None = the inner early stop is off."""
+        opts = model_options.get("lanpaint_semantic_stop") if isinstance(model_options, dict) else None
+        threshold, patience, fn = float(self.early_stop_threshold), int(self.early_stop_patience), self.early_stop_hook
+        if isinstance(opts, dict):
+            threshold = float(opts.get("threshold", threshold))
+            patience = int(opts.get("patience", patience))
+            fn = opts.get("distance_fn", fn)
+            if patience > 0 and opts.get("min_steps") is not None:
+                try:
+                    min_steps = int(opts.get("min_steps"))
+                except (TypeError, ValueError):
+                    min_steps = 0
+                if min_steps > 1:
+                    patience = max(patience, min_steps - 1)
+        if not (threshold > 0.0 and patience > 0):
+            return None
+        trace = model_options.get("lanpaint_semantic_trace") if isinstance(model_options, dict) else None
+        tags = (None, None, None)
+        if isinstance(trace, list):
+            tags = (model_options.get("bench_case_id"), model_options.get("bench_outer_step"), model_options.get("bench_timestep"))
+        return {"threshold": threshold, "patience_eff": max(1, patience) + 1, "distance_fn": fn,
+                "trace": trace if isinstance(trace, list) else None, "tags": tags,
+                "device": not callable(fn) and self.early_stop_group is None}
+
+    def _device_stop(self, like, n_steps):
+        if self._ds is None or not self._ds.matches(like, n_steps):
+            self._ds = _DeviceStop(like, n_steps)
+        return self._ds
+
+    def _es_trace(self, es, ds, i):
+        """Append the reference's trace record of iteration i (earlystop.py:315-334) from the mailbox."""
+        trace = es["trace"]
+        if trace is None or ds.f64[3] == 0.0:
+            return
+        rec = ds.f64[_cabi.LP_ES_TRACE0 + 8 * i: _cabi.LP_ES_TRACE0 + 8 * i + 8]
+        thr_eff, opt = float(ds.f64[4]), (lambda v: None if v != v else float(v))
+        trace.append({"case_id": es["tags"][0], "outer_step": es["tags"][1], "bench_timestep": es["tags"][2],
+                      "inner_step": i + 1, "dist": float(rec[0]), "dist_inpaint": opt(rec[1]), "dist_ring": opt(rec[2]),
+                      "dist_drift": opt(rec[3]), "threshold": thr_eff, "threshold_eff": thr_eff,
+                      "patience_counter": int(rec[4]), "patience_eff": int(es["patience_eff"]), "abt": float(ds.f64[5]),
+                      "custom_dist": False, "stopped": bool(rec[5])})
+
+    def _es_resolve(self):
+        """A replayed early-stop loop reports how far it ran: wait for its "done" word, account the iterations, hand
+        over the trace records, and put torch's generator where the reference leaves it after that many iterations."""
+        p = self._es_pending
+        if p is None:
+            return
+        self._es_pending = None
+        ds, seq, n_steps, es, dev, inc = p
+        ds.wait(seq + _cabi.LP_ES_SEQ_DONE, dev)
+        n_ran = int(ds.f64[1])
+        self._iterations_run += n_ran
+        self.last_inner_steps = n_ran
+        for i in range(n_ran):
+            self._es_trace(es, ds, i)
+        if inc and n_ran < n_steps:      # the launches past the stop drew nothing the reference would have drawn
+            gen = self._generator(dev)
+            back = 2 * (n_steps - n_ran) * inc
+            gen.set_offset(gen.get_offset() - back)
+            self._torch_consumed -= back
 
     # ------------------------------------------------------------------ reference helpers
     def add_none_dims(self, array):
@@ -433,6 +576,8 @@ class LanPaint:
                                "there is no CPU fallback" % x.device.type)
         if self.rng == "torch" and not self._check_torch_stream(x.device):
             self.rng = "torch-eager"
+        self._es_resolve()
+        self._es_opts = self._es_options(model_options)
         self.img_dim_size = len(x.shape)
         self.latent_image = latent_image
         self.noise = noise
@@ -446,7 +591,7 @@ class LanPaint:
             n_steps = self.n_steps
         cap = self._last_cap
         if cap is not None and self._same_call(cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed):
-            self.iterations_run += cap.ran           # same tensors / shapes / options as the previous call:
+            self._iterations_run += cap.ran           # same tensors / shapes / options as the previous call:
             self.last_inner_steps = cap.ran          # skip the key construction, go straight to the replay
             return self._replay_fast(cap, x, sigma, current_times)
         run = self._call_graphed if self._graph_eligible(x, model_options, sigma, current_times) else self.LanPaint
@@ -506,7 +651,7 @@ class LanPaint:
         if self.rng == "torch" and cap.launches:
             self._generator(x.device).set_offset(off + cap.launches)
             self._torch_consumed += cap.launches
-        self.iterations_run += cap.ran
+        self._iterations_run += cap.ran
         self.last_inner_steps = cap.ran
         _cabi.check(self._lib.lp_replay_call(ctypes.byref(cap.tail), stream), "lp_replay_call")
         return out
@@ -550,10 +695,8 @@ class LanPaint:
             return False         # per-element times: the general path, eager only
         if self.audio_indicator is not None or self.audio_correction is not None:
             return False
-        if self.early_stop_threshold > 0.0 and self.early_stop_patience > 0:
-            return False
-        if isinstance(model_options, dict) and isinstance(model_options.get("lanpaint_semantic_stop"), dict):
-            return False
+        if self._es_opts is not None and not self._es_opts["device"]:
+            return False         # a custom distance_fn / a sharded batch keeps the stopper on the host
         if self._overridden("langevin_dynamics") or self._overridden("score_model") or \
                 self._overridden("prepare_step_size"):
             return False
@@ -569,7 +712,7 @@ class LanPaint:
         key = (tuple(x.shape), x.device.index, int(n_steps), bool(IS_FLUX), bool(IS_FLOW), self.latent_image.data_ptr(),
                latent_mask.data_ptr(), m_c.data_ptr() if m_c is not None else 0, int(sigma.numel()),
                tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng, self._hyper_key(),
-               self.model_dtype)
+               self.model_dtype, None if self._es_opts is None else (self._es_opts["threshold"], self._es_opts["patience_eff"]))
         cap = self._graphs.get(key)
         if cap is not None and cap.model_options is not model_options:
             del self._graphs[key]        # another dict at a recycled id(): the captured backbone calls used the old one
@@ -582,7 +725,7 @@ class LanPaint:
                 self._graphs.popitem(last=False)
         else:
             self._graphs.move_to_end(key)
-        self.iterations_run += cap.ran
+        self._iterations_run += cap.ran
         self.last_inner_steps = cap.ran
         srcs = (x, sigma, current_times[0], current_times[1], current_times[2], self.noise)
         if cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape \
@@ -595,14 +738,18 @@ class LanPaint:
                 self._last_cap = cap
             return self._replay_fast(cap, x, sigma, current_times)
         self._last_cap = None
-        st = self._prologue(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=cap.ws)
+        st = self._prologue(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=cap.ws,
+                            ds=cap.es["ds"] if cap.es is not None else None)
         cap.graph.replay()
         if self.rng == "torch":        # the replayed launches consumed this much of the generator's stream
             gen = self._generator(x.device)
             gen.set_offset(gen.get_offset() + cap.launches)
             self._torch_consumed += cap.launches
-        return self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None,
-                              in_graph=cap.final_in_graph)
+        out = self._epilogue(st, cap.final, rng_bump=(cap.counter, cap.launches) if self.rng == "philox" else None,
+                             in_graph=cap.final_in_graph)
+        if cap.es is not None and st.es is not None:
+            self._es_after_replay(cap, st.es["seq"], x.device)
+        return out
 
     def _replay_fast(self, cap, x, sigma, current_times):
         """Steady-state replay: the two launches around the graph (replace + coefficient table, lp_finalize) reuse
@@ -626,14 +773,30 @@ class LanPaint:
             k0.rng_state_val[0], k0.rng_state_val[1] = off, gen.initial_seed()
             gen.set_offset(off + cap.launches)
             self._torch_consumed += cap.launches
+        seq = 0
+        if cap.es is not None:         # the replace launch resets the device-side stopper for this call
+            seq = k0.es_seq_base = cap.es["ds"].next_seq()
         if cap.raw_exec is not None:
             _cabi.check(lib.lp_replay_call(ctypes.byref(cap.call), stream), "lp_replay_call")
-            return out
-        _cabi.check(lib.lp_step(ctypes.byref(k0), stream), "lp_step")
-        cap.graph.replay()
-        if not cap.final_in_graph:
-            _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
+        else:
+            _cabi.check(lib.lp_step(ctypes.byref(k0), stream), "lp_step")
+            cap.graph.replay()
+            if not cap.final_in_graph:
+                _cabi.check(lib.lp_finalize(ctypes.byref(f), stream), "lp_finalize")
+        if cap.es is not None:
+            self._es_after_replay(cap, seq, x.device)
         return out
+
+    def _es_after_replay(self, cap, seq, dev):
+        """The replayed loop decides its own length: remember what to collect.  With the trace requested, or with
+        torch's generator to be left exactly where the reference leaves it, collect it now -- ONE host read per
+        sigma call; otherwise at the next call / when iterations_run is read."""
+        es = dict(cap.es, trace=self._es_opts["trace"] if self._es_opts is not None else None,
+                  tags=self._es_opts["tags"] if self._es_opts is not None else (None, None, None))
+        inc = self._randn_policy(dev, cap.ws.x_t.numel())[1] if self.rng == "torch" else 0
+        self._es_pending = (cap.es["ds"], seq, cap.n_steps, es, dev, inc)
+        if inc or es["trace"] is not None:
+            self._es_resolve()
 
     def _rng_state(self, dev):
         """Device u64[4] read by captured launches.  rng="philox": [0] = launch-sequence base, ONE per device and
@@ -662,10 +825,13 @@ class LanPaint:
                                                           model_dtype=self.model_dtype)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        it0 = self.iterations_run
+        it0 = self._iterations_run
         rng_state = torch.cuda.get_rng_state(dev)   # warm-up + capture must not consume the user's torch stream
         gen = self._generator(dev)
         off0, own0 = gen.get_offset(), self._torch_consumed
+        es_user = self._es_opts
+        if es_user is not None:                    # the warm-up below is not the caller's run: keep it out of their trace
+            self._es_opts = dict(es_user, trace=None)
         with torch.cuda.stream(side):              # one complete eager call on the side stream: lazy inits
             xw = x.detach().clone()
             st = self._prologue(xw, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
@@ -682,10 +848,11 @@ class LanPaint:
             # the engine's in-kernel draws and the backbone's own draws would have to interleave inside the graph
             # exactly as they do eagerly: not representable with one published offset -> this engine stays eager
             torch.cuda.set_rng_state(rng_state, dev)
-            self.iterations_run = it0
+            self._iterations_run = it0
             self._graph_blocked = True
+            self._es_opts = es_user
             return None
-        self.iterations_run = it0
+        self._iterations_run = it0
         self._capturing, self._cap_offset = counter, 0
         try:
             # thread_local: a live RCCL communicator's watchdog thread issues HIP calls of its own;
@@ -705,9 +872,10 @@ class LanPaint:
         finally:
             self._capturing = None
         cap.launches = self._cap_offset
+        self._es_opts = es_user
         torch.cuda.set_rng_state(rng_state, dev)
-        cap.ran = self.iterations_run - it0
-        self.iterations_run = it0
+        cap.ran = self._iterations_run - it0
+        self._iterations_run = it0
         cap.keep = st                              # descriptor-side tensors referenced by the baked launches
         # descriptors of the three launches that stay outside the graph, for the steady-state replay path
         cap.rows, cap.flow = st.rows, st.flow
@@ -715,6 +883,7 @@ class LanPaint:
         cap.k0_desc = st.k0_desc
         cap.f_desc = f
         cap.model_options = model_options
+        cap.es, cap.n_steps = st.es, st.n_steps
         cap.fast = bool(dense_ok and st.k0_desc is not None and st.replace_kind_static and st.xc is st.input_x)
         if cap.fast:
             if self.rng in ("philox", "torch") and not torch_rng_used and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0":
@@ -746,7 +915,7 @@ class LanPaint:
         return self._epilogue(st, final)
 
     # ---- prologue: per-call descriptor, coefficient table, replace step ------------------------------------
-    def _prologue(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=None):
+    def _prologue(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=None, ds=None):
         lib, d = self._lib, self._desc
         st = _CallState()
         st.input_x = x
@@ -879,10 +1048,23 @@ class LanPaint:
             st.out = torch.empty_like(xc)
             d.io_table_out = self._rng_state(xc.device).data_ptr() + 16
             d.io_table_val[0], d.io_table_val[1] = xc.data_ptr(), st.out.data_ptr()
+        # inner early stop evaluated on the device (default metric, row-table call): this launch resets the state
+        st.es = None
+        es = self._es_opts
+        d.es, d.es_reset = None, 0
+        if es is not None and es["device"] and not per_el and not st.compat and corr is None and n_steps > 0:
+            ds = ds if ds is not None else self._device_stop(xc, n_steps)
+            ring = ds.ring_for(latent_mask if latent_mask.shape == shape else m, m)
+            st.es = dict(es, ds=ds, seq=ds.next_seq(), ring=ring)
+            d.es, d.es_reset, d.es_seq_base = ds.state.data_ptr(), 1, st.es["seq"]
+            d.es_threshold, d.es_patience_eff, d.es_n_steps = es["threshold"], es["patience_eff"], n_steps
+            d.es_host, d.es_partials = ds.mailbox.data_ptr(), ds.partials.data_ptr()
+            d.es_ring = ring.data_ptr() if ring is not None else None
         self._launch_step(stream)
         st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
         st.k0_desc = _cabi.LpStepDesc.from_buffer_copy(d) if ws.static_io else None
         d.io_table_out = None          # the think-loop launches share this descriptor
+        d.es_reset = 0
         return st
 
     def _emit(self, st, final):
@@ -900,17 +1082,21 @@ class LanPaint:
         # a replayed capture bakes the descriptor of every launch: re-point the per-call fields it reads
         d.n_el, d.el_per_row, d.rows = st.n_el, st.n_el // st.rows, st.rows
         stopper = None
-        if self._capturing is None:
+        if self._capturing is None and st.es is None:
             stopper = LanPaintEarlyStopper.from_options(
                 model_options=model_options if isinstance(model_options, dict) else None, latent_mask=st.m, abt=st.abt,
                 default_threshold=self.early_stop_threshold, default_patience=self.early_stop_patience,
                 default_distance_fn=self.early_stop_hook)
+            if stopper is not None and self.early_stop_group is not None:
+                stopper.metric.reduce_group = self.early_stop_group       # one batch sharded over ranks
         ran = 0
         if st.compat:
             ran = self._loop_compat(ws, shape, st.m, st.y, st.abt, st.current_times, n_steps, model_options, seed, stopper)
             d.phases = LP_PH_EMIT
             d.flags = base_flags | self._emit(st, True)
             self._launch_step(stream)
+        elif st.es is not None:
+            ran = self._loop_es(st, n_steps, model_options, seed)
         elif stopper is not None:
             ran = self._loop_unfused(st, n_steps, model_options, seed, stopper)
         else:
@@ -923,7 +1109,7 @@ class LanPaint:
                 self._launch_step(stream)
                 del alive
             ran = n_steps
-        self.iterations_run += ran
+        self._iterations_run += ran
         self.last_inner_steps = ran
         x_model = st.x_final if self.model_dtype is None else st.x_final.to(self.model_dtype)
         return self.inner_model(x_model, st.sigma_model, model_options=model_options, seed=seed)     # lanpaint.py:151-153
@@ -1025,6 +1211,50 @@ class LanPaint:
         buf = torch.empty_like(ws.x_t)
         ws.x0s.append(buf)
         return buf
+
+    def _loop_es(self, st, n_steps, model_options, seed):
+        """Inner early stop with the default metric, evaluated on the device (LP_FL_ES): the POST launch of every
+        iteration also reduces the weighted MSEs of earlystop.py:279-306 and applies the threshold / patience /
+        drift-anchor rule in its last block.
+        Eager: the host reads the verdict from the pinned mailbox once per iteration and leaves the loop like the
+        reference does (no backbone call is wasted); the PRE half-step of the next iteration is a launch of its own.
+        Captured (hipGraph): nobody watches -- the launches are gated on the device-side flag (LP_FL_ES_GATED), keep
+        the fused one-launch-per-iteration shape, and the backbone calls after the stop still run (their results are
+        ignored).  Returns the iterations run (0 while capturing: the replay reports it, _es_resolve)."""
+        d, ws, shape, base_flags, stream = self._desc, st.ws, st.shape, st.base_flags, st.stream
+        es, ds = st.es, st.es["ds"]
+        d.es_n_steps = n_steps
+        gated = self._capturing is not None
+        ran = 0
+        for i in range(n_steps):
+            last = i == n_steps - 1
+            if i > 0 and not gated:                   # first half-step of iteration i, committed (lanpaint.py:280)
+                d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags | self._emit(st, False)
+                self._set_xi(d, ws.x_t, want_pre=True, want_post=False)
+                self._launch_step(stream)
+            output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
+            if gated:
+                alive = self._set_model_output(d, output, base_flags | LP_FL_ES | LP_FL_ES_GATED | self._emit(st, last), shape)
+                d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
+                self._set_xi(d, ws.x_t, want_pre=not last)
+            else:
+                alive = self._set_model_output(d, output, base_flags | LP_FL_ES, shape)
+                d.phases = LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY
+                self._set_xi(d, ws.x_t, want_pre=False)
+            d.es_index = i
+            self._launch_step(stream)
+            del alive
+            if gated:
+                continue
+            ds.wait(es["seq"] + i + 1, st.xc.device)
+            ran += 1
+            self._es_trace(es, ds, i)
+            if ds.f64[2] != 0.0:                      # stopped
+                break
+        if not gated:
+            d.phases, d.flags = LP_PH_EMIT, base_flags | self._emit(st, True)
+            self._launch_step(stream)
+        return ran
 
     def _loop_unfused(self, st, n_steps, model_options, seed, stopper):
         """Early stop enabled: the stopper decides after every iteration, so the POST

@@ -284,6 +284,63 @@ def test_graph_replay_outputs_are_fresh_tensors_that_stay_valid():
         np.testing.assert_array_equal(a, b)
 
 
+# ------------------------------------------------------------------ inner early stop decided on the device
+@pytest.mark.parametrize("name", sorted(EARLYSTOP))
+@pytest.mark.parametrize("rng", ["torch", "philox"])
+def test_early_stop_inside_a_replayed_graph_equals_the_host_watched_loop(name, rng):
+    """Graph replay cannot ask the host after every iteration: its launches are gated on the device-side stop flag
+    (LP_FL_ES_GATED: tentative half-step, redone by the next launch from the same noise).  Against the eager loop,
+    which reads the verdict from the mailbox each iteration and is pinned to the reference's golden traces above:
+    same iteration count, same trace, bitwise the same x / out, and torch's generator left in the same place --
+    over several sigma calls (replays) with the stop landing on different iterations."""
+    import torch
+    from lanpaint_amd import LanPaint
+    case = gc.build_case(name)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")   # noqa: E731
+    h = case["hyper"]
+    stop = case["model_options"]["lanpaint_semantic_stop"]
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(4242)
+        model = MODELS[case["model"]](flow=case["flow"] or case["flux"])
+        eng = LanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], IS_FLUX=case["flux"],
+                       IS_FLOW=case["flow"], MinStepFrac=h["MinStepFrac"], rng=rng, philox_seed=9, graph=graph)
+        y, noise, mask = tt(case["y"]), tt(case["noise"]), tt(case["mask"])
+        times = tuple(tt(t) for t in case["times"])
+        sig = tt(case["sigma"])
+        runs = []
+        for rep in range(4):
+            mo = {"lanpaint_semantic_stop": dict(stop), "lanpaint_semantic_trace": []} if rep != 2 else \
+                {"lanpaint_semantic_stop": dict(stop)}
+            x = tt(case["x"] + np.float32(0.05 * rep))
+            it0 = eng.iterations_run
+            out = eng(x, y, noise, sig, mask, times, mo, 0, n_steps=case["n_steps"])
+            ran = eng.iterations_run - it0
+            tr = mo.get("lanpaint_semantic_trace", [])
+            runs.append((x.cpu().numpy(), out.cpu().numpy(), ran,
+                         [(t["inner_step"], t["patience_counter"], t["stopped"]) for t in tr],
+                         [t["dist"] for t in tr], int(torch.cuda.default_generators[0].get_offset())))
+        res[graph] = runs
+        if graph:
+            assert len(eng._graphs) >= 1 and all(c.es is not None for c in eng._graphs.values())
+    n = case["n_steps"] if case["n_steps"] is not None else h["NSteps"]
+    for e, g in zip(res[False], res[True]):
+        for r in (e, g):
+            assert 1 <= r[2] <= n and np.isfinite(r[0]).all() and np.isfinite(r[1]).all()
+            assert len(r[3]) in (0, r[2]) and [t[0] for t in r[3]] == list(range(1, len(r[3]) + 1))
+            assert all(not t[2] for t in r[3][:-1])                  # only the last record may say "stopped"
+        if rng == "torch":                       # same noise stream -> the very same bits, generator state included
+            assert e[2] == g[2] and e[3] == g[3]
+            np.testing.assert_allclose(e[4], g[4], rtol=1e-12)
+            np.testing.assert_array_equal(e[0], g[0])
+            np.testing.assert_array_equal(e[1], g[1])
+            assert e[5] == g[5]
+    if name == "ve_earlystop_run_all":
+        assert all(r[2] == n for r in res[True])
+    else:
+        assert any(r[2] < n for r in res[True])
+
+
 # ------------------------------------------------------------------ CFG combination fused into the step kernel
 @pytest.mark.parametrize("name,dtype", [("ve_basic", "float32"), ("flow_batch", "float32"), ("ve_odd_numel", "float32"),
                                         ("ve_basic", "bfloat16")])
