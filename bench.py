@@ -183,9 +183,23 @@ def run_gpu(args):
     # Per-dispatch event timing of the dominant kernel, taken FIRST in the process: the same burst repeated after
     # graph captures / other streams exist reads ~1.2 us higher at the video-latent size (11.4 vs 10.2 us) although
     # rocprofv3 shows the same 10.5-10.7 us per dispatch in both places -- event bookkeeping, not the kernel.
-    pre_busy = pre_large = None
+    pre_busy = pre_large = pre_past = None
     if rank == 0:
         try:
+            if world == 1 and not args.no_large_shape:
+                # 1.2 GB per launch: nothing of it survives in the 256 MiB Infinity Cache between launches.
+                # Every operand streamed (what SURVEY.md 8d's 36 B / element describes) ...
+                pre_past = measure_hbm_bound_shape(_cabi, dev, workload="x_wan_b16", launches=24, every_stream=True)
+                # ... and as shipped: waves whose mask bits are uniform skip the streams their region never reads
+                ra = measure_hbm_bound_shape(_cabi, dev, workload="x_wan_b16", launches=24)
+                pre_past["region_aware_streams"] = {
+                    k: ra[k] for k in ("mean_launch_us", "rocprofv3_mean_launch_us", "duration_used_us", "traffic", "achieved",
+                                       "frac", "hbm_side_GBps")}
+                pre_past["region_aware_streams"]["note"] = (
+                    "same launch with the wave-uniform stream skipping on (the default): fewer bytes than the algorithmic "
+                    "36 B / element have to move, so `achieved` (algorithmic bytes / duration) can exceed what HBM delivers; "
+                    "hbm_side_GBps = PMC traffic / duration is the HBM-side rate")
+                torch.cuda.empty_cache()
             if world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
                 pre_large = measure_hbm_bound_shape(_cabi, dev)      # the bandwidth-bound shape is the sensitive one
             pre_busy = measure_hbm_bound_shape(_cabi, dev, workload=args.workload, launches=120)
@@ -272,11 +286,7 @@ def run_gpu(args):
             large = pre_large if pre_large is not None else measure_hbm_bound_shape(_cabi, dev)
         except Exception as e:
             large = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_large_shape:
-        try:      # 1.2 GB per launch: nothing of it survives in the 256 MiB Infinity Cache between launches
-            past_l3 = measure_hbm_bound_shape(_cabi, dev, workload="x_wan_b16", launches=24)
-        except Exception as e:
-            past_l3 = {"error": repr(e)}
+    past_l3 = pre_past
     if rank == 0 and world == 1 and args.extras:
         try:
             extras = extra_lines(args, dev)
@@ -525,13 +535,15 @@ def graph_burst_us_per_launch(_cabi, workload, dev, reps=200, replays=20):
     return us
 
 
-def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
+def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60, every_stream=False):
     """Supplementary evidence: the same steady-state kernel on the video-latent shape (75 MB of
     algorithmic traffic per launch -- the regime where the kernel is bandwidth bound, not launch
     bound), launched back to back through lp_step_timed."""
     import ctypes
     lib = _cabi.load()
     d, keep, n_el = standalone_step(_cabi, workload, dev)
+    if every_stream:
+        d.flags |= _cabi.LP_FL_NO_REGION_SKIP
     st = torch.cuda.current_stream(dev).cuda_stream
     for k in range(10):
         d.rng_offset = k
@@ -556,7 +568,8 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
     bytes_per_launch = BYTES_PER_EL_STEADY * n_el
     shape = WORKLOADS[workload][0]
     del keep
-    event_us, prof_us = float(durs.mean()) * 1e6, rocprof_duration(workload)
+    prof_key = workload + ("_every_stream" if every_stream else "")
+    event_us, prof_us = float(durs.mean()) * 1e6, rocprof_duration(prof_key)
     used_us = max(event_us, prof_us or 0.0)          # the more conservative of this run's events and the committed trace
     achieved = bytes_per_launch / (used_us * 1e-6) / 1e9
     working_set = 9 * 4 * n_el                        # the nine fp32 streams of the steady launch
@@ -567,7 +580,8 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60):
             "regime": regime, "working_set_bytes": working_set,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "frac_vs_6290": achieved / 6290.0, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "traffic": pmc_traffic(workload), "duration_used_us": used_us, "rocprofv3_mean_launch_us": prof_us,
+            "traffic": pmc_traffic(prof_key), "duration_used_us": used_us, "rocprofv3_mean_launch_us": prof_us,
+            "hbm_side_GBps": (pmc_traffic(prof_key) / (used_us * 1e-6) / 1e9) if pmc_traffic(prof_key) else None,
             "mean_launch_us": event_us, "median_launch_us": float(np.median(durs)) * 1e6,
             "min_launch_us": float(durs.min()) * 1e6, "launches_timed": int(durs.size)}
 
@@ -609,6 +623,33 @@ def extra_lines(args, dev):
                         "torch.randn_like(x_t) returns for the device generator, bit for bit, generated in-kernel"}
         except Exception as e:
             out["reference_noise_stream"] = {"error": repr(e)}
+    # ---- the headline workload with the inner early stop armed but never firing (threshold far below any distance):
+    # what the device-side stop rule costs per iteration (LP_FL_ES: three more streams, the block reduction, the decision)
+    try:
+        shape, flow, n_sig, n_think = WORKLOADS[args.workload]
+        sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
+        x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed, dev, tt)
+        mask = attach_mask_format(mask, args.mask_format)
+        sig_list = [torch.full((shape[0],), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+        times_list = [times_from_sigma(s, flow) for s in sig_list]
+        ratios = euler_ratios(sig_list, len(shape))
+        eng = LanPaint(StubBackbone(flow), n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
+                       IS_FLOW=flow, EarlyStopThreshold=1e-30, EarlyStopPatience=1, rng=args.rng, philox_seed=args.seed,
+                       graph=bool(args.graph))
+        for _ in range(5):
+            schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        torch.cuda.synchronize()
+        it0, t0, reps = eng.iterations_run, time.perf_counter(), max(5, args.steps // 4)
+        for _ in range(reps):
+            schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["inner_early_stop_armed"] = {
+            "value": (eng.iterations_run - it0) / dt, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
+            "note": f"{args.workload} as in the headline with EarlyStopThreshold > 0 (never reached): the stop rule is "
+                    "evaluated on the device inside every replayed launch, no host read in the loop"}
+    except Exception as e:
+        out["inner_early_stop_armed"] = {"error": repr(e)}
     # ---- node-default schedule through the sampler-facing callable
     shape, flow, n_sig, n_think = WORKLOADS["c2_sdxl"]
     sig_np = karras_sigmas(n_sig)

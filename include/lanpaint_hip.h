@@ -118,10 +118,10 @@ typedef struct lp_hyper {
                                           one of them unused for a whole wave (measurement / A-B switch)       */
 #define LP_FL_ES            (1u << 13) /* the POST phase of this launch also evaluates the inner early-stop rule ON THE DEVICE
                                           (earlystop.py:238-336): per-block partial sums of the weighted MSEs (x0s against the
-                                          previous x0s and against the drift anchor; iteration 0: x_t after against x_t before),
-                                          reduced in a fixed order by the last block to finish, which applies the threshold /
-                                          patience / drift-anchor logic, updates lp_es_state and posts the trace record to
-                                          `es_host`.  Row-table launches only (not LP_FL_PER_ELEMENT), run-time phase kernel. */
+                                          previous x0s and against the drift anchor; iteration 0: x_t after against x_t before);
+                                          lp_step then enqueues a one-block kernel that reduces them in a fixed order, applies
+                                          the threshold / patience / drift-anchor logic, updates lp_es_state and posts the
+                                          trace record to `es_host`.  Row-table launches only (not LP_FL_PER_ELEMENT).       */
 #define LP_FL_ES_GATED      (1u << 14) /* with LP_FL_ES, a launch of a loop the host does not watch (hipGraph replay): once
                                           lp_es_state.stopped is set the launch only re-emits x_in from the committed x_t;
                                           otherwise PRE_HALF is TENTATIVE -- x_t is stored in its post-iteration state, the
@@ -143,10 +143,12 @@ typedef struct lp_es_state {
     int32_t  cur_slot;        /* x0s_buf index of the last committed iteration's x0s, -1 = none yet     */
     int32_t  anchor_slot;     /* x0s_buf index of the drift anchor, -1 = none                           */
     int32_t  write_slot;      /* x0s_buf index the next POST writes                                     */
-    uint32_t ticket;          /* blocks of the launch in flight that have deposited their partial sums  */
+    uint32_t reserved0;
     int32_t  enabled;         /* threshold_eff > 0 (earlystop.py:111-113); the zero-inpaint-weight test
                                  (:115-117) is applied when the sums are known                          */
     int64_t  seq_base;        /* mailbox sequence base of the call in flight (set at reset)             */
+    int64_t  total_ran;       /* iterations committed since the state was created (never reset): lets a
+                                 host that does not wait after every call account them later             */
     double   threshold_eff;   /* threshold * clamp01(4 abt (1 - abt)), abt = mean over rows             */
     double   abt_val;
     float*   x0s_buf[3];
@@ -154,7 +156,7 @@ typedef struct lp_es_state {
 
 /* Mailbox (`es_host`, pinned host or device memory, doubles): [0] sequence word (int64 bits, stored last with a
  * system-scope release): seq_base + i + 1 after the decision of iteration i, seq_base + LP_ES_SEQ_DONE after the
- * last launch of a gated loop; [1] n_ran, [2] stopped, [3] enabled, [4] threshold_eff, [5] abt_val;
+ * last launch of a gated loop; [1] n_ran, [2] stopped, [3] enabled, [4] threshold_eff, [5] abt_val, [6] total_ran;
  * [LP_ES_TRACE0 + 8 i ..]: record of iteration i = { dist, dist_inpaint, dist_ring, dist_drift (NaN = not
  * evaluated), patience_counter, stopped, 0, 0 }.                                                       */
 #define LP_ES_SEQ_DONE   0x10000
@@ -237,6 +239,8 @@ typedef struct lp_step_desc {
     uint64_t     io_table_val[2];
     /* Inner early stop on the device (LP_FL_ES; earlystop.py:58-336 with the default metric).                 */
     lp_es_state* es;             /* device state; also given to the launch that resets it                     */
+    float*       es_x0s[3];      /* the three rotating x0s buffers (== es->x0s_buf, as launch arguments so the kernel
+                                    selects one by slot index instead of chasing a pointer through the state)     */
     const float* es_ring;        /* mask-edge ring weight (lp_boundary_ring; 4-D latents), or NULL           */
     double*      es_partials;    /* device scratch: 8 doubles per block of the launch                        */
     double*      es_host;        /* mailbox, LP_ES_MAILBOX_DOUBLES(es_n_steps) doubles                       */

@@ -60,7 +60,7 @@ class LpStepDesc(C.Structure):
         ("rng_kind", C.c_int32), ("rng_bg", C.c_uint32), ("rng_inc", C.c_uint32),
         ("rng_state_out", C.c_void_p), ("rng_state_val", C.c_uint64 * 2),
         ("io_table_out", C.c_void_p), ("io_table_val", C.c_uint64 * 2),
-        ("es", C.c_void_p), ("es_ring", C.c_void_p), ("es_partials", C.c_void_p), ("es_host", C.c_void_p),
+        ("es", C.c_void_p), ("es_x0s", C.c_void_p * 3), ("es_ring", C.c_void_p), ("es_partials", C.c_void_p), ("es_host", C.c_void_p),
         ("es_threshold", C.c_double), ("es_seq_base", C.c_int64), ("es_patience_eff", C.c_int32), ("es_index", C.c_int32),
         ("es_n_steps", C.c_int32), ("es_reset", C.c_int32),
     ]
@@ -68,8 +68,8 @@ class LpStepDesc(C.Structure):
 
 class LpEsState(C.Structure):
     _fields_ = [("stopped", C.c_int32), ("counter", C.c_int32), ("n_ran", C.c_int32), ("cur_slot", C.c_int32),
-                ("anchor_slot", C.c_int32), ("write_slot", C.c_int32), ("ticket", C.c_uint32), ("enabled", C.c_int32),
-                ("seq_base", C.c_int64), ("threshold_eff", C.c_double), ("abt_val", C.c_double), ("x0s_buf", C.c_void_p * 3)]
+                ("anchor_slot", C.c_int32), ("write_slot", C.c_int32), ("reserved0", C.c_uint32), ("enabled", C.c_int32),
+                ("seq_base", C.c_int64), ("total_ran", C.c_int64), ("threshold_eff", C.c_double), ("abt_val", C.c_double), ("x0s_buf", C.c_void_p * 3)]
 
 
 LP_ES_SEQ_DONE, LP_ES_TRACE0 = 0x10000, 8

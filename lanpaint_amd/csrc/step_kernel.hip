@@ -133,7 +133,6 @@ __device__ __forceinline__ void es_reset_state(const lp_step_desc& d, bool fold)
     const double thr_eff = d.es_threshold * clamp01(4.0 * a * (1.0 - a));
     es->stopped = 0; es->counter = 0; es->n_ran = 0;
     es->cur_slot = -1; es->anchor_slot = -1; es->write_slot = 0;
-    es->ticket = 0u;
     es->enabled = thr_eff > 0.0 ? 1 : 0;
     es->seq_base = d.es_seq_base;
     es->threshold_eff = thr_eff;
@@ -145,9 +144,11 @@ __device__ __forceinline__ void es_post_seq(double* host, int64_t seq) {
     __hip_atomic_store(reinterpret_cast<int64_t*>(host), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// The stop rule of one iteration (earlystop.py:279-313) from the six sums; one thread.
-__device__ __forceinline__ void es_decide(const lp_step_desc& d, const double (&s)[kEsSums], bool have_prev, bool have_anchor) {
-    lp_es_state* es = d.es;
+// The stop rule of one iteration (earlystop.py:279-313) from the six sums; one thread.  `st` is the state as ONE
+// block load at the top of the deciding kernel (field-by-field reads through the pointer cost a memory round trip
+// each: 9 -> ~5 us per iteration at SDXL size), updated in registers and written back by the caller.
+__device__ __forceinline__ void es_decide(const lp_step_desc& d, lp_es_state& st, const double (&s)[kEsSums], bool have_prev,
+                                          bool have_anchor) {
     double* host = d.es_host;
     const bool has_ring = d.es_ring != nullptr;
     const double nan = __builtin_nan("");
@@ -158,11 +159,11 @@ __device__ __forceinline__ void es_decide(const lp_step_desc& d, const double (&
         dist = dist_in > dist_ring ? dist_in : dist_ring;
     }
     const int i = d.es_index;
-    const bool enabled = es->enabled != 0 && s[1] >= 1e-6;          // earlystop.py:111-117
-    int counter = es->counter, anchor = es->anchor_slot, stopped = 0;
-    const int cur = es->write_slot;                                  // this iteration's x0s
+    const bool enabled = st.enabled != 0 && s[1] >= 1e-6;           // earlystop.py:111-117
+    int counter = st.counter, anchor = st.anchor_slot, stopped = 0;
+    const int cur = st.write_slot;                                   // this iteration's x0s
     if (enabled) {
-        const double thr = es->threshold_eff;
+        const double thr = st.threshold_eff;
         if (dist <= thr) {                                           // drift guard, :295-306
             if (anchor < 0) {
                 anchor = cur;
@@ -183,23 +184,27 @@ __device__ __forceinline__ void es_decide(const lp_step_desc& d, const double (&
         }
         stopped = counter >= d.es_patience_eff ? 1 : 0;
     }
-    es->counter = counter;
-    es->anchor_slot = anchor;
-    es->cur_slot = cur;
+    st.counter = counter;
+    st.anchor_slot = anchor;
+    st.cur_slot = cur;
     int w = 0;
     while (w == cur || w == anchor) ++w;                             // the buffer that is neither
-    es->write_slot = w;
-    es->n_ran = i + 1;
-    es->stopped = stopped;
-    es->ticket = 0u;
+    st.write_slot = w;
+    st.n_ran = i + 1;
+    st.total_ran += 1;
+    st.stopped = stopped;
     if (host) {
         double* rec = host + LP_ES_TRACE0 + 8 * i;
         rec[0] = dist; rec[1] = dist_in; rec[2] = dist_ring; rec[3] = dist_drift;
         rec[4] = static_cast<double>(counter); rec[5] = static_cast<double>(stopped); rec[6] = 0.0; rec[7] = 0.0;
         host[1] = static_cast<double>(i + 1); host[2] = static_cast<double>(stopped);
-        host[3] = enabled ? 1.0 : 0.0; host[4] = es->threshold_eff; host[5] = es->abt_val;
-        const bool last = (d.flags & LP_FL_ES_GATED) && i + 1 == d.es_n_steps;
-        es_post_seq(host, es->seq_base + (last ? LP_ES_SEQ_DONE : i + 1));
+        host[3] = enabled ? 1.0 : 0.0; host[4] = st.threshold_eff; host[5] = st.abt_val;
+        host[6] = static_cast<double>(st.total_ran);
+        // a watched loop (eager) hears about every iteration; a gated one only when its last launch has run -- the
+        // system-scope fence in front of the sequence word waits for the PCIe writes above (~3 us per launch)
+        const bool gated = (d.flags & LP_FL_ES_GATED) != 0;
+        if (!gated) es_post_seq(host, st.seq_base + i + 1);
+        else if (i + 1 == d.es_n_steps) es_post_seq(host, st.seq_base + LP_ES_SEQ_DONE);
     }
 }
 
@@ -360,8 +365,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         const bool es_redo = ES && es_gated && (ph & LP_PH_POST_STEADY);    // redo the tentative half-step of the last launch
         if constexpr (ES) {
             if (post) {
-                if (es_prev >= 0) load_f32<VEC>(d.es->x0s_buf[es_prev], i, x0p);
-                if (es_anchor >= 0) load_f32<VEC>(d.es->x0s_buf[es_anchor], i, anc);
+                if (es_prev >= 0) load_f32<VEC>(es_prev == 0 ? d.es_x0s[0] : es_prev == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0p);
+                if (es_anchor >= 0) load_f32<VEC>(es_anchor == 0 ? d.es_x0s[0] : es_anchor == 1 ? d.es_x0s[1] : d.es_x0s[2], i, anc);
                 if (d.es_ring) load_f32<VEC>(d.es_ring, i, rg);
             }
         }
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             if ((fl & LP_FL_WRITE_X0S) && active) store_f32<VEC>(d.x0s, i, x0s);
             if constexpr (ES) {
                 if (active) {
-                    store_f32<VEC>(d.es->x0s_buf[es_write], i, x0s);
+                    store_f32<VEC>(es_write == 0 ? d.es_x0s[0] : es_write == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0s);
                     // weighted squared differences (earlystop.py:52-55): w1 = 1 - mask, w2 = ring
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
@@ -608,17 +613,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         }
     }
 
-    // ---- early stop: block partials -> last block reduces in a fixed order and applies the rule ---------------
+    // ---- early stop: this block's partial sums; lp_es_decide_kernel (next launch) reduces them and applies the rule.
+    // (One kernel with a "last block done" ticket needs a device-scope fence per block, i.e. an L2 write-back on
+    // every XCD: measured 30 us per launch at 65 536 elements.  A kernel boundary gives the same visibility for
+    // the price of one more dependent launch, ~2 us.)
     if constexpr (ES) {
-        if (es_idle) {           // stopped loop: nothing to decide; its last launch tells the host the call is done
-            if (d.es_host && d.es_index + 1 == d.es_n_steps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-                es_post_seq(d.es_host, d.es->seq_base + LP_ES_SEQ_DONE);
-            return;
-        }
-        if (!post) return;
+        if (es_idle || !post) return;
         __shared__ double es_part[4][kEsSums];
-        __shared__ double es_red[256];
-        __shared__ int es_last;
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
         for (int k = 0; k < kEsSums; ++k) {
@@ -626,34 +627,44 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             if (lane == 0) es_part[wave][k] = v;
         }
         __syncthreads();
-        const unsigned nblocks = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
         if (threadIdx.x < kEsSums) {
+            const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
             double v = 0.0;
             for (unsigned w = 0; w < blockDim.x / kWave; ++w) v += es_part[w][threadIdx.x];
             d.es_partials[static_cast<size_t>(blk) * 8 + threadIdx.x] = v;
         }
-        __threadfence();                                         // partials visible device-wide before the ticket
-        __syncthreads();
-        if (threadIdx.x == 0) es_last = (atomicAdd(&d.es->ticket, 1u) == nblocks - 1u) ? 1 : 0;
-        __syncthreads();
-        if (!es_last) return;
-        __threadfence();
-        double tot[kEsSums];
+    }
+}
+
+// One block: fixed-order reduction of the per-block partial sums of the LP_FL_ES launch before it, then the stop rule.
+__global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d, unsigned nblocks) {
+    const bool gated = (d.flags & LP_FL_ES_GATED) != 0;
+    if (gated && d.es->stopped != 0) {   // stopped loop: its last launch tells the host the call is done
+        if (d.es_host && d.es_index + 1 == d.es_n_steps && threadIdx.x == 0)
+            es_post_seq(d.es_host, d.es->seq_base + LP_ES_SEQ_DONE);
+        return;
+    }
+    __shared__ double es_part[4][kEsSums];
+    const int es_prev = d.es->cur_slot, es_anchor = d.es->anchor_slot;      // wave-uniform scalar loads
+    double v[kEsSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {          // thread t: blocks t, t + 256, ...
 #pragma unroll
-        for (int k = 0; k < kEsSums; ++k) {                     // thread t: blocks t, t + 256, ...; then a fixed tree
-            double v = 0.0;
-            for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x)
-                v += __builtin_nontemporal_load(d.es_partials + static_cast<size_t>(b) * 8 + k);
-            es_red[threadIdx.x] = v;
-            __syncthreads();
-            for (unsigned sft = blockDim.x / 2; sft > 0; sft >>= 1) {
-                if (threadIdx.x < sft) es_red[threadIdx.x] += es_red[threadIdx.x + sft];
-                __syncthreads();
-            }
-            tot[k] = es_red[0];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) es_decide(d, tot, es_prev >= 0, es_anchor >= 0);
+        for (int k = 0; k < kEsSums; ++k) v[k] += d.es_partials[static_cast<size_t>(b) * 8 + k];
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < kEsSums; ++k) {                                     // fixed shuffle tree, then the four waves in order
+        const double w = wave_sum(v[k]);
+        if (lane == 0) es_part[wave][k] = w;
+    }
+    __syncthreads();
+    double tot[kEsSums];
+#pragma unroll
+    for (int k = 0; k < kEsSums; ++k) tot[k] = es_part[0][k] + es_part[1][k] + es_part[2][k] + es_part[3][k];
+    if (threadIdx.x == 0) {
+        lp_es_state st = *d.es;          // one block load, updated in registers, one block store
+        es_decide(d, st, tot, es_prev >= 0, es_anchor >= 0);
+        *d.es = st;
     }
 }
 
@@ -664,12 +675,14 @@ struct Timer {
 
 struct Tune {
     int vec = 0, block = 0;   // 0 = automatic
+    bool es_no_decide = false;
     int64_t small_elems = 0;
     Tune() {
         // developer knobs for the micro-benchmarks (scripts/microbench_step.py); not an API
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_VEC")) vec = std::atoi(e);
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_BLOCK")) block = std::atoi(e);
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_SMALL")) small_elems = std::atoll(e);
+        es_no_decide = std::getenv("LANPAINT_AMD_TUNE_ES_NO_DECIDE") != nullptr;
     }
 };
 
@@ -695,6 +708,12 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
                               timer->stop, 0, d);
     } else {
         hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, d);
+    }
+    if constexpr (ES) {
+        if ((d.phases & kPost) && !t.es_no_decide) {
+            if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+            hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(256), 0, stream, d, grid.x * grid.y);
+        }
     }
     return hipGetLastError();
 }
@@ -790,6 +809,7 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if (d.es_reset && !d.es) return LP_E_INVALID;
     if (d.flags & LP_FL_ES) {
         if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
+        if (!d.es_x0s[0] || !d.es_x0s[1] || !d.es_x0s[2]) return LP_E_INVALID;
         if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator
         if (tune().block && tune().block != 256) return LP_E_UNSUPPORTED;
     } else if (d.flags & LP_FL_ES_GATED) {

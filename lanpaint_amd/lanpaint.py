@@ -152,6 +152,7 @@ class _DeviceStop:
         self.f64 = self.mailbox.numpy()
         self.i64 = self.mailbox.view(torch.int64).numpy()
         self.seq_base = 0
+        self.seen_total = 0         # of the device's running iteration count, what the engine has accounted already
         self.ring = None            # (weakref(mask), version, ring tensor | None)
 
     def matches(self, like, n_steps):
@@ -357,7 +358,9 @@ class LanPaint:
         ds, seq, n_steps, es, dev, inc = p
         ds.wait(seq + _cabi.LP_ES_SEQ_DONE, dev)
         n_ran = int(ds.f64[1])
-        self._iterations_run += n_ran
+        total = int(ds.f64[6])             # the device counts across calls: every replay since the last collection
+        self._iterations_run += total - ds.seen_total
+        ds.seen_total = total
         self.last_inner_steps = n_ran
         for i in range(n_ran):
             self._es_trace(es, ds, i)
@@ -576,8 +579,10 @@ class LanPaint:
                                "there is no CPU fallback" % x.device.type)
         if self.rng == "torch" and not self._check_torch_stream(x.device):
             self.rng = "torch-eager"
-        self._es_resolve()
         self._es_opts = self._es_options(model_options)
+        if self._es_pending is not None and (self._es_opts is None or self._es_opts["trace"] is not None
+                                             or self._es_pending[0] is not self._ds):
+            self._es_resolve()       # (a loop that only has to be counted is collected when somebody asks)
         self.img_dim_size = len(x.shape)
         self.latent_image = latent_image
         self.noise = noise
@@ -1059,6 +1064,8 @@ class LanPaint:
             d.es, d.es_reset, d.es_seq_base = ds.state.data_ptr(), 1, st.es["seq"]
             d.es_threshold, d.es_patience_eff, d.es_n_steps = es["threshold"], es["patience_eff"], n_steps
             d.es_host, d.es_partials = ds.mailbox.data_ptr(), ds.partials.data_ptr()
+            for k in range(3):
+                d.es_x0s[k] = ds.x0s[k].data_ptr()
             d.es_ring = ring.data_ptr() if ring is not None else None
         self._launch_step(stream)
         st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
@@ -1252,6 +1259,7 @@ class LanPaint:
             if ds.f64[2] != 0.0:                      # stopped
                 break
         if not gated:
+            ds.seen_total += ran                  # this loop's iterations are accounted by its caller
             d.phases, d.flags = LP_PH_EMIT, base_flags | self._emit(st, True)
             self._launch_step(stream)
         return ran

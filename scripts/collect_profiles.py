@@ -14,7 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profiles")
 DST = os.path.join(ROOT, "profiles")
 N_EL = {"c1": ("c1_sd15", 16384), "c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c4": ("c4_flux", 65536),
-        "c5": ("c5_wan", 2096640)}
+        "c5": ("c5_wan", 2096640), "xwanb16": ("x_wan_b16", 33546240), "xwanb16_noskip": ("x_wan_b16_every_stream", 33546240)}
+
+
+def steady_duration(path):
+    """(mean us, dispatches) of the steady lp_step kernel in a kernel-trace summary (scripts/rocprof_summary.py)."""
+    for line in open(path):
+        m = re.match(r"\| `lp::lp_step_kernel<\d, \w+, 28u[^`]*` \| [^|]* \| \d+ \| (\d+) \| [0-9.]+ \| ([0-9.]+) \|", line)
+        if m:
+            return float(m.group(2)), int(m.group(1))
+    return None
 
 
 def steady_mean(path):
@@ -51,6 +60,15 @@ def main():
                        "dispatches": fe[2], "traffic_bytes_per_launch": tb, "algorithmic_bytes_per_launch": 36 * n_el,
                        "traffic_over_algorithmic": round(tb / (36 * n_el), 4)}
     json.dump(traffic, open(os.path.join(DST, f"r{rnd}_pmc_traffic.json"), "w"), indent=1)
+    durations = {"_doc": "mean per-dispatch duration of the steady-state lp_step kernel as rocprofv3 --kernel-trace measured it "
+                         "(profiles/r%s_*_kernel_trace.md); bench.py computes roofline.frac from the larger of this and its own "
+                         "event timing" % rnd}
+    for tag, (wl, _n) in N_EL.items():
+        path = os.path.join(SRC, f"{tag}_kernel_trace.md")
+        got = steady_duration(path) if os.path.exists(path) else None
+        if got:
+            durations[wl] = {"mean_us": got[0], "dispatches": got[1], "source": f"r{rnd}_{tag}_kernel_trace.md"}
+    json.dump(durations, open(os.path.join(DST, f"r{rnd}_kernel_durations.json"), "w"), indent=1)
     print(json.dumps({k: v.get("traffic_over_algorithmic") for k, v in traffic.items() if isinstance(v, dict)}))
 
 
