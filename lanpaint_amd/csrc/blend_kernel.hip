@@ -107,12 +107,12 @@ static hipError_t launch_blend(const lp_blend_desc& d, hipStream_t stream) {
     const int R = d.k / 2;
     const size_t lds = sizeof(float) * (static_cast<size_t>(TH + 4 * R) * (TW + 4 * R) +
                                         static_cast<size_t>(TH + 4 * R) * (TW + 2 * R) + d.k);
-    static bool attr_done = false;        // raise the dynamic-LDS cap once per instantiation (160 KiB per CU on gfx950)
-    if (!attr_done) {
+    // above the default 64 KiB cap the dynamic-LDS limit has to be raised (160 KiB per CU on gfx950).  The attribute is
+    // per DEVICE, so it is set on whatever device this launch goes to -- no process-wide "done" flag (the library
+    // keeps no state; a second GPU of the same process would otherwise fail to launch)
+    if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lp_mask_blend_kernel<TH, TW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
     const dim3 grid((d.width + TW - 1) / TW, (d.height + TH - 1) / TH, d.batch);
     hipLaunchKernelGGL((lp_mask_blend_kernel<TH, TW>), grid, dim3(256), lds, stream, d);
     return hipGetLastError();

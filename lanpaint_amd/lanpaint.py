@@ -93,22 +93,25 @@ def aten_randn_policy(numel: int, multi_processor_count: int, max_threads_per_mu
     return bg, ((numel - 1) // (bg * 4) + 1) * 4
 
 
-def _noise_scaling_kind(model_sampling) -> str:
-    """Which closed form the replace step may fuse (lanpaint.py:84-94).  'callback'
-    keeps the reference behaviour for any model_sampling: call its noise_scaling."""
+def _noise_scaling_kind(model_sampling):
+    """Which closed form the replace step may fuse (lanpaint.py:84-94), and the noise scale that form uses.
+    'callback' keeps the reference behaviour for any model_sampling: call its noise_scaling.
+    A model_sampling that DECLARES its form (`lanpaint_noise_scaling_kind`) is taken at its word, `noise_scale`
+    attribute included; ComfyUI's stock CONST.noise_scaling is `sigma * noise + (1 - sigma) * latent` with no
+    noise_scale term, so a subclass that inherits it but carries a `noise_scale` attribute still gets scale 1."""
     kind = getattr(model_sampling, "lanpaint_noise_scaling_kind", None)
     if kind in ("ve", "flow"):
-        return kind
+        return kind, float(getattr(model_sampling, "noise_scale", 1.0))
     try:                                   # ComfyUI present: recognise its stock EPS / CONST forms
         import comfy.model_sampling as cms  # type: ignore
         fn = getattr(type(model_sampling), "noise_scaling", None)
         if fn is getattr(getattr(cms, "CONST", None), "noise_scaling", object()):
-            return "flow"
+            return "flow", 1.0
         if fn is getattr(getattr(cms, "EPS", None), "noise_scaling", object()):
-            return "ve"
+            return "ve", 1.0
     except Exception:
         pass
-    return "callback"
+    return "callback", 1.0
 
 
 class _Workspace:
@@ -1006,7 +1009,7 @@ class LanPaint:
         d.known = None
         d.noise = nz.data_ptr()
         if s_b.numel() == 1:
-            kind = _noise_scaling_kind(ms)
+            kind, ns = _noise_scaling_kind(ms)
             if kind == "callback":
                 known = _as_f32c(ms.noise_scaling(s_b, nz, y))
                 keep.append(known)
@@ -1014,8 +1017,8 @@ class LanPaint:
             elif kind == "ve":
                 d.replace_kind = LP_REPLACE_VE
             else:
-                d.replace_kind, d.noise_scale = LP_REPLACE_FLOW, float(getattr(ms, "noise_scale", 1.0))
-        else:        # per-row sigma: the reference emulates the FLOW form elementwise (lanpaint.py:89-92)
+                d.replace_kind, d.noise_scale = LP_REPLACE_FLOW, ns
+        else:        # per-row sigma: the reference emulates the FLOW form elementwise, noise_scale included (lanpaint.py:89-92)
             d.replace_kind, d.noise_scale = LP_REPLACE_FLOW, float(getattr(ms, "noise_scale", 1.0))
 
         st.compat = self._overridden("langevin_dynamics") or self._overridden("score_model") or \

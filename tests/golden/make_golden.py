@@ -86,6 +86,26 @@ def run_case(name):
     if mo is not None:
         mo = {k: dict(v) if isinstance(v, dict) else v for k, v in mo.items()}
         mo["lanpaint_semantic_trace"] = []
+    if case["xi_seed"] is not None:
+        # compact fixture: the reference's torch.randn_like is fed from a numpy seed; only the outputs are stored
+        draws = iter(gc.seeded_xi(case["xi_seed"], case["shape"], 64))
+        used = []
+        orig = torch.randn_like
+
+        def fed(t, *a, **k):
+            d = next(draws)
+            used.append(1)
+            return torch.from_numpy(d).to(t.dtype)
+        torch.randn_like = fed
+        try:
+            out = eng(x, _t(case["y"]), _t(case["noise"]), _t(case["sigma"]), _t(case["mask"]),
+                      tuple(_t(t) for t in case["times"]), mo, 0, n_steps=case["n_steps"], **kw)
+        finally:
+            torch.randn_like = orig
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), x_out=x.numpy(), out=out.numpy(),
+                            n_draws=np.int64(len(used)), model_calls=np.int64(model.calls),
+                            xi_seed=np.int64(case["xi_seed"]), shape=np.asarray(case["shape"], dtype=np.int64))
+        return len(used), model.calls
     with XiRecorder() as rec:
         out = eng(x, _t(case["y"]), _t(case["noise"]), _t(case["sigma"]), _t(case["mask"]),
                   tuple(_t(t) for t in case["times"]), mo, 0, n_steps=case["n_steps"], **kw)
@@ -222,9 +242,14 @@ def blend_kat():
 
 
 def main():
+    only = sys.argv[1:]                   # `make_golden.py name ...` regenerates just those single-call cases
     for name in gc.CASES:
+        if only and name not in only:
+            continue
         nd, mc = run_case(name)
         print(f"{name:24s} draws={nd:3d} model_calls={mc}")
+    if only:
+        return
     for name in gc.SCHEDULES:
         print(f"{name:24s} draws={run_schedule(name)}")
     coefficient_kat()

@@ -62,7 +62,13 @@ def build_case(name):
                 x=x, y=y, noise=noise, mask=mask,
                 times=(ve.astype(np.float32), abt.astype(np.float32), flow_t.astype(np.float32)),
                 hyper=hyper, model=c.get("model", "linear_tuple"), n_steps=c.get("n_steps", None),
-                model_options=c.get("model_options", None), audio=c.get("audio", None))
+                model_options=c.get("model_options", None), audio=c.get("audio", None), xi_seed=c.get("xi_seed", None))
+
+
+def seeded_xi(xi_seed, shape, n):
+    """The xi stream of a compact fixture: n standard-normal draws of `shape` from numpy's PCG64 (portable)."""
+    g = np.random.default_rng(xi_seed)
+    return [g.standard_normal(shape, dtype=np.float32) for _ in range(n)]
 
 
 CASES = {
@@ -87,6 +93,11 @@ CASES = {
     "ve_zero_noise":   dict(shape=(1, 4, 8, 8), sigma=[2.0], zero_noise=True, seed=17),
     "ve_lambda_beta":  dict(shape=(1, 4, 8, 8), sigma=[2.0], hyper=dict(Lambda=8.0, Beta=0.5, StepSize=0.15), seed=18),
     "ve_sdxl_shape":   dict(shape=(1, 4, 32, 32), sigma=[1.0], seed=19),
+    # BASELINE shapes at FULL size, straight from the reference (no oracle in between): C2 = SDXL 1x4x128x128 and
+    # C4 = Flux 1x16x64x64, one sigma call of 5 think iterations.  The xi stream comes from a numpy seed (the
+    # reference's torch.randn_like is fed from it), so the fixture only has to store the two outputs.
+    "ve_sdxl_full":    dict(shape=(1, 4, 128, 128), sigma=[1.0], seed=33, xi_seed=4242),
+    "flow_flux_full":  dict(shape=(1, 16, 64, 64), sigma=[0.6], flow=True, seed=34, xi_seed=4243),
     # flow / flux (Flux, Wan, SD3 notation)
     "flow_basic":      dict(shape=(1, 16, 4, 4), sigma=[0.7], flow=True, seed=20),
     "flow_flux_flag":  dict(shape=(1, 16, 4, 4), sigma=[0.5], flux=True, seed=21),

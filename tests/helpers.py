@@ -17,6 +17,8 @@ def load_golden(name):
 
 
 def xi_list(g):
+    if "xi_seed" in g.files:          # compact full-size fixture: the draws are regenerated from the seed
+        return gc.seeded_xi(int(g["xi_seed"]), tuple(int(v) for v in g["shape"]), int(g["n_draws"]))
     return [g[f"xi_{i}"] for i in range(int(g["n_draws"]))]
 
 

@@ -7,6 +7,7 @@ import pytest
 from oracle import lanpaint_oracle as orc
 from tests import golden_cases as gc
 from tests.helpers import assert_close
+from tests.stubs import MODELS
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -480,3 +481,41 @@ class _DummyLinear(_DummyModel):
     def __call__(self, x, sigma, model_options=None, seed=None):
         self.calls += 1
         return 0.9 * x, 0.8 * x
+
+
+def test_rows_whose_step_size_is_zero_are_identity_updates_and_do_not_disturb_the_other_rows():
+    """Documented deviation: the reference tests `mean(dtx) <= 0` over the whole batch
+    (lanpaint.py:205) -- all rows skip or none does, and a row with step 0 inside a batch that goes on divides by
+    zero (A = 1 / (1 - abt) with abt = 1).  Here the test is per row (LP_C_VALID): the row with sigma = 0 passes
+    through the loop unchanged, finite, and the other row gets exactly what it gets when run alone."""
+    import torch
+    from lanpaint_amd import LanPaint
+    shape = (2, 4, 8, 8)
+    rng = np.random.default_rng(17)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    mask = gc.box_mask(shape)
+    sig = np.float32([0.0, 1.3])
+    x = (y + noise * sig.reshape(2, 1, 1, 1)).astype(np.float32)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+
+    def run(sig_rows):
+        it = iter([tt(d) for d in xi])
+        eng = LanPaint(MODELS["linear_tuple"](), 4, 15.0, 5.0, 1.0, 0.2, rng=lambda like: next(it))
+        s = tt(sig_rows)
+        xx = tt(x)
+        out = eng(xx, tt(y), tt(noise), s, tt(mask), gc.times_from_sigma(s, False), None, 0)
+        torch.cuda.synchronize()
+        return xx.cpu().numpy(), out.cpu().numpy(), eng
+
+    xi = [rng.standard_normal(shape, dtype=np.float32) for _ in range(7)]
+    xb, ob, eng = run(sig)
+    x1, o1, _ = run(np.float32([1.3, 1.3]))      # (two rows again: per-row sigma takes the reference's flow-form replace step)
+    assert eng.iterations_run == 4                                      # the backbone is still called (per-row rule)
+    assert np.isfinite(xb).all() and np.isfinite(ob).all()
+    np.testing.assert_array_equal(xb[1], x1[1])                         # the live row: untouched by its dead neighbour
+    np.testing.assert_array_equal(ob[1], o1[1])
+    # the dead row: replace step (sigma = 0 -> known region = y, inpaint region = x) and the x_t <-> x round trip only
+    m = mask[0] == 1
+    np.testing.assert_allclose(xb[0][m], y[0][m], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(xb[0][~m], x[0][~m], rtol=1e-6, atol=1e-6)

@@ -6,6 +6,7 @@ orders of magnitude inside BASELINE.json's "output MSE vs reference < 1e-5"."""
 import numpy as np
 import pytest
 
+from oracle.lanpaint_oracle import OracleLanPaint
 from tests import golden_cases as gc
 from tests.helpers import assert_close, load_golden, run_oracle_case, run_product_case, xi_list
 from tests.stubs import MODELS, OpaqueVESampling
@@ -372,6 +373,46 @@ def test_fused_cfg_heads_equal_eager_cfg(name, dtype):
     rel = 2e-5 if dtype == "float32" else 3e-2            # bf16: eager rounds the heads to bf16, fused keeps fp32
     assert_close(b["x"], a["x"], f"{name}: fused-CFG x", rel=rel, mse=1e-9 if dtype == "float32" else 1e-4)
     assert_close(b["out"], a["out"], f"{name}: fused-CFG out", rel=rel, mse=1e-9 if dtype == "float32" else 1e-4)
+
+
+@pytest.mark.parametrize("name", ["ve_basic", "flow_batch", "ve_sdxl_full"])
+def test_fused_cfg_heads_match_the_oracle_fed_the_reference_cfg_combination(name):
+    """Direct check (no HIP on the expected side): the CPU oracle -- pinned to the reference -- runs with a backbone
+    that forms both CFG heads the way the reference's sampling_function_LanPaint does through ComfyUI's stock
+    cfg_function, `uncond + (cond - uncond) * scale` twice (nodes.py:161-175); the HIP engine gets the same cond /
+    uncond predictions as FusedCFGHeads and combines them inside the step and finalise kernels."""
+    from lanpaint_amd import FusedCFGHeads
+    s0, s1 = 4.5, -0.5
+
+    class Heads(MODELS["linear_tuple"]):
+        def preds(self, x):
+            return 0.9 * x + 0.05, 0.7 * x - 0.1                    # cond, uncond (operators only: numpy and torch)
+
+    class RefCFG(Heads):                                             # what the reference's model function returns
+        def __call__(self, x, t, model_options=None, seed=None):
+            self._note(x, t)
+            c, u = self.preds(x)
+            return u + (c - u) * s0, u + (c - u) * s1
+
+    class Fused(Heads):
+        def __call__(self, x, t, model_options=None, seed=None):
+            self._note(x, t)
+            c, u = self.preds(x)
+            return FusedCFGHeads(c, u, s0, s1)
+
+    case = gc.build_case(name)
+    g = load_golden(name)
+    it = iter(xi_list(g))
+    h = case["hyper"]
+    omodel = RefCFG(flow=case["flow"] or case["flux"])
+    o = OracleLanPaint(omodel, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], is_flux=case["flux"],
+                       is_flow=case["flow"], min_step_frac=h["MinStepFrac"], randn=lambda like: next(it))
+    xo = case["x"].copy()
+    out_o = o(xo, case["y"], case["noise"], case["sigma"], case["mask"], case["times"], None, 0, n_steps=case["n_steps"])
+    r = run_product_case(name, model_cls=Fused)
+    assert r["model"].calls == omodel.calls and r["leftover"] == 0
+    assert_close(r["x"], xo, f"{name}: fused-CFG x vs oracle", rel=3e-5)
+    assert_close(r["out"], out_o, f"{name}: fused-CFG out vs oracle", rel=3e-5)
 
 
 def test_engine_in_front_of_dummy_unet_matches_oracle():
