@@ -238,11 +238,12 @@ typedef struct lp_step_desc {
     uint64_t*    io_table_out;
     uint64_t     io_table_val[2];
     /* Inner early stop on the device (LP_FL_ES; earlystop.py:58-336 with the default metric).                 */
-    lp_es_state* es;             /* device state; also given to the launch that resets it                     */
+    lp_es_state* es;             /* device state, TWO consecutive lp_es_state (a gated loop on a small grid alternates
+                                    between them); also given to the launch that resets it                     */
     float*       es_x0s[3];      /* the three rotating x0s buffers (== es->x0s_buf, as launch arguments so the kernel
                                     selects one by slot index instead of chasing a pointer through the state)     */
     const float* es_ring;        /* mask-edge ring weight (lp_boundary_ring; 4-D latents), or NULL           */
-    double*      es_partials;    /* device scratch: 8 doubles per block of the launch                        */
+    double*      es_partials;    /* device scratch: 2 x 8 doubles per block of the launch                    */
     double*      es_host;        /* mailbox, LP_ES_MAILBOX_DOUBLES(es_n_steps) doubles                       */
     double       es_threshold;   /* threshold before the abt scaling (earlystop.py:78-81)                    */
     int64_t      es_seq_base;    /* es_reset: sequence base of this call                                     */

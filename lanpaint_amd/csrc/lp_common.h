@@ -447,6 +447,20 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// N sums at once: the N shuffle chains are independent, so each level issues all its cross-lane moves before it
+// waits (one LDS-permute round trip per level instead of one per level AND value: 6 instead of 36 for six sums)
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        double t[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = __shfl_down(v[k], off, kWave);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += t[k];
+    }
+}
+
 __host__ __device__ inline int x0_dtype(uint32_t flags) {
     return (flags & LP_FL_X0_BF16) ? DT_BF16 : (flags & LP_FL_X0_F16) ? DT_F16 : DT_F32;
 }

@@ -113,6 +113,7 @@ __device__ __forceinline__ float ou_general(float x, float tau, float a, float c
 }
 
 // ---- inner early stop on the device (earlystop.py:58-336, default metric) ----------------------------------
+constexpr uint32_t kFlEsFold = 1u << 31;   // internal (set by the dispatcher): the decision of iteration i - 1 is folded into launch i
 constexpr int kEsSums = 6;    // { sum w1 dA^2, sum w1, sum w2 dA^2, sum w2, sum w1 dB^2, sum w2 dB^2 }
 
 __device__ __forceinline__ double clamp01(double v) { return v <= 0.0 ? 0.0 : (v >= 1.0 ? 1.0 : v); }
@@ -137,6 +138,7 @@ __device__ __forceinline__ void es_reset_state(const lp_step_desc& d, bool fold)
     es->seq_base = d.es_seq_base;
     es->threshold_eff = thr_eff;
     es->abt_val = abt_val;
+    es[1] = es[0];                     // second slot of the ping-pong pair a folded loop alternates between
 }
 
 __device__ __forceinline__ void es_post_seq(double* host, int64_t seq) {
@@ -148,8 +150,8 @@ __device__ __forceinline__ void es_post_seq(double* host, int64_t seq) {
 // block load at the top of the deciding kernel (field-by-field reads through the pointer cost a memory round trip
 // each: 9 -> ~5 us per iteration at SDXL size), updated in registers and written back by the caller.
 __device__ __forceinline__ void es_decide(const lp_step_desc& d, lp_es_state& st, const double (&s)[kEsSums], bool have_prev,
-                                          bool have_anchor) {
-    double* host = d.es_host;
+                                          bool have_anchor, int i, bool post) {
+    double* host = post ? d.es_host : nullptr;
     const bool has_ring = d.es_ring != nullptr;
     const double nan = __builtin_nan("");
     double dist_in = s[0] / (s[1] + 1e-12), dist_ring = nan, dist_drift = nan;
@@ -158,7 +160,6 @@ __device__ __forceinline__ void es_decide(const lp_step_desc& d, lp_es_state& st
         dist_ring = s[2] / (s[3] + 1e-12);
         dist = dist_in > dist_ring ? dist_in : dist_ring;
     }
-    const int i = d.es_index;
     const bool enabled = st.enabled != 0 && s[1] >= 1e-6;           // earlystop.py:111-117
     int counter = st.counter, anchor = st.anchor_slot, stopped = 0;
     const int cur = st.write_slot;                                   // this iteration's x0s
@@ -237,10 +238,60 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     uint32_t ph_rt = PH ? PH : d.phases;             // compile-time for the hot combinations
     bool es_gated = false, es_idle = false;
     int es_prev = -1, es_anchor = -1, es_write = 0;
-    if constexpr (ES) {                              // wave-uniform scalar loads of the device-side stop state
+    bool es_fold = false;
+    if constexpr (ES) {
         es_gated = (fl & LP_FL_ES_GATED) != 0;
-        es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot;
-        if (es_gated && d.es->stopped != 0) {        // the loop has stopped: only re-emit x_in from the committed x_t
+        es_fold = (fl & kFlEsFold) != 0;
+        int stopped;
+        if (es_fold) {
+            // Folded decision (latency-bound sizes): launch i first applies the stop rule of iteration i - 1 -- every
+            // block reduces the previous launch's per-block sums itself (same fixed order -> same bits in every
+            // block) and steps the state in registers; block 0 stores it.  The state ping-pongs between two slots
+            // and the sums between two buffers, so nobody reads what a neighbour block of the same launch writes.
+            // This replaces a one-block kernel between every two launches: ~5 us per iteration at SDXL size.
+            const int i = d.es_index, rd = (i + 1) & 1;
+            const lp_es_state* sp = d.es + rd;
+            // the few fields every lane needs, as scalar loads; the whole state only travels through ONE thread (every
+            // lane holding a copy of the 104-byte struct sent it through LDS: 31 us per launch instead of 7)
+            lp_es_state lite;
+            lite.stopped = sp->stopped; lite.counter = sp->counter; lite.n_ran = sp->n_ran; lite.cur_slot = sp->cur_slot;
+            lite.anchor_slot = sp->anchor_slot; lite.write_slot = sp->write_slot; lite.enabled = sp->enabled;
+            lite.seq_base = 0; lite.total_ran = 0; lite.threshold_eff = sp->threshold_eff; lite.abt_val = 0.0;
+            const bool keeper = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+            if (i > 0 && lite.stopped == 0) {
+                __shared__ double fold_part[4][kEsSums];
+                const unsigned nblocks = gridDim.x * gridDim.y;
+                const double* src = d.es_partials + static_cast<size_t>(rd) * nblocks * 8;
+                double v[kEsSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {
+#pragma unroll
+                    for (int k = 0; k < kEsSums; ++k) v[k] += src[static_cast<size_t>(b) * 8 + k];
+                }
+                const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+                wave_sum_n<kEsSums>(v);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < kEsSums; ++k) fold_part[wave][k] = v[k];
+                }
+                __syncthreads();
+                double tot[kEsSums];
+#pragma unroll
+                for (int k = 0; k < kEsSums; ++k) tot[k] = fold_part[0][k] + fold_part[1][k] + fold_part[2][k] + fold_part[3][k];
+                const bool hp = lite.cur_slot >= 0, ha = lite.anchor_slot >= 0;
+                es_decide(d, lite, tot, hp, ha, i - 1, false);
+                if (keeper) {
+                    lp_es_state st = *sp;
+                    es_decide(d, st, tot, hp, ha, i - 1, true);
+                    d.es[i & 1] = st;
+                }
+            } else if (keeper) {
+                d.es[i & 1] = *sp;
+            }
+            es_prev = lite.cur_slot; es_anchor = lite.anchor_slot; es_write = lite.write_slot; stopped = lite.stopped;
+        } else {                                     // wave-uniform scalar loads of the device-side stop state
+            es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot; stopped = d.es->stopped;
+        }
+        if (es_gated && stopped != 0) {              // the loop has stopped: only re-emit x_in from the committed x_t
             es_idle = true;
             ph_rt = LP_PH_EMIT;
         }
@@ -621,51 +672,64 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         if (es_idle || !post) return;
         __shared__ double es_part[4][kEsSums];
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        double pv[kEsSums];
 #pragma unroll
-        for (int k = 0; k < kEsSums; ++k) {
-            const double v = wave_sum(static_cast<double>(es_p[k]));
-            if (lane == 0) es_part[wave][k] = v;
+        for (int k = 0; k < kEsSums; ++k) pv[k] = static_cast<double>(es_p[k]);
+        wave_sum_n<kEsSums>(pv);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kEsSums; ++k) es_part[wave][k] = pv[k];
         }
         __syncthreads();
         if (threadIdx.x < kEsSums) {
             const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
             double v = 0.0;
             for (unsigned w = 0; w < blockDim.x / kWave; ++w) v += es_part[w][threadIdx.x];
-            d.es_partials[static_cast<size_t>(blk) * 8 + threadIdx.x] = v;
+            const size_t base = es_fold ? static_cast<size_t>(d.es_index & 1) * gridDim.x * gridDim.y * 8 : 0;
+            d.es_partials[base + static_cast<size_t>(blk) * 8 + threadIdx.x] = v;
         }
     }
 }
 
 // One block: fixed-order reduction of the per-block partial sums of the LP_FL_ES launch before it, then the stop rule.
-__global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d, unsigned nblocks) {
-    const bool gated = (d.flags & LP_FL_ES_GATED) != 0;
-    if (gated && d.es->stopped != 0) {   // stopped loop: its last launch tells the host the call is done
-        if (d.es_host && d.es_index + 1 == d.es_n_steps && threadIdx.x == 0)
-            es_post_seq(d.es_host, d.es->seq_base + LP_ES_SEQ_DONE);
-        return;
-    }
-    __shared__ double es_part[4][kEsSums];
-    const int es_prev = d.es->cur_slot, es_anchor = d.es->anchor_slot;      // wave-uniform scalar loads
+// `slot`: which of the two state slots / partial-sum buffers (0 unless it closes a folded loop).
+__global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d, unsigned nblocks, int slot) {
+    // Every load of this kernel is issued up front -- the partial sums, and (thread 0) the whole state as one block
+    // load -- so the launch pays ONE memory round trip, not one per dependent step (state flag -> partials -> state
+    // fields cost ~5.5 us per launch when chained; the data was written by the previous kernel on other XCDs and
+    // comes from HBM).  A stopped loop simply discards what it loaded.
     double v[kEsSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {          // thread t: blocks t, t + 256, ...
 #pragma unroll
-        for (int k = 0; k < kEsSums; ++k) v[k] += d.es_partials[static_cast<size_t>(b) * 8 + k];
+        for (int k = 0; k < kEsSums; ++k)
+            v[k] += __builtin_nontemporal_load(d.es_partials + (static_cast<size_t>(slot) * nblocks + b) * 8 + k);
     }
+    lp_es_state st;
+    if (threadIdx.x == 0) st = d.es[slot];
+    const bool gated = (d.flags & LP_FL_ES_GATED) != 0;
+    __shared__ double es_part[4][kEsSums];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    wave_sum_n<kEsSums>(v);                                                 // fixed shuffle tree, then the four waves in order
+    if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < kEsSums; ++k) {                                     // fixed shuffle tree, then the four waves in order
-        const double w = wave_sum(v[k]);
-        if (lane == 0) es_part[wave][k] = w;
+        for (int k = 0; k < kEsSums; ++k) es_part[wave][k] = v[k];
     }
     __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (gated && st.stopped != 0) {      // stopped loop: its last launch tells the host the call is done
+        if (d.es_index + 1 == d.es_n_steps) {
+            d.es[0] = st;
+            d.es[1] = st;
+            if (d.es_host) es_post_seq(d.es_host, st.seq_base + LP_ES_SEQ_DONE);
+        }
+        return;
+    }
     double tot[kEsSums];
 #pragma unroll
     for (int k = 0; k < kEsSums; ++k) tot[k] = es_part[0][k] + es_part[1][k] + es_part[2][k] + es_part[3][k];
-    if (threadIdx.x == 0) {
-        lp_es_state st = *d.es;          // one block load, updated in registers, one block store
-        es_decide(d, st, tot, es_prev >= 0, es_anchor >= 0);
-        *d.es = st;
-    }
+    es_decide(d, st, tot, st.cur_slot >= 0, st.anchor_slot >= 0, d.es_index, true);
+    d.es[0] = st;                        // both slots: the next reset / the next watched launch start from slot 0
+    d.es[1] = st;
 }
 
 // ---- launch geometry ------------------------------------------------------------------------
@@ -675,7 +739,7 @@ struct Timer {
 
 struct Tune {
     int vec = 0, block = 0;   // 0 = automatic
-    bool es_no_decide = false;
+    bool es_no_decide = false, es_no_fold = false;
     int64_t small_elems = 0;
     Tune() {
         // developer knobs for the micro-benchmarks (scripts/microbench_step.py); not an API
@@ -683,6 +747,7 @@ struct Tune {
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_BLOCK")) block = std::atoi(e);
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_SMALL")) small_elems = std::atoll(e);
         es_no_decide = std::getenv("LANPAINT_AMD_TUNE_ES_NO_DECIDE") != nullptr;
+        es_no_fold = std::getenv("LANPAINT_AMD_TUNE_ES_NO_FOLD") != nullptr;
     }
 };
 
@@ -703,17 +768,26 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     if (bx < 1) bx = 1;
     if (bx > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
+    if constexpr (ES) {
+        // gated loop on a latency-bound latent: the stop rule of iteration i - 1 rides in launch i (every block redoes the
+        // small reduction), one closing lp_es_decide_kernel after the last launch.  Larger grids keep the one-block kernel
+        // per iteration: re-reading nblocks x 48 B in every block would cost more than the launch it saves.
+        const unsigned nblocks = grid.x * grid.y;
+        lp_step_desc dd = d;
+        const bool fold = (d.flags & LP_FL_ES_GATED) && nblocks <= 512 && !t.es_no_fold;
+        if (fold) dd.flags |= kFlEsFold;
+        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, dd);
+        if ((d.phases & kPost) && !t.es_no_decide && (!fold || d.es_index + 1 == d.es_n_steps)) {
+            if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+            hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(256), 0, stream, dd, nblocks, fold ? (d.es_index & 1) : 0);
+        }
+        return hipGetLastError();
+    }
     if (timer) {
         hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, timer->start,
                               timer->stop, 0, d);
     } else {
         hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, d);
-    }
-    if constexpr (ES) {
-        if ((d.phases & kPost) && !t.es_no_decide) {
-            if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-            hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(256), 0, stream, d, grid.x * grid.y);
-        }
     }
     return hipGetLastError();
 }
@@ -809,6 +883,7 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if (d.es_reset && !d.es) return LP_E_INVALID;
     if (d.flags & LP_FL_ES) {
         if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
+        if (d.flags & kFlEsFold) return LP_E_INVALID;             // internal bit
         if (!d.es_x0s[0] || !d.es_x0s[1] || !d.es_x0s[2]) return LP_E_INVALID;
         if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator
         if (tune().block && tune().block != 256) return LP_E_UNSUPPORTED;

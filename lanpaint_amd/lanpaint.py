@@ -145,12 +145,12 @@ class _DeviceStop:
         init.cur_slot = init.anchor_slot = -1
         for k in range(3):
             init.x0s_buf[k] = self.x0s[k].data_ptr()
-        raw = torch.frombuffer(bytearray(bytes(init)), dtype=torch.uint8)
+        raw = torch.frombuffer(bytearray(bytes(init) * 2), dtype=torch.uint8)     # two slots (folded gated loops ping-pong)
         self.state = torch.empty(raw.numel(), dtype=torch.uint8, device=dev)
         self.state.copy_(raw)
         rows = like.shape[0]
         blocks = ((like.numel() // rows + 255) // 256) * rows
-        self.partials = torch.empty(blocks * 8, dtype=torch.float64, device=dev)
+        self.partials = torch.empty(2 * blocks * 8, dtype=torch.float64, device=dev)
         self.mailbox = torch.zeros(_cabi.LP_ES_TRACE0 + 8 * self.n_cap, dtype=torch.float64).pin_memory()
         self.f64 = self.mailbox.numpy()
         self.i64 = self.mailbox.view(torch.int64).numpy()
