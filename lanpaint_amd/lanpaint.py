@@ -35,6 +35,15 @@ from ._cabi import (LP_FL_ES, LP_FL_ES_GATED, LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL
 from .earlystop import LanPaintEarlyStopper
 from .types import FusedCFGHeads, LangevinState
 
+def raw_stream(device) -> int:
+    """hipStream_t of torch's current stream on `device` (torch.cuda.current_stream() builds a Stream object: 2.2 us
+    against 0.1 us for the raw accessor, measured on the MI355X box -- scripts/host_cost_probe.py)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+    except AttributeError:                          # a torch build without the private accessor
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 def _as_f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.to(torch.float32).contiguous()
@@ -443,12 +452,7 @@ class LanPaint:
         return name in self.__dict__ or getattr(type(self), name) is not getattr(LanPaint, name)
 
     def _stream(self, device):
-        # the raw hipStream_t of torch's current stream (torch.cuda.current_stream() builds a Stream object: 2.2 us
-        # against 0.1 us, measured on the MI355X box -- scripts/host_cost_probe.py)
-        try:
-            return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
-        except AttributeError:                      # a torch build without the private accessor
-            return torch.cuda.current_stream(device).cuda_stream
+        return raw_stream(device)
 
     def _noise_is_zero(self, noise):
         """lanpaint.py:51: `mean|noise| < 1e-8` costs the reference one host sync per sigma; the verdict is

@@ -27,7 +27,7 @@ import torch
 
 from . import _cabi
 from .blend import MaskBlend, gaussian_kernel_2d, merge_video_with_mask  # noqa: F401
-from .lanpaint import LanPaint, pack_mask
+from .lanpaint import LanPaint, pack_mask, raw_stream
 from .types import FusedCFGHeads
 
 try:                                    # ComfyUI present (or stubbed by tests)
@@ -318,7 +318,7 @@ class KSamplerX0Inpaint:
             with torch.cuda.device(sigma.device):
                 _cabi.check(_cabi.load().lp_sigma_times_mailbox(
                     sig_c.data_ptr(), rows, sched.data_ptr(), sched.numel(), int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
-                    mb.data_ptr(), mb.data_ptr() + 8, fused_seq, torch._C._cuda_getCurrentRawStream(sigma.device.index)),
+                    mb.data_ptr(), mb.data_ptr() + 8, fused_seq, raw_stream(sigma.device)),
                     "lp_sigma_times_mailbox")
             VE_Sigma, abt, Flow_t = buf[:rows], buf[rows:2 * rows], buf[2 * rows:3 * rows]
         elif IS_FLUX or IS_FLOW:                                            # nodes.py:242-245

@@ -71,7 +71,11 @@ def test_struct_layout_matches_c(tmp_path):
     prog.append('printf("\\n");')
     for f in fields_call:
         prog.append(f'printf("%zu ", offsetof(lp_call_desc, {f}));')
-    prog.append('printf("%zu\\n", sizeof(lp_call_desc)); return 0;}')
+    prog.append('printf("%zu\\n", sizeof(lp_call_desc));')
+    fields_es = [f for f, _ in _cabi.LpEsState._fields_]
+    for f in fields_es:
+        prog.append(f'printf("%zu ", offsetof(lp_es_state, {f}));')
+    prog.append('printf("%zu %d %d\\n", sizeof(lp_es_state), LP_ES_SEQ_DONE, LP_ES_TRACE0); return 0;}')
     src = tmp_path / "layout.c"
     src.write_text("\n".join(prog))
     exe = tmp_path / "layout"
@@ -83,6 +87,8 @@ def test_struct_layout_matches_c(tmp_path):
     assert [int(v) for v in lines[2].split()] == [getattr(_cabi.LpFinalDesc, f).offset for f in fields_final]
     assert [int(v) for v in lines[3].split()] == [getattr(_cabi.LpCallDesc, f).offset for f in fields_call] + \
         [ctypes.sizeof(_cabi.LpCallDesc)]
+    assert [int(v) for v in lines[4].split()] == [getattr(_cabi.LpEsState, f).offset for f in fields_es] + \
+        [ctypes.sizeof(_cabi.LpEsState), _cabi.LP_ES_SEQ_DONE, _cabi.LP_ES_TRACE0]
 
 
 def test_engine_refuses_cpu_tensors(hip_lib):

@@ -342,6 +342,79 @@ def test_early_stop_inside_a_replayed_graph_equals_the_host_watched_loop(name, r
         assert any(r[2] < n for r in res[True])
 
 
+ES_ORACLE_CASES = {
+    # name: (shape, flow, sigma per row, mask kind, threshold, patience, n_steps, pack bits)
+    "rows2_ve":      ((2, 4, 12, 12), False, [1.4, 0.8], "blob", 0.45, 1, 8, False),
+    "video5d_flow":  ((1, 4, 3, 6, 10), True, [0.55], "box", 0.2, 1, 8, False),
+    "soft_ve":       ((1, 4, 10, 10), False, [1.0], "soft", 0.5, 1, 8, False),
+    "odd_numel":     ((1, 3, 5, 7), False, [1.2], "box", 0.45, 2, 9, False),
+    "vec4_f32":      ((1, 4, 384, 384), False, [1.0], "blob", 0.3, 1, 6, False),
+    "vec4_bits":     ((1, 4, 384, 384), False, [1.0], "blob", 0.3, 1, 6, True),
+    "never_enabled": ((1, 4, 8, 8), False, [1.0], "ones", 0.5, 1, 4, False),       # no inpaint weight: stopper off (:115-117)
+}
+
+
+@pytest.mark.parametrize("name", sorted(ES_ORACLE_CASES))
+def test_device_side_early_stop_matches_the_oracle_stopper(name):
+    """The stop rule evaluated on the device (LP_FL_ES) against the oracle's restatement of earlystop.py:58-336 on
+    shapes the reference-generated goldens do not cover: batch rows with their own sigma (abt mean over rows), a 5-D
+    latent (no ring), a soft mask (general arithmetic path), the 16 B/lane kernels with fp32 and bit-packed masks,
+    and a mask without inpaint region (stopper disabled).  Same recorded xi stream on both sides."""
+    import torch
+    from lanpaint_amd import LanPaint, pack_mask
+    shape, flow, sig, mkind, thr, pat, n, bits = ES_ORACLE_CASES[name]
+    rng = np.random.default_rng(sorted(ES_ORACLE_CASES).index(name) + 100)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    sigma = np.float32(sig)
+    sb = sigma.reshape((-1,) + (1,) * (len(shape) - 1))
+    x = ((sb * noise + (1 - sb) * y) if flow else (y + noise * sb)).astype(np.float32)
+    if mkind == "soft":
+        mask = rng.random(shape, dtype=np.float32)
+    elif mkind == "ones":
+        mask = np.ones(shape, dtype=np.float32)
+    elif mkind == "blob":
+        mask = np.ones(shape, dtype=np.float32)
+        h, w = shape[-2], shape[-1]
+        mask[..., h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 0.0
+    else:
+        mask = gc.box_mask(shape)
+    times = gc.times_from_sigma(sigma, flow)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(2 * n)]
+    mo = {"lanpaint_semantic_stop": {"threshold": thr, "patience": pat}}
+    it_o = iter(draws)
+    o = OracleLanPaint(MODELS["linear_tuple"](flow=flow), n, 15.0, 5.0, 1.0, 0.2, is_flow=flow, randn=lambda like: next(it_o))
+    xo = x.copy()
+    out_o = o(xo, y, noise, sigma, mask, times, dict(mo), 0)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")   # noqa: E731
+    it_g = iter([tt(d) for d in draws])
+    model = MODELS["linear_tuple"](flow=flow)
+    eng = LanPaint(model, n, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, rng=lambda like: next(it_g))
+    mg = tt(mask)
+    if bits:
+        mg = pack_mask(mg)
+    mo_g = dict(mo, lanpaint_semantic_trace=[])
+    xg = tt(x)
+    out_g = eng(xg, tt(y), tt(noise), tt(sigma), mg, tuple(tt(t) for t in times), mo_g, 0)
+    torch.cuda.synchronize()
+    tr_o = o.last_stopper.trace if o.last_stopper is not None else []
+    tr_g = mo_g["lanpaint_semantic_trace"]
+    assert eng.iterations_run == o.iterations_run and model.calls == o.iterations_run + 1
+    assert len(tr_g) == len(tr_o)
+    assert [t["patience_counter"] for t in tr_g] == [t["counter"] for t in tr_o]
+    assert [t["stopped"] for t in tr_g] == [t["stopped"] for t in tr_o]
+    np.testing.assert_allclose([t["dist"] for t in tr_g], [t["dist"] for t in tr_o], rtol=2e-4)
+    assert sum(1 for _ in it_g) == sum(1 for _ in it_o)             # the same number of draws consumed
+    assert_close(xg.cpu().numpy(), xo, f"{name}: x", rel=5e-5)
+    assert_close(out_g.cpu().numpy(), out_o, f"{name}: out", rel=5e-5)
+    if name == "never_enabled":
+        assert tr_g == [] and eng.iterations_run == n
+    elif name == "odd_numel":
+        assert eng.iterations_run == n and any(t["dist_drift"] is not None for t in tr_g)   # the drift anchor vetoes the stop
+    else:
+        assert eng.iterations_run < n                                # every other case does stop early
+
+
 # ------------------------------------------------------------------ CFG combination fused into the step kernel
 @pytest.mark.parametrize("name,dtype", [("ve_basic", "float32"), ("flow_batch", "float32"), ("ve_odd_numel", "float32"),
                                         ("ve_basic", "bfloat16")])
