@@ -9,12 +9,16 @@ operation of the loop is one launch of the fused HIP kernel behind the C ABI
 (include/lanpaint_hip.h), reached through ctypes with raw device pointers.
 
 Loop shape (the backbone call is the only cut):
-    lp_coeffs                         per-row table on the device (no host sync)
-    lp_step REPLACE|EMIT              replace step, VP rescale, first model input
+    lp_step REPLACE|EMIT|COEFFS       replace step, VP rescale, first model input; the same launch builds the
+                                      per-row coefficient table on the device (no host sync)
     for i in range(n):   model(x_in)  -> (x0, x0_BIG)
         lp_step POST|PRE_HALF|EMIT    post-model half of iteration i fused with the
                                       pre-model half of iteration i+1
     model(x) ; lp_finalize            known-region reprojection + write-back of x
+graph=True: everything after the first launch is one hipGraph per sigma call (the captured lp_finalize finds x / out
+through a device table the first launch publishes).  Inner early stop (default metric): LP_FL_ES on the POST
+launches -- the stop rule runs on the device; eager loops poll one verdict per iteration from a pinned mailbox,
+replayed loops are gated on the device-side flag.
 
 There is no CPU / eager fallback: a missing extension or a non-HIP tensor raises.
 """
