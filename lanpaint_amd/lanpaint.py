@@ -711,8 +711,9 @@ class LanPaint:
             return False         # per-element times: the general path, eager only
         if self.audio_indicator is not None or self.audio_correction is not None:
             return False
-        if self._es_opts is not None and not self._es_opts["device"]:
-            return False         # a custom distance_fn / a sharded batch keeps the stopper on the host
+        if self._es_opts is not None and (not self._es_opts["device"] or self.rng not in ("torch", "philox")):
+            return False         # a custom distance_fn / a sharded batch keeps the stopper on the host; a gated loop
+                                 # redoes its tentative half-step from a counter-based in-kernel generator only
         if self._overridden("langevin_dynamics") or self._overridden("score_model") or \
                 self._overridden("prepare_step_size"):
             return False
