@@ -342,6 +342,40 @@ def test_early_stop_inside_a_replayed_graph_equals_the_host_watched_loop(name, r
         assert any(r[2] < n for r in res[True])
 
 
+def test_early_stop_graph_equals_eager_with_bf16_backbone_input_and_fused_cfg_heads():
+    """The gated loop next to the other launch options: the backbone input emitted as bf16 (`model_dtype`: stopped
+    launches must re-emit it, the last one the fp32 x that is written back) and CFG heads combined in the kernel."""
+    import torch
+    from lanpaint_amd import FusedCFGHeads, LanPaint
+
+    class Heads(MODELS["linear_tuple"]):
+        def __call__(self, x, t, model_options=None, seed=None):
+            self._note(x, t)
+            xf = x.float()
+            return FusedCFGHeads(0.9 * xf + 0.05, 0.7 * xf - 0.1, 4.0, -0.5)
+
+    case = gc.build_case("ve_earlystop")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")   # noqa: E731
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(99)
+        eng = LanPaint(Heads(), 10, 15.0, 5.0, 1.0, 0.2, rng="torch", graph=graph, model_dtype=torch.bfloat16,
+                       EarlyStopThreshold=20.0, EarlyStopPatience=2)
+        y, noise, mask = tt(case["y"]), tt(case["noise"]), tt(case["mask"])
+        runs = []
+        for rep in range(3):
+            x = tt(case["x"] + np.float32(0.03 * rep))
+            it0 = eng.iterations_run
+            out = eng(x, y, noise, tt(case["sigma"]), mask, tuple(tt(t) for t in case["times"]), {}, 0)
+            runs.append((x.cpu().numpy(), out.cpu().numpy(), eng.iterations_run - it0))
+        res[graph] = runs
+    assert any(r[2] < 10 for r in res[False])
+    for e, g in zip(res[False], res[True]):
+        assert e[2] == g[2]
+        np.testing.assert_array_equal(e[0], g[0])
+        np.testing.assert_array_equal(e[1], g[1])
+
+
 ES_ORACLE_CASES = {
     # name: (shape, flow, sigma per row, mask kind, threshold, patience, n_steps, pack bits)
     "rows2_ve":      ((2, 4, 12, 12), False, [1.4, 0.8], "blob", 0.45, 1, 8, False),
