@@ -126,3 +126,81 @@ def test_fast_paths_equal_the_plain_path_bitwise(seed):
     for (xa, oa), (xb, ob) in zip(plain, fast):
         assert np.array_equal(xa.numpy(), xb.numpy()), "x | " + what
         assert np.array_equal(oa.numpy(), ob.numpy()), "out | " + what
+
+
+# ---------------------------------------------------------------- inner early stop on the device vs the oracle stopper
+def _es_case(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    shape = [(1, 4, 8, 8), (2, 4, 9, 7), (1, 3, 5, 7), (3, 2, 6, 10), (1, 8, 3, 6, 8), (4, 4, 16, 16), (1, 4, 40, 40),
+             (1, 1, 33)][int(rng.integers(8))]
+    flow = bool(rng.integers(2))
+    rows = shape[0]
+    per_row = bool(rng.integers(2))
+    sig = rng.uniform(0.25, 0.75, size=rows if per_row else 1) if flow else \
+        np.exp(rng.uniform(np.log(0.4), np.log(2.5), size=rows if per_row else 1))
+    sigma = np.broadcast_to(sig, (rows,)).astype(np.float32).copy()
+    kind = str(rng.choice(["box", "random", "soft"], p=[0.45, 0.4, 0.15]))
+    if kind == "box":
+        mask = np.zeros(shape, dtype=np.float32)
+        mask[..., : max(1, shape[-1] // 2)] = 1.0
+    elif kind == "random":
+        mask = (rng.random(shape) > rng.uniform(0.3, 0.7)).astype(np.float32)
+    else:
+        mask = rng.random(shape, dtype=np.float32)
+    n = int(rng.choice([4, 7, 10]))
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    sb = sigma.reshape((-1,) + (1,) * (len(shape) - 1))
+    x = ((sb * noise + (1 - sb) * y) if flow else (y + noise * sb)).astype(np.float32)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(2 * n)]
+    return dict(shape=shape, flow=flow, sigma=sigma, mask=mask, n=n, y=y, noise=noise, x=x, draws=draws, kind=kind,
+                patience=int(rng.choice([1, 1, 2])), lamb=float(rng.choice([5.0, 2.0])), quantile=float(rng.uniform(0.3, 0.8)))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_early_stop_configurations_match_the_oracle_stopper(seed):
+    """Seeded sweep of the device-side stop rule (LP_FL_ES) against the oracle's restatement of earlystop.py:58-336:
+    shapes with and without a ring (4-D / other ranks), per-row sigmas, hard and soft masks, patience 1-2.  The
+    threshold is placed inside the run's own distance distribution (a quantile of a stopper-free dry run, nudged away
+    from every observed distance so fp32-vs-double summation cannot flip a comparison), so stops, resets and drift
+    vetoes all occur."""
+    import torch
+    from lanpaint_amd import LanPaint
+    c = _es_case(seed)
+    times = times_from_sigma(c["sigma"], c["flow"])
+
+    def oracle(thr):
+        it = iter(c["draws"])
+        o = OracleLanPaint(MODELS["linear_tuple"](flow=c["flow"]), c["n"], 15.0, c["lamb"], 1.0, 0.2, is_flow=c["flow"],
+                           randn=lambda like: next(it))
+        xo = c["x"].copy()
+        out = o(xo, c["y"], c["noise"], c["sigma"], c["mask"], times,
+                {"lanpaint_semantic_stop": {"threshold": thr, "patience": c["patience"]}}, 0)
+        return o, xo, out, sum(1 for _ in it)
+
+    dry, _, _, _ = oracle(1e-30)                                        # never stops: the distances of the full run
+    dists = np.asarray([t["dist"] for t in dry.last_stopper.trace])
+    scale = dry.last_stopper.threshold_eff / 1e-30                      # abt scaling of the threshold
+    thr_eff = float(np.quantile(dists, c["quantile"]))
+    gaps = np.abs(dists - thr_eff) / thr_eff
+    if gaps.min() < 1e-3:
+        thr_eff *= 1.0 + 4e-3
+    o, xo, out_o, left_o = oracle(thr_eff / scale)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    it2 = iter([tt(d) for d in c["draws"]])
+    eng = LanPaint(MODELS["linear_tuple"](flow=c["flow"]), c["n"], 15.0, c["lamb"], 1.0, 0.2, IS_FLOW=c["flow"],
+                   rng=lambda like: next(it2))
+    trace = []
+    mo = {"lanpaint_semantic_stop": {"threshold": thr_eff / scale, "patience": c["patience"]}, "lanpaint_semantic_trace": trace}
+    xg = tt(c["x"])
+    out_g = eng(xg, tt(c["y"]), tt(c["noise"]), tt(c["sigma"]), tt(c["mask"]), tuple(tt(t) for t in times), mo, 0)
+    torch.cuda.synchronize()
+    what = f"seed={seed} shape={c['shape']} flow={c['flow']} mask={c['kind']} n={c['n']} patience={c['patience']}"
+    tr_o = o.last_stopper.trace
+    assert eng.iterations_run == o.iterations_run, what
+    assert [t["patience_counter"] for t in trace] == [t["counter"] for t in tr_o], what
+    assert [t["stopped"] for t in trace] == [t["stopped"] for t in tr_o], what
+    np.testing.assert_allclose([t["dist"] for t in trace], [t["dist"] for t in tr_o], rtol=3e-4, err_msg=what)
+    assert sum(1 for _ in it2) == left_o, what
+    assert_close(xg.cpu().numpy(), xo, what + " x", rel=5e-5)
+    assert_close(out_g.cpu().numpy(), out_o, what + " out", rel=5e-5)
