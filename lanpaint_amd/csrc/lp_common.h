@@ -4,12 +4,10 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
-// rocRAND's device code is what torch's own kernels inline for torch.randn (LP_RNG_TORCH).  The library is built
-// with -ffp-contract=on (lanpaint_amd/build.py): torch's build contracts a*b+c only inside one expression, and
-// under hipcc's default "fast" the Box-Muller results differ in the last bit in ~15 % of the draws -- measured on
-// the MI355X against torch.randn, 0 mismatches with "on" (a file-scope pragma around this include is not enough).
-#include <rocrand/rocrand_kernel.h>
-
+// LP_RNG_TORCH restates what torch's own kernels inline for torch.randn (ATen's Philox mapping over rocRAND's normal
+// transform).  The library is built with -ffp-contract=on (lanpaint_amd/build.py): torch's build contracts a*b+c only
+// inside one expression, and under hipcc's default "fast" the Box-Muller results differ in the last bit in ~15 % of the
+// draws -- measured on the MI355X against torch.randn, 0 mismatches with "on".
 #include "lanpaint_hip.h"
 
 namespace lp {
@@ -64,6 +62,21 @@ __device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_
 // Philox4x32-10 as in Random123 / rocRAND's philox4x32_10_engine (same constants, same output order): the counter
 // is (offset / 4 [64 bit], subsequence [64 bit]), the key the seed.  Written out so that a launch evaluates exactly
 // one block per call (rocrand_init + rocrand4 carry state bookkeeping the compiler does not always drop).
+// rocRAND's Box-Muller (rocrand_normal.h, box_muller(unsigned, unsigned)) restated expression for expression -- the
+// same constants, the same fused a + x*a shapes, library logf / sqrtf, the native sine / cosine of __sincosf: the
+// library no longer reaches into rocrand_device::detail.  (sine first: .x of the pair is the sine branch.)
+__device__ __forceinline__ float2 box_muller_u32(uint32_t x, uint32_t y) {
+#pragma clang fp contract(on)
+    float2 r;
+    const float u = 2.3283064e-10f + (x * 2.3283064e-10f);
+    const float v = 1.46291807e-09f + (y * 1.46291807e-09f);
+    const float s = sqrtf(-2.0f * logf(u));
+    __sincosf(v, &r.x, &r.y);
+    r.x *= s;
+    r.y *= s;
+    return r;
+}
+
 __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t subseq, uint64_t seed) {
     uint32_t c0 = static_cast<uint32_t>(ctr), c1 = static_cast<uint32_t>(ctr >> 32);
     uint32_t c2 = static_cast<uint32_t>(subseq), c3 = static_cast<uint32_t>(subseq >> 32);
@@ -95,10 +108,10 @@ __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64
         q = static_cast<uint32_t>(li / bg);
     }
     const uint4 c = philox4x32_10((offset >> 2) + (q >> 2), idx, seed);
-    // rocrand_normal4 = Box-Muller on (c.x, c.y) and on (c.z, c.w); only the pair this element's value comes
+    // rocrand_normal4 (what ATen calls) = Box-Muller on (c.x, c.y) and on (c.z, c.w); only the pair this element's value comes
     // from is transformed (the other three values belong to elements bg, 2 bg, 3 bg away)
     const uint32_t ii = q & 3u;
-    const float2 r = rocrand_device::detail::box_muller(ii < 2 ? c.x : c.z, ii < 2 ? c.y : c.w);
+    const float2 r = box_muller_u32(ii < 2 ? c.x : c.z, ii < 2 ? c.y : c.w);
     const float v = (ii & 1u) ? r.y : r.x;
     return v * 1.0f + 0.0f;
 }
@@ -108,7 +121,7 @@ __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64
 __device__ __forceinline__ void torch_normal4(uint32_t idx, uint64_t seed, uint64_t offset, float (&o)[4]) {
 #pragma clang fp contract(on)
     const uint4 c = philox4x32_10(offset >> 2, idx, seed);
-    const float2 a = rocrand_device::detail::box_muller(c.x, c.y), b = rocrand_device::detail::box_muller(c.z, c.w);
+    const float2 a = box_muller_u32(c.x, c.y), b = box_muller_u32(c.z, c.w);
     o[0] = a.x * 1.0f + 0.0f; o[1] = a.y * 1.0f + 0.0f; o[2] = b.x * 1.0f + 0.0f; o[3] = b.y * 1.0f + 0.0f;
 }
 
