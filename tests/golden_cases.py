@@ -93,9 +93,10 @@ CASES = {
     "ve_zero_noise":   dict(shape=(1, 4, 8, 8), sigma=[2.0], zero_noise=True, seed=17),
     "ve_lambda_beta":  dict(shape=(1, 4, 8, 8), sigma=[2.0], hyper=dict(Lambda=8.0, Beta=0.5, StepSize=0.15), seed=18),
     "ve_sdxl_shape":   dict(shape=(1, 4, 32, 32), sigma=[1.0], seed=19),
-    # BASELINE shapes at FULL size, straight from the reference (no oracle in between): C2 = SDXL 1x4x128x128 and
-    # C4 = Flux 1x16x64x64, one sigma call of 5 think iterations.  The xi stream comes from a numpy seed (the
+    # BASELINE shapes at FULL size, straight from the reference (no oracle in between): C1 = SD1.5 1x4x64x64, C2 = SDXL
+    # 1x4x128x128 and C4 = Flux 1x16x64x64, one sigma call of 5 think iterations.  The xi stream comes from a numpy seed (the
     # reference's torch.randn_like is fed from it), so the fixture only has to store the two outputs.
+    "ve_sd15_full":    dict(shape=(1, 4, 64, 64), sigma=[2.5], seed=35, xi_seed=4244),          # C1 = SD1.5 1x4x64x64
     "ve_sdxl_full":    dict(shape=(1, 4, 128, 128), sigma=[1.0], seed=33, xi_seed=4242),
     "flow_flux_full":  dict(shape=(1, 16, 64, 64), sigma=[0.6], flow=True, seed=34, xi_seed=4243),
     # flow / flux (Flux, Wan, SD3 notation)
