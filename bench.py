@@ -28,8 +28,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# RCCL / IPC between the ranks of one node needs dmabuf IPC on this driver stack; must be in the environment before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
