@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 9
+#define LP_ABI_VERSION 10
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -243,7 +243,7 @@ typedef struct lp_step_desc {
     float*       es_x0s[3];      /* the three rotating x0s buffers (== es->x0s_buf, as launch arguments so the kernel
                                     selects one by slot index instead of chasing a pointer through the state)     */
     const float* es_ring;        /* mask-edge ring weight (lp_boundary_ring; 4-D latents), or NULL           */
-    double*      es_partials;    /* device scratch: 2 x 8 doubles per block of the launch                    */
+    float*       es_partials;    /* device scratch: 2 x 8 floats per block of the launch                     */
     double*      es_host;        /* mailbox, LP_ES_MAILBOX_DOUBLES(es_n_steps) doubles                       */
     double       es_threshold;   /* threshold before the abt scaling (earlystop.py:78-81)                    */
     int64_t      es_seq_base;    /* es_reset: sequence base of this call                                     */

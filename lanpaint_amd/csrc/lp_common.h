@@ -474,6 +474,39 @@ __device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
     }
 }
 
+// The same reductions through DPP lane moves (VALU, no LDS crossbar): the six-sum shuffle tree above is 72
+// ds_bpermute and measured ~1 us per call inside the early-stop step kernel; this is ~0.1-0.2 us.  Fixed order
+// (butterfly inside each row of 16 lanes, then row 0 -> 1, 2 -> 3, {0,1} -> {2,3}); the total is valid in the LAST
+// lane of the wave (kWave - 1) only.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(b), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<long long>(static_cast<uint32_t>(lo)));
+}
+template <int CTRL, int ROW_MASK, typename T, int N>
+__device__ __forceinline__ void dpp_level(T (&v)[N]) {
+    T t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = dpp_move<CTRL, ROW_MASK>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += t[k];
+}
+template <typename T, int N>
+__device__ __forceinline__ void wave_sum_dpp(T (&v)[N]) {
+    dpp_level<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
+    dpp_level<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
+    dpp_level<0x124, 0xf>(v);     // row_ror 4
+    dpp_level<0x128, 0xf>(v);     // row_ror 8: every lane of a row holds the row's sum
+    dpp_level<0x142, 0xa>(v);     // row_bcast 15 into rows 1 and 3 (rows 0, 2 add the 0.0 of a masked-off move)
+    dpp_level<0x143, 0xc>(v);     // row_bcast 31 into rows 2 and 3: lane 63 = the wave's sum
+}
+
 __host__ __device__ inline int x0_dtype(uint32_t flags) {
     return (flags & LP_FL_X0_BF16) ? DT_BF16 : (flags & LP_FL_X0_F16) ? DT_F16 : DT_F32;
 }

@@ -18,6 +18,7 @@
 //   exact OU step + noise       lanpaint.py:232-254
 //   overdamped scheme           lanpaint.py:274-286 (second half-step uses the OLD C)
 //   back to model space         lanpaint.py:144-147, 163, 168
+#include <cstddef>
 #include <cstdlib>
 
 #include "lp_common.h"
@@ -113,7 +114,6 @@ __device__ __forceinline__ float ou_general(float x, float tau, float a, float c
 }
 
 // ---- inner early stop on the device (earlystop.py:58-336, default metric) ----------------------------------
-constexpr uint32_t kFlEsFold = 1u << 31;   // internal (set by the dispatcher): the decision of iteration i - 1 is folded into launch i
 constexpr int kEsSums = 6;    // { sum w1 dA^2, sum w1, sum w2 dA^2, sum w2, sum w1 dB^2, sum w2 dB^2 }
 
 __device__ __forceinline__ double clamp01(double v) { return v <= 0.0 ? 0.0 : (v >= 1.0 ? 1.0 : v); }
@@ -146,21 +146,46 @@ __device__ __forceinline__ void es_post_seq(double* host, int64_t seq) {
     __hip_atomic_store(reinterpret_cast<int64_t*>(host), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Block-wide fixed-order total of each thread's six partial sums (thread t holds rows t, t + 256, ... of the per-block
+// table): DPP inside the wave, the waves in order through LDS.  Every thread returns the same bits; the folded
+// prologue of the step kernel and lp_es_decide_kernel both come here, so a captured and an eager loop agree exactly.
+// (Blocks of exactly four waves -- the dispatcher launches LP_FL_ES work with 256 threads -- and all 24 LDS words read
+// before the first add: a run-time wave loop made it 18 dependent LDS round trips, 0.9 us by the shader clock.)
+__device__ __forceinline__ void es_block_total(float (&v)[kEsSums], float (&tot)[kEsSums], float (*part)[kEsSums]) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    wave_sum_dpp(v);
+    if (lane == kWave - 1) {
+#pragma unroll
+        for (int k = 0; k < kEsSums; ++k) part[wave][k] = v[k];
+    }
+    __syncthreads();
+    float p[4][kEsSums];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+#pragma unroll
+        for (int k = 0; k < kEsSums; ++k) p[w][k] = part[w][k];
+    }
+#pragma unroll
+    for (int k = 0; k < kEsSums; ++k) tot[k] = ((p[0][k] + p[1][k]) + p[2][k]) + p[3][k];
+}
+
 // The stop rule of one iteration (earlystop.py:279-313) from the six sums; one thread.  `st` is the state as ONE
 // block load at the top of the deciding kernel (field-by-field reads through the pointer cost a memory round trip
 // each: 9 -> ~5 us per iteration at SDXL size), updated in registers and written back by the caller.
-__device__ __forceinline__ void es_decide(const lp_step_desc& d, lp_es_state& st, const double (&s)[kEsSums], bool have_prev,
+__device__ __forceinline__ void es_decide(const lp_step_desc& d, lp_es_state& st, const float (&sf)[kEsSums], bool have_prev,
                                           bool have_anchor, int i, bool post) {
     double* host = post ? d.es_host : nullptr;
     const bool has_ring = d.es_ring != nullptr;
+    const float* s = sf;
     const double nan = __builtin_nan("");
-    double dist_in = s[0] / (s[1] + 1e-12), dist_ring = nan, dist_drift = nan;
+    // fp32 quotients like the reference's (earlystop.py:55); only the threshold compare is in double
+    double dist_in = static_cast<double>(s[0] / (s[1] + 1e-12f)), dist_ring = nan, dist_drift = nan;
     double dist = dist_in;
     if (have_prev && has_ring) {
-        dist_ring = s[2] / (s[3] + 1e-12);
+        dist_ring = static_cast<double>(s[2] / (s[3] + 1e-12f));
         dist = dist_in > dist_ring ? dist_in : dist_ring;
     }
-    const bool enabled = st.enabled != 0 && s[1] >= 1e-6;           // earlystop.py:111-117
+    const bool enabled = st.enabled != 0 && s[1] >= 1e-6f;          // earlystop.py:111-117
     int counter = st.counter, anchor = st.anchor_slot, stopped = 0;
     const int cur = st.write_slot;                                   // this iteration's x0s
     if (enabled) {
@@ -169,8 +194,8 @@ __device__ __forceinline__ void es_decide(const lp_step_desc& d, lp_es_state& st
             if (anchor < 0) {
                 anchor = cur;
             } else if (have_anchor) {
-                const double di = s[4] / (s[1] + 1e-12);
-                const double dr = has_ring ? s[5] / (s[3] + 1e-12) : nan;
+                const double di = static_cast<double>(s[4] / (s[1] + 1e-12f));
+                const double dr = has_ring ? static_cast<double>(s[5] / (s[3] + 1e-12f)) : nan;
                 dist_drift = has_ring ? (di > dr ? di : dr) : di;
                 dist = dist > dist_drift ? dist : dist_drift;
             }
@@ -209,6 +234,12 @@ __device__ __forceinline__ void es_decide(const lp_step_desc& d, lp_es_state& st
     }
 }
 
+// the fields a decision changes (the rest are per-call constants the reset wrote into both slots of the ping-pong pair)
+__device__ __forceinline__ void es_store_dynamic(lp_es_state* dst, const lp_es_state& st) {
+    dst->stopped = st.stopped; dst->counter = st.counter; dst->n_ran = st.n_ran; dst->cur_slot = st.cur_slot;
+    dst->anchor_slot = st.anchor_slot; dst->write_slot = st.write_slot; dst->total_ran = st.total_ran;
+}
+
 constexpr uint32_t kPost = LP_PH_POST_FIRST | LP_PH_POST_STEADY;
 constexpr uint32_t kTouchXt = LP_PH_REPLACE | kPost | LP_PH_PRE_HALF;
 
@@ -228,75 +259,76 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // idx + bg, idx + 2 bg, idx + 3 bg -- so ONE Philox4x32 block and its two Box-Muller pairs serve all four, as
 // in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
 // ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES); run-time phase kernel only.
-template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, bool ES = false>
+template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, int ES = 0>
 __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     constexpr bool PER_EL = MODE == MODE_PER_EL;
     constexpr bool HARD = MODE == MODE_HARD;
-    static_assert(!ES || (PH == 0 && !ST && !PER_EL), "early stop runs in the run-time phase kernel, row-table modes");
+    static_assert(!ES || (!ST && !PER_EL && (PH & LP_PH_REPLACE) == 0), "early stop: think-step launches of the row-table modes");
+    constexpr bool es_fold = ES == 2;               // the verdict of iteration i - 1 rides in launch i (small grids)
     const int row = blockIdx.y;
     const uint32_t fl = d.flags;
-    uint32_t ph_rt = PH ? PH : d.phases;             // compile-time for the hot combinations
     bool es_gated = false, es_idle = false;
     int es_prev = -1, es_anchor = -1, es_write = 0;
-    bool es_fold = false;
+    bool es_keeper = false;
+    // folded decision: what its prologue loads (state fields, the previous launch's per-block sums)
+    lp_es_state es_lite;
+    uint2 es_words[8];
+    float es_fv[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (ES) {
         es_gated = (fl & LP_FL_ES_GATED) != 0;
-        es_fold = (fl & kFlEsFold) != 0;
-        int stopped;
-        if (es_fold) {
+        if constexpr (es_fold) {
             // Folded decision (latency-bound sizes): launch i first applies the stop rule of iteration i - 1 -- every
             // block reduces the previous launch's per-block sums itself (same fixed order -> same bits in every
             // block) and steps the state in registers; block 0 stores it.  The state ping-pongs between two slots
             // and the sums between two buffers, so nobody reads what a neighbour block of the same launch writes.
             // This replaces a one-block kernel between every two launches: ~5 us per iteration at SDXL size.
-            const int i = d.es_index, rd = (i + 1) & 1;
+            // Everything the verdict needs is only LOADED here; it is formed after the operand loads of the step have
+            // been issued as well (below, behind the Philox rounds), so the launch pays one memory round trip where a
+            // verdict-first order pays three (state -> sums -> the x0s buffers the verdict selects).
+            const int rd = (d.es_index + 1) & 1;
             const lp_es_state* sp = d.es + rd;
-            // the few fields every lane needs, as scalar loads; the whole state only travels through ONE thread (every
-            // lane holding a copy of the 104-byte struct sent it through LDS: 31 us per launch instead of 7)
-            lp_es_state lite;
-            lite.stopped = sp->stopped; lite.counter = sp->counter; lite.n_ran = sp->n_ran; lite.cur_slot = sp->cur_slot;
-            lite.anchor_slot = sp->anchor_slot; lite.write_slot = sp->write_slot; lite.enabled = sp->enabled;
-            lite.seq_base = 0; lite.total_ran = 0; lite.threshold_eff = sp->threshold_eff; lite.abt_val = 0.0;
-            const bool keeper = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
-            if (i > 0 && lite.stopped == 0) {
-                __shared__ double fold_part[4][kEsSums];
-                const unsigned nblocks = gridDim.x * gridDim.y;
-                const double* src = d.es_partials + static_cast<size_t>(rd) * nblocks * 8;
-                double v[kEsSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {
+            // The state's 64 leading bytes through VECTOR loads of one address (every lane the same words, made
+            // wave-uniform again with readfirstlane where the verdict is formed): a scalar load would be waited for by
+            // the next s_waitcnt lgkmcnt(0) -- the kernarg reads in front of the operand loads -- i.e. put its whole
+            // round trip back in front of them; vector loads retire in order behind nothing.
+            uint32_t lane_zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));          // opaque: keeps the address in a VGPR
+            const uint2* sv = reinterpret_cast<const uint2*>(sp) + lane_zero;
 #pragma unroll
-                    for (int k = 0; k < kEsSums; ++k) v[k] += src[static_cast<size_t>(b) * 8 + k];
-                }
-                const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-                wave_sum_n<kEsSums>(v);
-                if (lane == 0) {
+            for (int k = 0; k < 8; ++k) es_words[k] = sv[k];
+            es_keeper = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+            // thread t: rows t and t + blockDim of the previous launch's sums (the dispatcher folds up to 2 rows per
+            // thread).  Unconditional loads from clamped rows + selects: a predicated load becomes a branch with its
+            // own wait, six round trips in a row.
+            const unsigned nblocks = gridDim.x * gridDim.y;
+            const float* src = d.es_partials + static_cast<size_t>(rd) * nblocks * 8;
+            const unsigned t0 = threadIdx.x, t1 = threadIdx.x + blockDim.x;
+            const unsigned b0 = t0 < nblocks ? t0 : nblocks - 1, b1 = t1 < nblocks ? t1 : nblocks - 1;
+            float r0[kEsSums], r1[kEsSums];
 #pragma unroll
-                    for (int k = 0; k < kEsSums; ++k) fold_part[wave][k] = v[k];
-                }
-                __syncthreads();
-                double tot[kEsSums];
-#pragma unroll
-                for (int k = 0; k < kEsSums; ++k) tot[k] = fold_part[0][k] + fold_part[1][k] + fold_part[2][k] + fold_part[3][k];
-                const bool hp = lite.cur_slot >= 0, ha = lite.anchor_slot >= 0;
-                es_decide(d, lite, tot, hp, ha, i - 1, false);
-                if (keeper) {
-                    lp_es_state st = *sp;
-                    es_decide(d, st, tot, hp, ha, i - 1, true);
-                    d.es[i & 1] = st;
-                }
-            } else if (keeper) {
-                d.es[i & 1] = *sp;
+            for (int k = 0; k < kEsSums; ++k) {
+                r0[k] = src[static_cast<size_t>(b0) * 8 + k];
+                r1[k] = src[static_cast<size_t>(b1) * 8 + k];
             }
-            es_prev = lite.cur_slot; es_anchor = lite.anchor_slot; es_write = lite.write_slot; stopped = lite.stopped;
+#pragma unroll
+            for (int k = 0; k < kEsSums; ++k) es_fv[k] = (0.0f + (t0 < nblocks ? r0[k] : 0.0f)) + (t1 < nblocks ? r1[k] : 0.0f);
         } else {                                     // wave-uniform scalar loads of the device-side stop state
-            es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot; stopped = d.es->stopped;
-        }
-        if (es_gated && stopped != 0) {              // the loop has stopped: only re-emit x_in from the committed x_t
-            es_idle = true;
-            ph_rt = LP_PH_EMIT;
+            es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot;
+            if (es_gated && d.es->stopped != 0) {    // the loop has stopped: only re-emit x_in from the committed x_t
+                const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+                if (g >= d.el_per_row / VEC) return;
+                const int64_t i = static_cast<int64_t>(row) * d.el_per_row + g * VEC;
+                const float sc = load_row(d.coef, row).scale;
+                float xt[VEC], xo[VEC];
+                load_f32<VEC>(d.x_t, i, xt);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xo[k] = (fl & LP_FL_FLOW) ? xt[k] / sc : xt[k] * sc;
+                store_any<VEC>(d.x_in, xin_dtype(fl), i, xo);
+                return;
+            }
         }
     }
-    const uint32_t ph = ph_rt;
+    const uint32_t ph = PH ? PH : d.phases;          // compile-time for the hot combinations
     const bool flow = fl & LP_FL_FLOW;
     const bool post = ph & kPost;
     const bool given = fl & LP_FL_X0S_GIVEN;
@@ -412,12 +444,18 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         }
         if ((ph & LP_PH_PRE_HALF) && host_pre) load_f32<VEC>(d.xi_pre, i, xi_b);
         // early stop: the previous x0s, the drift anchor and the ring weight the metric compares against
-        float x0p[VEC], anc[VEC], rg[VEC], xi_r[VEC];
+        float x0p[VEC], anc[VEC], rg[VEC], xi_r[VEC], xt0[VEC], es_b0[VEC], es_b1[VEC], es_b2[VEC];
         const bool es_redo = ES && es_gated && (ph & LP_PH_POST_STEADY);    // redo the tentative half-step of the last launch
         if constexpr (ES) {
             if (post) {
-                if (es_prev >= 0) load_f32<VEC>(es_prev == 0 ? d.es_x0s[0] : es_prev == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0p);
-                if (es_anchor >= 0) load_f32<VEC>(es_anchor == 0 ? d.es_x0s[0] : es_anchor == 1 ? d.es_x0s[1] : d.es_x0s[2], i, anc);
+                if constexpr (es_fold) {      // which two of the three buffers the metric compares against is part of the pending verdict
+                    load_f32<VEC>(d.es_x0s[0], i, es_b0);
+                    load_f32<VEC>(d.es_x0s[1], i, es_b1);
+                    load_f32<VEC>(d.es_x0s[2], i, es_b2);
+                } else {
+                    if (es_prev >= 0) load_f32<VEC>(es_prev == 0 ? d.es_x0s[0] : es_prev == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0p);
+                    if (es_anchor >= 0) load_f32<VEC>(es_anchor == 0 ? d.es_x0s[0] : es_anchor == 1 ? d.es_x0s[1] : d.es_x0s[2], i, anc);
+                }
                 if (d.es_ring) load_f32<VEC>(d.es_ring, i, rg);
             }
         }
@@ -462,6 +500,44 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                 }
             }
         }
+
+        // ---- folded early stop: the verdict of the previous iteration, now that its inputs have had time to arrive --
+        if constexpr (ES) {
+            if constexpr (es_fold) {
+                const int it = d.es_index;
+                {
+                    const auto u = [&](int w) { return __builtin_amdgcn_readfirstlane(static_cast<int>((w & 1) ? es_words[w >> 1].y : es_words[w >> 1].x)); };
+                    const auto u64 = [&](int w) { return (static_cast<uint64_t>(static_cast<uint32_t>(u(w + 1))) << 32) | static_cast<uint32_t>(u(w)); };
+                    static_assert(offsetof(lp_es_state, enabled) == 28 && offsetof(lp_es_state, seq_base) == 32 &&
+                                  offsetof(lp_es_state, abt_val) == 56, "lp_es_state layout");
+                    es_lite.stopped = u(0); es_lite.counter = u(1); es_lite.n_ran = u(2); es_lite.cur_slot = u(3);
+                    es_lite.anchor_slot = u(4); es_lite.write_slot = u(5); es_lite.enabled = u(7);
+                    es_lite.seq_base = static_cast<int64_t>(u64(8)); es_lite.total_ran = static_cast<int64_t>(u64(10));
+                    es_lite.threshold_eff = __longlong_as_double(static_cast<long long>(u64(12)));
+                    es_lite.abt_val = __longlong_as_double(static_cast<long long>(u64(14)));
+                }
+                if (it > 0 && es_lite.stopped == 0) {
+                    __shared__ float fold_part[4][kEsSums];
+                    float tot[kEsSums];
+                    es_block_total(es_fv, tot, fold_part);
+                    const bool hp = es_lite.cur_slot >= 0, ha = es_lite.anchor_slot >= 0;
+                    es_decide(d, es_lite, tot, hp, ha, it - 1, es_keeper);
+                }
+                if (es_keeper) es_store_dynamic(d.es + (it & 1), es_lite);
+                es_prev = es_lite.cur_slot; es_anchor = es_lite.anchor_slot; es_write = es_lite.write_slot;
+                es_idle = es_lite.stopped != 0;      // stopped: only re-emit x_in from the committed x_t (stores below)
+                if (post) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        x0p[k] = es_prev == 0 ? es_b0[k] : es_prev == 1 ? es_b1[k] : es_b2[k];
+                        anc[k] = es_anchor == 0 ? es_b0[k] : es_anchor == 1 ? es_b1[k] : es_b2[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) xt0[k] = xt[k];
+        }
+        const bool live = active && !es_idle;         // lanes that commit results (a stopped folded loop only emits)
 
         // ---- decode what was loaded in a storage format --------------------------------------------
         cvt_mask<VEC>(mfl, i, m_raw, m);
@@ -605,9 +681,9 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
                     }
                 }
             }
-            if ((fl & LP_FL_WRITE_X0S) && active) store_f32<VEC>(d.x0s, i, x0s);
+            if ((fl & LP_FL_WRITE_X0S) && live) store_f32<VEC>(d.x0s, i, x0s);
             if constexpr (ES) {
-                if (active) {
+                if (live) {
                     store_f32<VEC>(es_write == 0 ? d.es_x0s[0] : es_write == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0s);
                     // weighted squared differences (earlystop.py:52-55): w1 = 1 - mask, w2 = ring
 #pragma unroll
@@ -644,8 +720,14 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             }
         }
 
-        if (post && active) store_f32<VEC>(d.C, i, cv);
-        if ((ph & kTouchXt) && active) store_f32<VEC>(d.x_t, i, xt);
+        if (post && live) store_f32<VEC>(d.C, i, cv);
+        if ((ph & kTouchXt) && live) store_f32<VEC>(d.x_t, i, xt);
+        if constexpr (ES) {
+            if (es_fold && es_idle) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xe[k] = xt0[k];
+            }
+        }
 
         // ---- EMIT: model-space latent for the next backbone call --------------------------------
         if (ph & LP_PH_EMIT) {
@@ -670,21 +752,20 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     // the price of one more dependent launch, ~2 us.)
     if constexpr (ES) {
         if (es_idle || !post) return;
-        __shared__ double es_part[4][kEsSums];
+        // fp32 throughout, like the reference's own sums (earlystop.py:52-55), in a fixed order
+        __shared__ float es_part[4][kEsSums];
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-        double pv[kEsSums];
+        wave_sum_dpp(es_p);
+        if (lane == kWave - 1) {
 #pragma unroll
-        for (int k = 0; k < kEsSums; ++k) pv[k] = static_cast<double>(es_p[k]);
-        wave_sum_n<kEsSums>(pv);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < kEsSums; ++k) es_part[wave][k] = pv[k];
+            for (int k = 0; k < kEsSums; ++k) es_part[wave][k] = es_p[k];
         }
         __syncthreads();
         if (threadIdx.x < kEsSums) {
             const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
-            double v = 0.0;
-            for (unsigned w = 0; w < blockDim.x / kWave; ++w) v += es_part[w][threadIdx.x];
+            const float p0 = es_part[0][threadIdx.x], p1 = es_part[1][threadIdx.x], p2 = es_part[2][threadIdx.x],
+                        p3 = es_part[3][threadIdx.x];
+            const float v = ((p0 + p1) + p2) + p3;
             const size_t base = es_fold ? static_cast<size_t>(d.es_index & 1) * gridDim.x * gridDim.y * 8 : 0;
             d.es_partials[base + static_cast<size_t>(blk) * 8 + threadIdx.x] = v;
         }
@@ -698,7 +779,7 @@ __global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d,
     // load -- so the launch pays ONE memory round trip, not one per dependent step (state flag -> partials -> state
     // fields cost ~5.5 us per launch when chained; the data was written by the previous kernel on other XCDs and
     // comes from HBM).  A stopped loop simply discards what it loaded.
-    double v[kEsSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    float v[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {          // thread t: blocks t, t + 256, ...
 #pragma unroll
         for (int k = 0; k < kEsSums; ++k)
@@ -707,14 +788,9 @@ __global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d,
     lp_es_state st;
     if (threadIdx.x == 0) st = d.es[slot];
     const bool gated = (d.flags & LP_FL_ES_GATED) != 0;
-    __shared__ double es_part[4][kEsSums];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    wave_sum_n<kEsSums>(v);                                                 // fixed shuffle tree, then the four waves in order
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < kEsSums; ++k) es_part[wave][k] = v[k];
-    }
-    __syncthreads();
+    __shared__ float es_part[4][kEsSums];
+    float tot[kEsSums];
+    es_block_total(v, tot, es_part);                                        // fixed order: DPP tree, then the four waves
     if (threadIdx.x != 0) return;
     if (gated && st.stopped != 0) {      // stopped loop: its last launch tells the host the call is done
         if (d.es_index + 1 == d.es_n_steps) {
@@ -724,9 +800,6 @@ __global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d,
         }
         return;
     }
-    double tot[kEsSums];
-#pragma unroll
-    for (int k = 0; k < kEsSums; ++k) tot[k] = es_part[0][k] + es_part[1][k] + es_part[2][k] + es_part[3][k];
     es_decide(d, st, tot, st.cur_slot >= 0, st.anchor_slot >= 0, d.es_index, true);
     d.es[0] = st;                        // both slots: the next reset / the next watched launch start from slot 0
     d.es[1] = st;
@@ -756,11 +829,11 @@ static const Tune& tune() {
     return t;
 }
 
-template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2, bool ST = false, bool ES = false>
+template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2, bool ST = false, int ES = 0>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     const Tune& t = tune();
     const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
-    const int block = t.block ? t.block : 256;
+    const int block = (t.block && !ES) ? t.block : 256;      // (early-stop reductions assume four waves)
     int64_t bx = (groups + block - 1) / block;
     // One group per lane, no grid-stride loop: capping the grid at 2048 blocks cost 30 % on a 33 M-element
     // batch (220 -> 170 us; profiles/r01_microbench_kernel_variants.log); the BASELINE shapes all fit in
@@ -768,18 +841,23 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     if (bx < 1) bx = 1;
     if (bx > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
-    if constexpr (ES) {
+    if constexpr (ES != 0) {
         // gated loop on a latency-bound latent: the stop rule of iteration i - 1 rides in launch i (every block redoes the
         // small reduction), one closing lp_es_decide_kernel after the last launch.  Larger grids keep the one-block kernel
         // per iteration: re-reading nblocks x 48 B in every block would cost more than the launch it saves.
+        // (The folded kernel is its own instantiation, VEC = 1 only: its extra live state costs the streaming sizes
+        // occupancy they need and it never applies there.)
         const unsigned nblocks = grid.x * grid.y;
-        lp_step_desc dd = d;
-        const bool fold = (d.flags & LP_FL_ES_GATED) && nblocks <= 512 && !t.es_no_fold;
-        if (fold) dd.flags |= kFlEsFold;
-        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, dd);
+        const bool fold = VEC == 1 && (d.flags & LP_FL_ES_GATED) && nblocks <= 2u * static_cast<unsigned>(block) && !t.es_no_fold;
+        if constexpr (VEC == 1) {
+            if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, d);
+            else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, d);
+        } else {
+            hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, d);
+        }
         if ((d.phases & kPost) && !t.es_no_decide && (!fold || d.es_index + 1 == d.es_n_steps)) {
             if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-            hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(256), 0, stream, dd, nblocks, fold ? (d.es_index & 1) : 0);
+            hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(256), 0, stream, d, nblocks, fold ? (d.es_index & 1) : 0);
         }
         return hipGetLastError();
     }
@@ -800,9 +878,21 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     // a bit-packed mask is hard by construction; the audio correction needs the general branch
     const bool hard = (d.flags & LP_FL_MASK_BITS) && d.corr_el == nullptr;
     const bool x0_half = x0_dtype(d.flags) != DT_F32;
-    if (d.flags & LP_FL_ES)                                  // inner early stop evaluated on the device: run-time phase kernel
-        return hard ? launch<VEC, MODE_HARD, 0, 0, 2, false, true>(d, stream, timer)
-                    : launch<VEC, MODE_ROW, 0, 0, 2, false, true>(d, stream, timer);
+    if (d.flags & LP_FL_ES) {                                // inner early stop evaluated on the device
+        // the two launches a loop repeats, specialised like the plain hot kernels (bit-packed mask, fp32 heads): the
+        // run-time phase kernel spends 1.0 us of shader clock before its first operand load, these 0.6
+        if (hard && !x0_half && !d.xi_post && !d.xi_pre) {
+            const bool rt = d.rng_kind == LP_RNG_TORCH;
+            if (d.phases == (S | P | E))
+                return rt ? launch<VEC, MODE_HARD, S | P | E, 4, 1, false, 1>(d, stream, timer)
+                          : launch<VEC, MODE_HARD, S | P | E, 4, 0, false, 1>(d, stream, timer);
+            if (d.phases == (F | P | E))
+                return rt ? launch<VEC, MODE_HARD, F | P | E, 4, 1, false, 1>(d, stream, timer)
+                          : launch<VEC, MODE_HARD, F | P | E, 4, 0, false, 1>(d, stream, timer);
+        }
+        return hard ? launch<VEC, MODE_HARD, 0, 0, 2, false, 1>(d, stream, timer)
+                    : launch<VEC, MODE_ROW, 0, 0, 2, false, 1>(d, stream, timer);
+    }
     if (d.flags & LP_FL_MASK_U8) return launch<VEC, MODE_ROW, 0>(d, stream, timer);   // legacy format: run-time everything
     if (d.phases == (R | E))                                                         // replace step: no x0 at all
         return hard ? launch<VEC, MODE_HARD, R | E>(d, stream, timer) : launch<VEC, MODE_ROW, R | E>(d, stream, timer);
@@ -883,7 +973,6 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if (d.es_reset && !d.es) return LP_E_INVALID;
     if (d.flags & LP_FL_ES) {
         if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
-        if (d.flags & kFlEsFold) return LP_E_INVALID;             // internal bit
         if (!d.es_x0s[0] || !d.es_x0s[1] || !d.es_x0s[2]) return LP_E_INVALID;
         if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator
         if (tune().block && tune().block != 256) return LP_E_UNSUPPORTED;

@@ -163,7 +163,7 @@ class _DeviceStop:
         self.state.copy_(raw)
         rows = like.shape[0]
         blocks = ((like.numel() // rows + 255) // 256) * rows
-        self.partials = torch.empty(2 * blocks * 8, dtype=torch.float64, device=dev)
+        self.partials = torch.empty(2 * blocks * 8, dtype=torch.float32, device=dev)
         self.mailbox = torch.zeros(_cabi.LP_ES_TRACE0 + 8 * self.n_cap, dtype=torch.float64).pin_memory()
         self.f64 = self.mailbox.numpy()
         self.i64 = self.mailbox.view(torch.int64).numpy()
