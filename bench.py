@@ -376,8 +376,9 @@ def steady_kernel_name(workload, rng, mask_format):
     vec = 4 if n_el > 512 * 1024 else 1
     strided = rng == "torch" and vec == 4 and WORKLOADS[workload][0][0] == 1
     return (f"lp::lp_step_kernel<{vec}, {2 if mask_format == 'bits' else 0}, 28u, 4, {1 if rng == 'torch' else 0}, "
-            f"{'true' if strided else 'false'}, false>  (VEC, MODE: 2 = bit-packed hard mask, PH 28 = POST_STEADY|PRE_HALF|EMIT, "
-            "fp32 backbone outputs, RNG: 0 = Philox 1 = torch stream, ATen-strided lanes, early stop)")
+            f"{'true' if strided else 'false'}, 0>  (VEC, MODE: 2 = bit-packed hard mask, PH 28 = POST_STEADY|PRE_HALF|EMIT, "
+            "fp32 backbone outputs, RNG: 0 = Philox 1 = torch stream, ATen-strided lanes, early stop: 0 = off 1 = on "
+            "2 = on with the verdict folded into the launch)")
 
 
 def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ratios, n_think, args, busy=None):

@@ -251,7 +251,14 @@ typedef struct lp_step_desc {
     int32_t      es_index;       /* iteration i this launch's POST belongs to                                */
     int32_t      es_n_steps;     /* iterations of the loop (the last launch of a gated loop posts "done")    */
     int32_t      es_reset;       /* 1: this launch (a replace launch) initialises *es for a new call         */
+    /* Profiling builds only (library compiled with -DLP_SHADER_CLOCK, scripts/shader_clock.py): thread 0 of the
+     * first and of the last block store LP_CLK_STAMPS shader-clock stamps each (s_memtime ticks since its own kernel
+     * entry) at clk_out[0..] and clk_out[16..], then the 100 MHz s_memrealtime span of the kernel at [15] / [31].
+     * A release build ignores the field.                                                                      */
+    double*      clk_out;
 } lp_step_desc;
+#define LP_CLK_STAMPS 8  /* 0 entry, 1 operand loads issued, 2 noise generated, 3 operands arrived, 4 stop verdict
+                            formed, 5 arithmetic done, 6 stores issued, 7 per-block sums written                */
 
 typedef struct lp_final_desc {
     int64_t   n_el;

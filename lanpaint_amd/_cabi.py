@@ -62,7 +62,7 @@ class LpStepDesc(C.Structure):
         ("io_table_out", C.c_void_p), ("io_table_val", C.c_uint64 * 2),
         ("es", C.c_void_p), ("es_x0s", C.c_void_p * 3), ("es_ring", C.c_void_p), ("es_partials", C.c_void_p), ("es_host", C.c_void_p),
         ("es_threshold", C.c_double), ("es_seq_base", C.c_int64), ("es_patience_eff", C.c_int32), ("es_index", C.c_int32),
-        ("es_n_steps", C.c_int32), ("es_reset", C.c_int32),
+        ("es_n_steps", C.c_int32), ("es_reset", C.c_int32), ("clk_out", C.c_void_p),
     ]
 
 

@@ -32,20 +32,32 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, shader_clock=False):
+    """`shader_clock`: the profiling variant (-DLP_SHADER_CLOCK, scripts/shader_clock.py) as build/liblanpaint_hip_clk.so;
+    the product library is never built with it."""
+    if shader_clock:
+        out = os.path.join(ROOT, "build", "liblanpaint_hip_clk.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        return _compile(out, ["-DLP_SHADER_CLOCK"], verbose)
     if not force and not needs_build():
         return OUT
+    return _compile(OUT, [], verbose)
+
+
+def _compile(out, extra, verbose):
     # -ffp-contract=on: a*b+c fuses only inside one source expression (never across statements).  Needed for
     # LP_RNG_TORCH to reproduce torch.randn bit for bit (csrc/lp_common.h); it also makes the arithmetic of every
     # kernel independent of what the optimiser happens to fuse.
+    # -amdgpu-kernarg-preload-count: leading scalar / pointer kernel arguments arrive in SGPRs (csrc/step_kernel.hip)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared",
+           "-mllvm", "-amdgpu-kernarg-preload-count=14",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    cmd += extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, shader_clock="--shader-clock" in sys.argv)

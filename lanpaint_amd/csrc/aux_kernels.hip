@@ -117,11 +117,19 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
 // ---------------------------------------------------------------------------------
 // K3: out = model_out*(1-m) + y*m ; x_dst <- x_src      (lanpaint.py:154,156)
 // ---------------------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(256) void lp_finalize_kernel(const lp_final_desc d) {
+// The leading arguments are preloaded into SGPRs by the command processor (see lp_step_kernel in step_kernel.hip):
+// the four input streams, the I/O table, the length and the flags are there at entry instead of behind a cold read of
+// the argument segment (a replayed finalize was argument segment -> table -> stores, three dependent round trips).
+template <int VEC, int BLOCK>
+__global__ __launch_bounds__(256) void lp_finalize_kernel(const void* a_mask, const void* a_model_out, const float* a_y,
+                                                          const float* a_x_src, const uint64_t* a_io_table, int64_t a_n_el,
+                                                          uint32_t a_flags, const lp_final_desc d_arg) {
+    lp_final_desc d = d_arg;
+    d.mask = a_mask; d.model_out = a_model_out; d.y = a_y; d.x_src = a_x_src; d.io_table = a_io_table;
+    d.n_el = a_n_el; d.flags = a_flags;
     const int64_t groups = d.n_el / VEC;
     const int dt = x0_dtype(d.flags);
-    const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;     // one group per lane
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x;          // one group per lane
     // a finalize replayed from a hipGraph takes the caller's two tensors of THIS call from the table the replace
     // launch published (scalar loads, issued first; only the stores at the end of the body wait for them)
     float* const x_dst = d.io_table ? reinterpret_cast<float*>(d.io_table[0]) : d.x_dst;
@@ -172,10 +180,13 @@ int finalize_dispatch(const lp_final_desc* dp, hipStream_t stream) {
     const int block = groups <= 64 * 1024 ? 64 : 256;
     const int64_t bx = (groups + block - 1) / block;
     if (bx > 0x7fffffff) return LP_E_INVALID;
-    if (vec4)
-        hipLaunchKernelGGL(lp_finalize_kernel<4>, dim3(static_cast<unsigned>(bx)), dim3(block), 0, stream, d);
-    else
-        hipLaunchKernelGGL(lp_finalize_kernel<1>, dim3(static_cast<unsigned>(bx)), dim3(block), 0, stream, d);
+#define LP_FINAL_ARGS d.mask, d.model_out, d.y, d.x_src, d.io_table, d.n_el, d.flags, d
+    const dim3 grid(static_cast<unsigned>(bx));
+    if (vec4 && block == 64) hipLaunchKernelGGL((lp_finalize_kernel<4, 64>), grid, dim3(64), 0, stream, LP_FINAL_ARGS);
+    else if (vec4) hipLaunchKernelGGL((lp_finalize_kernel<4, 256>), grid, dim3(256), 0, stream, LP_FINAL_ARGS);
+    else if (block == 64) hipLaunchKernelGGL((lp_finalize_kernel<1, 64>), grid, dim3(64), 0, stream, LP_FINAL_ARGS);
+    else hipLaunchKernelGGL((lp_finalize_kernel<1, 256>), grid, dim3(256), 0, stream, LP_FINAL_ARGS);
+#undef LP_FINAL_ARGS
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 

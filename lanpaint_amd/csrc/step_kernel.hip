@@ -55,6 +55,34 @@ __device__ __forceinline__ RowCoef load_row(const float* __restrict__ coef, int 
     return r;
 }
 
+// The same row through VECTOR loads of one address (eight dwordx4, every lane the same words).  Scalar loads are
+// "invariant" to the compiler, which sinks them to their first use -- behind the first wait for the argument segment --
+// and then waits for them there: a second dependent round trip in front of the arithmetic.  A vector load stays where
+// it is written, i.e. it is in flight from kernel entry when the table pointer is preloaded (VEC = 1 kernels).
+__device__ __forceinline__ RowCoef load_row_early(const float* coef, int row) {
+    uint32_t lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));              // opaque: keeps the address in a VGPR
+    const float4* c = reinterpret_cast<const float4*>(coef + static_cast<int64_t>(row) * LP_COEF_STRIDE) + lane_zero;
+    float w[32];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 q = c[k];
+        w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+    }
+    static_assert(LP_COEF_STRIDE % 4 == 0 && LP_C_REGION1 + 10 <= 32, "coefficient row layout");
+    RowCoef r;
+    r.scale = w[LP_C_SCALE]; r.sqrt_abt = w[LP_C_SQRT_ABT]; r.oma = w[LP_C_OMA]; r.abt = w[LP_C_ABT];
+    r.rsigma = w[LP_C_RSIGMA]; r.dtx = w[LP_C_DTX]; r.dty = w[LP_C_DTY]; r.ax = w[LP_C_AX]; r.ay = w[LP_C_AY];
+    r.dx = w[LP_C_DX]; r.dy = w[LP_C_DY]; r.valid = w[LP_C_VALID];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float* q = w + (g ? LP_C_REGION1 : LP_C_REGION0);
+        r.reg[g] = RegionCoef{q[LP_R_E_FULL], q[LP_R_K_FULL], q[LP_R_STD_FULL], q[LP_R_E_HALF], q[LP_R_K_HALF],
+                              q[LP_R_STD_HALF], q[LP_R_DT], q[LP_R_A], q[LP_R_CX0], q[LP_R_CXT]};
+    }
+    return r;
+}
+
 // per-element coefficient set of the GENERAL path (soft masks, per-element times);
 // op order mirrors prepare_step_size (lanpaint.py:295-328) + lanpaint.py:212-214.
 struct ElemCoef {
@@ -240,6 +268,49 @@ __device__ __forceinline__ void es_store_dynamic(lp_es_state* dst, const lp_es_s
     dst->anchor_slot = st.anchor_slot; dst->write_slot = st.write_slot; dst->total_ran = st.total_ran;
 }
 
+// ---- profiling build (-DLP_SHADER_CLOCK; scripts/shader_clock.py): where a launch spends its time on the chip ---------
+// Stamps of the shader clock (s_memtime) at the points LP_CLK_STAMPS names, by thread 0 of the first and the last
+// block.  Stamp 3 waits for every outstanding load first, so it perturbs what follows a little; the release build
+// compiles all of it away.
+#ifdef LP_SHADER_CLOCK
+__device__ __forceinline__ uint64_t clk_now() {
+    uint64_t t;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ uint64_t clk_after_loads() {
+    uint64_t t;
+    asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ uint64_t clk_real() {
+    uint64_t t;
+    asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define LP_CLK_DECL                                                                                                  \
+    uint64_t clk_t[LP_CLK_STAMPS] = {}, clk_r0 = 0;                                                                  \
+    const bool clk_on = d_arg.clk_out && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1); \
+    if (clk_on) { clk_t[0] = clk_now(); clk_r0 = clk_real(); }
+#define LP_CLK(k) if (clk_on) clk_t[k] = clk_now();
+#define LP_CLK_LOADS(k) if (clk_on) clk_t[k] = clk_after_loads();
+#define LP_CLK_FLUSH                                                                                                 \
+    if (clk_on) {                                                                                                    \
+        double* clk_o = d_arg.clk_out + (blockIdx.x == 0 ? 0 : 16);                                                  \
+        for (int k = 0; k < LP_CLK_STAMPS; ++k) clk_o[k] = clk_t[k] ? static_cast<double>(clk_t[k] - clk_t[0]) : 0.0; \
+        clk_o[15] = static_cast<double>(clk_real() - clk_r0);                                                        \
+    }
+#else
+#define LP_CLK_DECL
+#define LP_CLK(k)
+#define LP_CLK_LOADS(k)
+#define LP_CLK_FLUSH
+#endif
+
+// Threads per block, fixed: blockDim.x read at run time is one more scalar-load round trip (a hidden kernel argument) in
+// front of the first operand load, and the early-stop reductions are written for four waves.
+constexpr int kBlock = 256;
+
 constexpr uint32_t kPost = LP_PH_POST_FIRST | LP_PH_POST_STEADY;
 constexpr uint32_t kTouchXt = LP_PH_REPLACE | kPost | LP_PH_PRE_HALF;
 
@@ -260,9 +331,38 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
 // ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES); run-time phase kernel only.
 template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, int ES = 0>
-__global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
+__global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const void* a2, const void* a3, const void* a4,
+                                                       const void* a5, int32_t a_el_per_row, uint32_t a_flags,
+                                                       const lp_step_desc d_arg) {
     constexpr bool PER_EL = MODE == MODE_PER_EL;
     constexpr bool HARD = MODE == MODE_HARD;
+    // Kernel-argument preload (gfx940+; build flag -amdgpu-kernarg-preload-count): the command processor puts the
+    // first 14 dwords of the argument segment into SGPRs before the wave starts.  The argument segment is written per
+    // launch, so reading the descriptor from it is a cold scalar load -- one DRAM round trip, ~0.3 us of the ~1 us a
+    // think step spends on the chip at SDXL size (scripts/shader_clock.py) -- and whatever is needed to ISSUE the
+    // first-touch loads of the step should not sit behind it.  Fourteen dwords hold six pointers, the row length and
+    // the flags (see step_args()): x_t, C and the two heads always; on the latency-bound sizes (VEC = 1) the
+    // coefficient table and the replayed graph's generator state, whose loads start the two longest dependent chains
+    // (state -> Philox rounds; table -> arithmetic), on the streaming sizes y and the mask (the region-aware decision
+    // waits for the mask).  The rest of the descriptor arrives while those loads fly.  (Older firmware runs the
+    // compiler's compatibility prologue, which loads the same SGPRs itself.)
+    constexpr bool SMALL = VEC == 1;
+    LP_CLK_DECL
+    lp_step_desc d = d_arg;
+    d.x_t = static_cast<float*>(a0); d.C = static_cast<float*>(a1);
+    if constexpr ((PH & LP_PH_REPLACE) != 0) {       // replace launch: its four input streams
+        d.x = static_cast<const float*>(a2);
+        d.known = d.noise = static_cast<const float*>(a3);
+        d.y = static_cast<const float*>(a4); d.mask = a5;
+    } else {
+        d.x0 = a2; d.x0_big = a3;
+        if constexpr (SMALL) {
+            d.coef = static_cast<const float*>(a4); d.rng_offset_ptr = static_cast<const uint64_t*>(a5);
+        } else {
+            d.y = static_cast<const float*>(a4); d.mask = a5;
+        }
+    }
+    d.el_per_row = a_el_per_row; d.flags = a_flags;
     static_assert(!ES || (!ST && !PER_EL && (PH & LP_PH_REPLACE) == 0), "early stop: think-step launches of the row-table modes");
     constexpr bool es_fold = ES == 2;               // the verdict of iteration i - 1 rides in launch i (small grids)
     const int row = blockIdx.y;
@@ -302,7 +402,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             // own wait, six round trips in a row.
             const unsigned nblocks = gridDim.x * gridDim.y;
             const float* src = d.es_partials + static_cast<size_t>(rd) * nblocks * 8;
-            const unsigned t0 = threadIdx.x, t1 = threadIdx.x + blockDim.x;
+            const unsigned t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
             const unsigned b0 = t0 < nblocks ? t0 : nblocks - 1, b1 = t1 < nblocks ? t1 : nblocks - 1;
             float r0[kEsSums], r1[kEsSums];
 #pragma unroll
@@ -315,7 +415,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         } else {                                     // wave-uniform scalar loads of the device-side stop state
             es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot;
             if (es_gated && d.es->stopped != 0) {    // the loop has stopped: only re-emit x_in from the committed x_t
-                const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+                const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
                 if (g >= d.el_per_row / VEC) return;
                 const int64_t i = static_cast<int64_t>(row) * d.el_per_row + g * VEC;
                 const float sc = load_row(d.coef, row).scale;
@@ -332,7 +432,6 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
     const bool flow = fl & LP_FL_FLOW;
     const bool post = ph & kPost;
     const bool given = fl & LP_FL_X0S_GIVEN;
-    const bool has_corr = d.corr_el != nullptr && !given;
     const int x0dt = X0W == 4 ? static_cast<int>(DT_F32) : x0_dtype(fl), xindt = xin_dtype(fl);
     const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
     const int64_t row_base = static_cast<int64_t>(row) * d.el_per_row;
@@ -363,25 +462,27 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             }
         }
     } else {
-        if constexpr (!PER_EL) rc = load_row(d.coef, row);
+        if constexpr (!PER_EL) {
+            if constexpr (SMALL && PH != 0) rc = load_row_early(d.coef, row);
+            else rc = load_row(d.coef, row);
+        }
     }
 
-    // per-call I/O pointers for the launches of this sigma call that live in a captured graph (lp_finalize)
-    if (d.io_table_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        d.io_table_out[0] = d.io_table_val[0];
-        d.io_table_out[1] = d.io_table_val[1];
+    // device-side generator state of a replayed graph: with the pointer preloaded its load starts here
+    uint64_t rng_w0 = 0, rng_w1 = 0;
+    bool rng_have = false;
+    if constexpr (SMALL) {
+        if (d.rng_offset_ptr) {
+            rng_w0 = d.rng_offset_ptr[0];
+            rng_w1 = d.rng_offset_ptr[1];
+            rng_have = true;
+        }
     }
-    if constexpr (PH == 0 || (PH & LP_PH_REPLACE) != 0) {
-        if (d.es_reset && d.es && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) es_reset_state(d, fold_coeffs);
-    }
-
-    const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
-    const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
 
     // one group per lane and no grid-stride loop: the launch covers the row (see launch()), which keeps every
     // address in this straight-line body a kernarg pointer + one offset and lets the scalar loads (coefficient
     // row, replayed-graph RNG counter) fly together with the vector loads instead of ahead of a loop
-    const int64_t g_raw = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t g_raw = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     // ES: every lane stays for the block reduction; a lane past the end recomputes the last group and stores nothing
     const bool active = g_raw < groups;
     if constexpr (!ES) {
@@ -401,7 +502,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         Raw<VEC> m_raw, x0_raw, x0b_raw;
         // HARD: bit-packed by dispatch; hot MODE_ROW variants: fp32 (uint8 masks are routed to PH = 0)
         const uint32_t mfl = HARD ? static_cast<uint32_t>(LP_FL_MASK_BITS) : (PH != 0 ? (fl & ~LP_FL_MASK_U8) : fl);
-        load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
+        if constexpr (!SMALL) load_mask_raw<VEC>(d.mask, mfl, i, m_raw);    // (SMALL: its pointer is not preloaded, below)
         // Region-aware streams (bit-packed mask, streaming sizes): an inpaint element needs head 0 only, a known one
         // needs head 1 and y only (lanpaint.py:182-184 with m in {0,1}).  Skipping a stream per LANE saves nothing (the
         // wave still touches the cache lines); skipping it for the whole WAVE does: 256 consecutive elements whose
@@ -429,7 +530,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         }
         if ((ph & LP_PH_POST_STEADY) || ((ph & LP_PH_PRE_HALF) && !post)) load_f32<VEC>(d.C, i, cv);
         if constexpr (RA) {
-            if (!given && d.x0_big != d.x0 && !(fl & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP)) && !has_corr) {
+            if (!given && d.x0_big != d.x0 && !(fl & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP))) {   // (HARD: no corr_el)
                 const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;   // this lane's 4 mask bits
                 need_known = __ballot(nib != 0u) != 0ull;
                 need_x0 = __ballot(nib != 0xFu) != 0ull;
@@ -438,6 +539,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         if (post) {
             if (need_x0) load_raw_w<VEC, X0W>(d.x0, x0dt, i, x0_raw);
             if (!(d.x0_big == d.x0 || given) && need_known) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i, x0b_raw);
+        }
+        // ---- from here on the descriptor proper is needed (the first wait for the argument segment) ----
+        if constexpr (SMALL) load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
+        const bool has_corr = d.corr_el != nullptr && !given;
+        const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
+        const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
+        if (post) {
             if (!given && need_known) load_f32<VEC>(d.y, i, yv);
             if (host_post) load_f32<VEC>(d.xi_post, i, xi_a);
             if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
@@ -460,13 +568,30 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             }
         }
 
+        // per-call I/O pointers for the launches of this sigma call that live in a captured graph (lp_finalize)
+        if (d.io_table_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            d.io_table_out[0] = d.io_table_val[0];
+            d.io_table_out[1] = d.io_table_val[1];
+        }
+        if constexpr (PH == 0 || (PH & LP_PH_REPLACE) != 0) {
+            if (d.es_reset && d.es && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) es_reset_state(d, fold_coeffs);
+        }
+
+        LP_CLK(1)
         // ---- Philox + Box-Muller while the loads are in flight ----------------------------
         if (need_rng) {
             const bool torch_kind = RNG == 2 ? (d.rng_kind == LP_RNG_TORCH) : (RNG == 1);
             uint64_t seq = d.rng_offset, seed = d.rng_seed;
-            if (d.rng_offset_ptr) {                              // device-side state of a replayed graph
-                seq += d.rng_offset_ptr[0];
-                if (torch_kind) seed = d.rng_offset_ptr[1];
+            if constexpr (!SMALL) {
+                if (d.rng_offset_ptr) {                          // device-side state of a replayed graph
+                    rng_w0 = d.rng_offset_ptr[0];
+                    rng_w1 = d.rng_offset_ptr[1];
+                    rng_have = true;
+                }
+            }
+            if (rng_have) {
+                seq += rng_w0;
+                if (torch_kind) seed = rng_w1;
             }
             if (torch_kind) {
                 // torch.randn_like(x_t) twice, in the reference's order: the POST draw, then the PRE draw
@@ -501,6 +626,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             }
         }
 
+        LP_CLK(2)
+        LP_CLK_LOADS(3)
         // ---- folded early stop: the verdict of the previous iteration, now that its inputs have had time to arrive --
         if constexpr (ES) {
             if constexpr (es_fold) {
@@ -537,6 +664,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) xt0[k] = xt[k];
         }
+        LP_CLK(4)
         const bool live = active && !es_idle;         // lanes that commit results (a stopped folded loop only emits)
 
         // ---- decode what was loaded in a storage format --------------------------------------------
@@ -720,6 +848,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             }
         }
 
+        LP_CLK(5)
         if (post && live) store_f32<VEC>(d.C, i, cv);
         if ((ph & kTouchXt) && live) store_f32<VEC>(d.x_t, i, xt);
         if constexpr (ES) {
@@ -746,6 +875,10 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
         }
     }
 
+    LP_CLK(6)
+    if constexpr (!ES) {
+        LP_CLK_FLUSH
+    }
     // ---- early stop: this block's partial sums; lp_es_decide_kernel (next launch) reduces them and applies the rule.
     // (One kernel with a "last block done" ticket needs a device-scope fence per block, i.e. an L2 write-back on
     // every XCD: measured 30 us per launch at 65 536 elements.  A kernel boundary gives the same visibility for
@@ -769,6 +902,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(const lp_step_desc d) {
             const size_t base = es_fold ? static_cast<size_t>(d.es_index & 1) * gridDim.x * gridDim.y * 8 : 0;
             d.es_partials[base + static_cast<size_t>(blk) * 8 + threadIdx.x] = v;
         }
+        LP_CLK(7)
+        LP_CLK_FLUSH
     }
 }
 
@@ -780,7 +915,7 @@ __global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d,
     // fields cost ~5.5 us per launch when chained; the data was written by the previous kernel on other XCDs and
     // comes from HBM).  A stopped loop simply discards what it loaded.
     float v[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {          // thread t: blocks t, t + 256, ...
+    for (unsigned b = threadIdx.x; b < nblocks; b += kBlock) {              // thread t: blocks t, t + 256, ...
 #pragma unroll
         for (int k = 0; k < kEsSums; ++k)
             v[k] += __builtin_nontemporal_load(d.es_partials + (static_cast<size_t>(slot) * nblocks + b) * 8 + k);
@@ -811,13 +946,12 @@ struct Timer {
 };
 
 struct Tune {
-    int vec = 0, block = 0;   // 0 = automatic
+    int vec = 0;              // 0 = automatic
     bool es_no_decide = false, es_no_fold = false;
     int64_t small_elems = 0;
     Tune() {
         // developer knobs for the micro-benchmarks (scripts/microbench_step.py); not an API
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_VEC")) vec = std::atoi(e);
-        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_BLOCK")) block = std::atoi(e);
         if (const char* e = std::getenv("LANPAINT_AMD_TUNE_SMALL")) small_elems = std::atoll(e);
         es_no_decide = std::getenv("LANPAINT_AMD_TUNE_ES_NO_DECIDE") != nullptr;
         es_no_fold = std::getenv("LANPAINT_AMD_TUNE_ES_NO_FOLD") != nullptr;
@@ -829,11 +963,21 @@ static const Tune& tune() {
     return t;
 }
 
+// the preloaded leading arguments of lp_step_kernel<VEC, ...> (see its head) followed by the descriptor
+#define LP_STEP_ARGS(d)                                                                                          \
+    static_cast<void*>((d).x_t), static_cast<void*>((d).C),                                                      \
+        ((PH & LP_PH_REPLACE) ? static_cast<const void*>((d).x) : (d).x0),                                        \
+        ((PH & LP_PH_REPLACE) ? static_cast<const void*>((d).replace_kind == LP_REPLACE_KNOWN ? (d).known : (d).noise) \
+                              : (d).x0_big),                                                                      \
+        ((PH & LP_PH_REPLACE) || VEC != 1 ? static_cast<const void*>((d).y) : static_cast<const void*>((d).coef)), \
+        ((PH & LP_PH_REPLACE) || VEC != 1 ? (d).mask : static_cast<const void*>((d).rng_offset_ptr)),             \
+        static_cast<int32_t>((d).el_per_row), (d).flags, (d)
+
 template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2, bool ST = false, int ES = 0>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     const Tune& t = tune();
     const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
-    const int block = (t.block && !ES) ? t.block : 256;      // (early-stop reductions assume four waves)
+    constexpr int block = kBlock;
     int64_t bx = (groups + block - 1) / block;
     // One group per lane, no grid-stride loop: capping the grid at 2048 blocks cost 30 % on a 33 M-element
     // batch (220 -> 170 us; profiles/r01_microbench_kernel_variants.log); the BASELINE shapes all fit in
@@ -850,10 +994,10 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
         const unsigned nblocks = grid.x * grid.y;
         const bool fold = VEC == 1 && (d.flags & LP_FL_ES_GATED) && nblocks <= 2u * static_cast<unsigned>(block) && !t.es_no_fold;
         if constexpr (VEC == 1) {
-            if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, d);
-            else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, d);
+            if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+            else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         } else {
-            hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, d);
+            hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         }
         if ((d.phases & kPost) && !t.es_no_decide && (!fold || d.es_index + 1 == d.es_n_steps)) {
             if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
@@ -863,9 +1007,9 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     }
     if (timer) {
         hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, timer->start,
-                              timer->stop, 0, d);
+                              timer->stop, 0, LP_STEP_ARGS(d));
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, d);
+        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
     }
     return hipGetLastError();
 }
@@ -934,7 +1078,7 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if (!dp) return LP_E_INVALID;
     const lp_step_desc& d = *dp;
     if (d.n_el <= 0 || d.rows <= 0 || d.el_per_row <= 0 || d.n_el != d.el_per_row * d.rows) return LP_E_INVALID;
-    if (d.rows > 65535) return LP_E_UNSUPPORTED;
+    if (d.rows > 65535 || d.el_per_row > 0x7fffffff) return LP_E_UNSUPPORTED;
     if (!d.mask || !d.x_t) return LP_E_INVALID;
     if ((d.flags & LP_FL_MASK_BITS) && ((d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_DENOISE)) || !aligned(d.mask, 4)))
         return LP_E_INVALID;
@@ -975,7 +1119,6 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
         if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
         if (!d.es_x0s[0] || !d.es_x0s[1] || !d.es_x0s[2]) return LP_E_INVALID;
         if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator
-        if (tune().block && tune().block != 256) return LP_E_UNSUPPORTED;
     } else if (d.flags & LP_FL_ES_GATED) {
         return LP_E_INVALID;
     }
