@@ -460,22 +460,8 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// N sums at once: the N shuffle chains are independent, so each level issues all its cross-lane moves before it
-// waits (one LDS-permute round trip per level instead of one per level AND value: 6 instead of 36 for six sums)
-template <int N>
-__device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        double t[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) t[k] = __shfl_down(v[k], off, kWave);
-#pragma unroll
-        for (int k = 0; k < N; ++k) v[k] += t[k];
-    }
-}
-
-// The same reductions through DPP lane moves (VALU, no LDS crossbar): the six-sum shuffle tree above is 72
-// ds_bpermute and measured ~1 us per call inside the early-stop step kernel; this is ~0.1-0.2 us.  Fixed order
+// N sums at once through DPP lane moves (VALU, no LDS crossbar): a six-sum __shfl_down tree is 72 ds_bpermute and
+// measured ~0.5 us per call inside the early-stop step kernel; this is ~0.1 us (scripts/shader_clock.py).  Fixed order
 // (butterfly inside each row of 16 lanes, then row 0 -> 1, 2 -> 3, {0,1} -> {2,3}); the total is valid in the LAST
 // lane of the wave (kWave - 1) only.
 template <int CTRL, int ROW_MASK>

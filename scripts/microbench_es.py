@@ -66,4 +66,3 @@ run("plain steady launch", lambda d, keep: None)
 run("ES step + decide (gated)", es_setup(True))
 run("ES step + decide (watched: mailbox fence per iteration)", es_setup(False))
 run("ES step + decide (gated, no mailbox at all)", es_setup(True, host=False))
-os.environ["LANPAINT_AMD_TUNE_ES_NO_DECIDE"] = "1"

@@ -342,6 +342,52 @@ def test_early_stop_inside_a_replayed_graph_equals_the_host_watched_loop(name, r
         assert any(r[2] < n for r in res[True])
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 160, 160), (1, 4, 256, 256), (1, 4, 384, 384), (3, 4, 96, 96)],
+                         ids=["fold_two_rows_per_thread", "vec1_decide_kernel", "vec4_decide_kernel", "fold_batch_rows"])
+def test_early_stop_graph_equals_eager_at_every_launch_geometry(shape):
+    """The gated (captured) loop against the watched (eager) one at the sizes that switch the early-stop machinery:
+    102 400 elements = 400 blocks, the verdict folded into the next launch with TWO rows of block sums per thread;
+    262 144 = 1 024 blocks of the 4 B/lane kernel and 589 824 of the 16 B/lane kernel, where a one-block kernel decides
+    and a stopped loop takes the emit-only exit; a batch whose rows share the fold.  torch's stream on both sides, so:
+    the same iteration count, the same trace, bitwise the same x / out over replays that stop on different iterations."""
+    import torch
+    from lanpaint_amd import LanPaint, pack_mask
+    rng = np.random.default_rng(shape[-1])
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    mask = np.ones(shape, dtype=np.float32)
+    h, w = shape[-2], shape[-1]
+    mask[..., h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 0.0
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")   # noqa: E731
+    n = 7
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(77)
+        eng = LanPaint(MODELS["linear_tuple"](), n, 15.0, 5.0, 1.0, 0.2, rng="torch", graph=graph)
+        yg, ng, mg = tt(y), tt(noise), pack_mask(tt(mask))
+        runs = []
+        for rep, (sg, thr) in enumerate([(1.0, 0.3), (1.4, 0.45), (1.0, 1e-9), (0.8, 0.3)]):
+            sigma = np.full((shape[0],), sg, dtype=np.float32)
+            times = tuple(tt(t) for t in gc.times_from_sigma(sigma, False))
+            mo = {"lanpaint_semantic_stop": {"threshold": thr, "patience": 1}, "lanpaint_semantic_trace": []}
+            x = tt(y + noise * np.float32(sg))
+            it0 = eng.iterations_run
+            out = eng(x, yg, ng, tt(sigma), mg, times, mo, 0)
+            runs.append((x.cpu().numpy(), out.cpu().numpy(), eng.iterations_run - it0,
+                         [(t["patience_counter"], t["stopped"]) for t in mo["lanpaint_semantic_trace"]],
+                         [t["dist"] for t in mo["lanpaint_semantic_trace"]]))
+        res[graph] = runs
+        if graph:
+            assert eng._graphs and all(c.es is not None for c in eng._graphs.values())
+    for e, g in zip(res[False], res[True]):
+        assert e[2] == g[2] and e[3] == g[3]
+        np.testing.assert_allclose(e[4], g[4], rtol=1e-12)
+        np.testing.assert_array_equal(e[0], g[0])
+        np.testing.assert_array_equal(e[1], g[1])
+    ran = [r[2] for r in res[True]]
+    assert ran[2] == n and min(ran) < n, ran            # the 1e-9 threshold never stops; the others stop early
+
+
 def test_early_stop_graph_equals_eager_with_bf16_backbone_input_and_fused_cfg_heads():
     """The gated loop next to the other launch options: the backbone input emitted as bf16 (`model_dtype`: stopped
     launches must re-emit it, the last one the fp32 x that is written back) and CFG heads combined in the kernel."""
