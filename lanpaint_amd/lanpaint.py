@@ -235,6 +235,9 @@ class _CapturedCall:
         self.key = None               # its key in the engine's graph table (siblings differ in the step count only)
         self.tail = None              # lp_call_desc that launches the graph alone (the replace went ahead, begin_call)
         self.model_options = None     # the dict the captured backbone calls were made with (kept alive: its id is in the key)
+        self.alive = True             # still in the engine's graph table
+        self.siblings = {}            # n_steps -> the capture of the same call shape for that count (finish_call)
+        self.times_seen = ()          # the (VE sigma, abt, flow t) tuples that passed the identity pre-check
 
 
 class LanPaint:
@@ -657,13 +660,16 @@ class LanPaint:
             n_steps = self.n_steps
         cap = cap0
         if cap0.ident[4] != n_steps:
-            cap = self._graphs.get(cap0.key[:2] + (int(n_steps),) + cap0.key[3:])
-            if cap is None or cap.tail is None or cap.model_options is not model_options or cap.ws is not cap0.ws:
-                # no capture for this count yet: the ordinary path captures it (and re-enqueues the replace step,
-                # which reads the same untouched x and publishes the same generator state)
-                return self(x, self.latent_image, self.noise, sigma, latent_mask, current_times, model_options, seed,
-                            n_steps=n_steps)
-            self._graphs.move_to_end(cap.key)
+            cap = cap0.siblings.get(n_steps)
+            if cap is None or not cap.alive:
+                cap = self._graphs.get(cap0.key[:2] + (int(n_steps),) + cap0.key[3:])
+                if cap is None or cap.tail is None or cap.model_options is not model_options or cap.ws is not cap0.ws:
+                    # no capture for this count yet: the ordinary path captures it (and re-enqueues the replace step,
+                    # which reads the same untouched x and publishes the same generator state)
+                    return self(x, self.latent_image, self.noise, sigma, latent_mask, current_times, model_options, seed,
+                                n_steps=n_steps)
+                cap0.siblings[n_steps] = cap
+                self._graphs.move_to_end(cap.key)
         if self.rng == "torch" and cap.launches:
             self._generator(x.device).set_offset(off + cap.launches)
             self._torch_consumed += cap.launches
@@ -685,15 +691,31 @@ class LanPaint:
                 and i[5] == seed and i[6] is self.rng and self.graph and not self._noise_regenerated
                 and i[7] == y.data_ptr() and i[8] == latent_mask.data_ptr()
                 and i[9] is getattr(latent_mask, "_lp_bits", None) and i[10] is getattr(latent_mask, "_lp_u8", None)
-                and i[11] == x.device and i[12] == sigma.numel() and i[13] == ve.numel() and i[14] == abt.numel()
-                and i[15] == ft.numel() and self.audio_indicator is None and self.audio_correction is None
+                and i[11] == x.device and i[12] == sigma.numel()
+                and self._times_ok(cap, current_times)
+                and self.audio_indicator is None and self.audio_correction is None
                 and not (self.early_stop_threshold > 0.0 and self.early_stop_patience > 0)
-                and x.dtype == f32 and sigma.dtype == f32 and ve.dtype == f32 and abt.dtype == f32 and ft.dtype == f32
+                and x.dtype == f32 and sigma.dtype == f32
                 and nz.dtype == f32 and nz.shape == x.shape and x.is_contiguous() and sigma.is_contiguous()
-                and ve.is_contiguous() and abt.is_contiguous() and ft.is_contiguous() and nz.is_contiguous()
+                and nz.is_contiguous()
                 and x.device.index == torch.cuda.current_device() and i[16] == self._override_state()
                 and i[17] == self._hyper_key() and (x.data_ptr() & 15) == 0
                 and not (isinstance(model_options, dict) and "lanpaint_semantic_stop" in model_options))
+
+    @staticmethod
+    def _times_ok(cap, current_times):
+        """The time tensors fit the capture (size, fp32, dense).  A caller that hands the same tensor objects call after
+        call -- KSamplerX0Inpaint alternates between two sets -- is only checked once per set."""
+        i, f32 = cap.ident, torch.float32
+        ve, abt, ft = current_times
+        for seen in cap.times_seen:                     # identity, never tensor ==
+            if seen[0] is ve and seen[1] is abt and seen[2] is ft:
+                return True
+        ok = (i[13] == ve.numel() and i[14] == abt.numel() and i[15] == ft.numel() and ve.dtype == f32 and abt.dtype == f32
+              and ft.dtype == f32 and ve.is_contiguous() and abt.is_contiguous() and ft.is_contiguous())
+        if ok:
+            cap.times_seen = (cap.times_seen + ((ve, abt, ft),))[-2:]
+        return ok
 
     def _hyper_key(self):
         """The public hyper-parameters a captured launch bakes in (the reference reads them on every call)."""
@@ -733,13 +755,14 @@ class LanPaint:
         cap = self._graphs.get(key)
         if cap is not None and cap.model_options is not model_options:
             del self._graphs[key]        # another dict at a recycled id(): the captured backbone calls used the old one
+            cap.alive = False
             cap = None
         if cap is None:
             cap = self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
             if cap is None:          # not capturable after all (see _capture): the eager path
                 return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
             while len(self._graphs) > self.MAX_GRAPHS:       # bound the static memory held by stale captures
-                self._graphs.popitem(last=False)
+                self._graphs.popitem(last=False)[1].alive = False
         else:
             self._graphs.move_to_end(key)
         self._iterations_run += cap.ran

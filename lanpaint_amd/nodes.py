@@ -266,6 +266,9 @@ class KSamplerX0Inpaint:
         self._mask_cache = None          # (weakref(denoise_mask), version, latent_mask): binarised once per run
         self._mailbox = None             # pinned host float32[4]: lp_sigma_times writes {step index, mean(1-abt), seq}
         self._seq = 0
+        self._times = None               # (rows, device, [two sets of (VE sigma, abt, flow t, buffer)]): the three time
+                                         # tensors of a call are views of one buffer, made once (a view costs the host
+                                         # ~1.5 us) and used by alternate calls
 
     def _mailbox_views(self):
         """The pinned host words the device writes the two scalars of the inner-step rule into (fine-grained host
@@ -312,15 +315,26 @@ class KSamplerX0Inpaint:
             # pinned host memory (lp_sigma_times_mailbox) -- no blocking device->host copy
             sig_c, sched = sigma.contiguous(), self.sigmas.contiguous()
             rows = sig_c.shape[0]
-            buf = torch.empty((3 * rows,), dtype=torch.float32, device=sigma.device)
+            tm = self._times
+            if tm is None or tm[0] != rows or tm[1] != sigma.device:
+                # Two sets, used by alternate calls: a call's launches read its times in stream order long before the
+                # call after the next overwrites them, and a backbone that keeps the previous call's `t` to compare it
+                # with the current one still sees two different tensors.
+                sets = []
+                for _ in range(2):
+                    b = torch.empty((3 * rows,), dtype=torch.float32, device=sigma.device)
+                    sets.append((b[:rows], b[rows:2 * rows], b[2 * rows:3 * rows], b))
+                self._times = tm = (rows, sigma.device, sets)
+            VE_Sigma, abt, Flow_t, buf = tm[2][self._seq & 1]
             mb = self._mailbox_views()[0]
             self._seq = fused_seq = (self._seq % 0x7ffffff0) + 1
-            with torch.cuda.device(sigma.device):
-                _cabi.check(_cabi.load().lp_sigma_times_mailbox(
-                    sig_c.data_ptr(), rows, sched.data_ptr(), sched.numel(), int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
-                    mb.data_ptr(), mb.data_ptr() + 8, fused_seq, raw_stream(sigma.device)),
-                    "lp_sigma_times_mailbox")
-            VE_Sigma, abt, Flow_t = buf[:rows], buf[rows:2 * rows], buf[2 * rows:3 * rows]
+            args = (sig_c.data_ptr(), rows, sched.data_ptr(), sched.numel(), int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
+                    mb.data_ptr(), mb.data_ptr() + 8, fused_seq, raw_stream(sigma.device))
+            if sigma.device.index == torch.cuda.current_device():     # (the context manager costs the host ~2 us)
+                _cabi.check(_cabi.load().lp_sigma_times_mailbox(*args), "lp_sigma_times_mailbox")
+            else:
+                with torch.cuda.device(sigma.device):
+                    _cabi.check(_cabi.load().lp_sigma_times_mailbox(*args), "lp_sigma_times_mailbox")
         elif IS_FLUX or IS_FLOW:                                            # nodes.py:242-245
             Flow_t = sigma
             abt = (1 - Flow_t) ** 2 / ((1 - Flow_t) ** 2 + Flow_t ** 2)
