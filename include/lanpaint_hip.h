@@ -128,6 +128,14 @@ typedef struct lp_hyper {
                                           half-step only feeds x_in -- and a POST_STEADY launch first redoes that half-step
                                           from the same noise (in-kernel generators only), so stopping after iteration i
                                           leaves exactly the reference's state after i iterations.                        */
+#define LP_FL_ES_CLOSE      (1u << 15) /* with LP_FL_ES_GATED on the LAST launch of a loop (es_index + 1 == es_n_steps) whose
+                                          verdict is folded into the launches (small grids): no closing decision kernel
+                                          follows.  The launch, having applied the verdict of the iteration before, accounts
+                                          its own iteration (n_ran, total_ran) and posts the call's "done" word itself; the
+                                          verdict of the last iteration is never formed -- stopping after the last iteration
+                                          changes nothing (earlystop.py:313 only breaks a loop that is over) -- and its trace
+                                          record is not written, so a caller that wants the full trace leaves the flag off.
+                                          Ignored where a one-block kernel decides every iteration anyway (larger grids).  */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 

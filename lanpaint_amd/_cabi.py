@@ -28,7 +28,7 @@ LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT, 
 LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
 LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED, LP_FL_MASK_BITS, LP_FL_NO_REGION_SKIP = 256, 512, 1024, 2048, 4096
-LP_FL_ES, LP_FL_ES_GATED = 1 << 13, 1 << 14
+LP_FL_ES, LP_FL_ES_GATED, LP_FL_ES_CLOSE = 1 << 13, 1 << 14, 1 << 15
 
 
 def mask_bits_bytes(n_el: int) -> int:

@@ -160,6 +160,9 @@ __device__ __forceinline__ void es_reset_state(const lp_step_desc& d, bool fold)
     const double abt_val = static_cast<double>(sum / static_cast<float>(n));        // float(torch.mean(abt).item())
     const double a = clamp01(abt_val);
     const double thr_eff = d.es_threshold * clamp01(4.0 * a * (1.0 - a));
+    // total_ran is never reset; a folded loop leaves it current in one slot of the pair only (LP_FL_ES_CLOSE)
+    const int64_t total = es[0].total_ran > es[1].total_ran ? es[0].total_ran : es[1].total_ran;
+    es->total_ran = total;
     es->stopped = 0; es->counter = 0; es->n_ran = 0;
     es->cur_slot = -1; es->anchor_slot = -1; es->write_slot = 0;
     es->enabled = thr_eff > 0.0 ? 1 : 0;
@@ -650,7 +653,27 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                     const bool hp = es_lite.cur_slot >= 0, ha = es_lite.anchor_slot >= 0;
                     es_decide(d, es_lite, tot, hp, ha, it - 1, es_keeper);
                 }
-                if (es_keeper) es_store_dynamic(d.es + (it & 1), es_lite);
+                if ((fl & LP_FL_ES_CLOSE) && it + 1 == d.es_n_steps) {
+                    // last launch of the loop and no closing decision kernel (LP_FL_ES_CLOSE): unless the loop has
+                    // stopped, this launch commits iteration `it` -- account it now and tell the host the call is done
+                    if (es_lite.stopped == 0) {
+                        es_lite.n_ran = it + 1;
+                        es_lite.total_ran += 1;
+                    }
+                    if (es_keeper) {
+                        // (this launch's own slot only: other blocks may still be reading the other one; the next
+                        // reset takes the running count from whichever slot is ahead)
+                        es_store_dynamic(d.es + (it & 1), es_lite);
+                        if (double* host = d.es_host) {
+                            host[1] = static_cast<double>(es_lite.n_ran); host[2] = static_cast<double>(es_lite.stopped);
+                            host[3] = es_lite.enabled ? 1.0 : 0.0; host[4] = es_lite.threshold_eff; host[5] = es_lite.abt_val;
+                            host[6] = static_cast<double>(es_lite.total_ran);
+                            es_post_seq(host, es_lite.seq_base + LP_ES_SEQ_DONE);
+                        }
+                    }
+                } else if (es_keeper) {
+                    es_store_dynamic(d.es + (it & 1), es_lite);
+                }
                 es_prev = es_lite.cur_slot; es_anchor = es_lite.anchor_slot; es_write = es_lite.write_slot;
                 es_idle = es_lite.stopped != 0;      // stopped: only re-emit x_in from the committed x_t (stores below)
                 if (post) {
@@ -999,7 +1022,8 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
         } else {
             hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         }
-        if ((d.phases & kPost) && !t.es_no_decide && (!fold || d.es_index + 1 == d.es_n_steps)) {
+        const bool close = fold && (d.flags & LP_FL_ES_CLOSE) && d.es_index + 1 == d.es_n_steps;
+        if ((d.phases & kPost) && !t.es_no_decide && !close && (!fold || d.es_index + 1 == d.es_n_steps)) {
             if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
             hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(256), 0, stream, d, nblocks, fold ? (d.es_index & 1) : 0);
         }
@@ -1119,7 +1143,8 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
         if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
         if (!d.es_x0s[0] || !d.es_x0s[1] || !d.es_x0s[2]) return LP_E_INVALID;
         if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator
-    } else if (d.flags & LP_FL_ES_GATED) {
+        if ((d.flags & LP_FL_ES_CLOSE) && !(d.flags & LP_FL_ES_GATED)) return LP_E_INVALID;
+    } else if (d.flags & (LP_FL_ES_GATED | LP_FL_ES_CLOSE)) {
         return LP_E_INVALID;
     }
 

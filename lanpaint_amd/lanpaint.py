@@ -33,7 +33,7 @@ from functools import partial
 import torch
 
 from . import _cabi
-from ._cabi import (LP_FL_ES, LP_FL_ES_GATED, LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_BITS, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
+from ._cabi import (LP_FL_ES, LP_FL_ES_GATED, LP_FL_ES_CLOSE, LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_BITS, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
                     LP_PH_EMIT, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_REPLACE, LP_REPLACE_FLOW,
                     LP_REPLACE_KNOWN, LP_REPLACE_VE)
 from .earlystop import LanPaintEarlyStopper
@@ -294,6 +294,7 @@ class LanPaint:
         self._graphs = OrderedDict()             # key -> _CapturedCall, LRU-bounded (MAX_GRAPHS)
         self._static_ws = {}                     # (shape, device, model dtype) -> workspace shared by the captures of that shape
         self._last_cap = None                    # the capture the previous call replayed (identity pre-check)
+        self._es_close = False                   # capture in progress: its loop closes itself (no trace requested)
         self._rng_counters = {}                  # device -> u64 counter read by captured Philox launches
         self._capturing = None                   # device u64 Philox counter while capturing
         self._cap_offset = 0
@@ -751,7 +752,8 @@ class LanPaint:
         key = (tuple(x.shape), x.device.index, int(n_steps), bool(IS_FLUX), bool(IS_FLOW), self.latent_image.data_ptr(),
                latent_mask.data_ptr(), m_c.data_ptr() if m_c is not None else 0, int(sigma.numel()),
                tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng, self._hyper_key(),
-               self.model_dtype, None if self._es_opts is None else (self._es_opts["threshold"], self._es_opts["patience_eff"]))
+               self.model_dtype, None if self._es_opts is None else (self._es_opts["threshold"], self._es_opts["patience_eff"],
+                                                                      self._es_opts["trace"] is not None))
         cap = self._graphs.get(key)
         if cap is not None and cap.model_options is not model_options:
             del self._graphs[key]        # another dict at a recycled id(): the captured backbone calls used the old one
@@ -872,6 +874,9 @@ class LanPaint:
         es_user = self._es_opts
         if es_user is not None:                    # the warm-up below is not the caller's run: keep it out of their trace
             self._es_opts = dict(es_user, trace=None)
+            # without a trace to fill nobody needs the verdict of the loop's LAST iteration: its launch closes the loop
+            # itself (LP_FL_ES_CLOSE) and the closing decision kernel -- one more graph node -- is not captured
+            self._es_close = es_user["trace"] is None
         with torch.cuda.stream(side):              # one complete eager call on the side stream: lazy inits
             xw = x.detach().clone()
             st = self._prologue(xw, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
@@ -1276,7 +1281,8 @@ class LanPaint:
                 self._launch_step(stream)
             output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
             if gated:
-                alive = self._set_model_output(d, output, base_flags | LP_FL_ES | LP_FL_ES_GATED | self._emit(st, last), shape)
+                close = LP_FL_ES_CLOSE if (last and self._es_close) else 0
+                alive = self._set_model_output(d, output, base_flags | LP_FL_ES | LP_FL_ES_GATED | close | self._emit(st, last), shape)
                 d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
                 self._set_xi(d, ws.x_t, want_pre=not last)
             else:
