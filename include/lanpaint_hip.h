@@ -182,7 +182,7 @@ typedef struct lp_es_state {
 
 typedef struct lp_step_desc {
     int64_t   n_el;            /* total latent elements                                   */
-    int64_t   el_per_row;      /* elements per batch row (C*(F)*H*W)                      */
+    int64_t   el_per_row;      /* elements per batch row (C*(F)*H*W), < 2^31               */
     int32_t   rows;            /* B                                                       */
     uint32_t  phases;          /* LP_PH_*                                                 */
     uint32_t  flags;           /* LP_FL_*                                                 */

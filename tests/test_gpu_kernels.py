@@ -547,3 +547,64 @@ def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert not torch.equal(res[0][0], x_t0) and torch.isfinite(res[0][0]).all()
+
+
+@pytest.mark.parametrize("stops", [False, True])
+def test_self_closing_gated_loop_through_the_c_abi(lib, stops):
+    """LP_FL_ES_CLOSE straight through lp_step: a gated loop of four launches on a latent small enough for the folded
+    verdict.  Without the flag the last launch is followed by the closing decision kernel, with it the launch accounts
+    its own iteration and posts "done" itself -- same x_t / C / x_in bits, same n_ran and running count in the state and
+    in the mailbox, for a loop that runs to its end (the backbone output moves every iteration) and for one that stops
+    after three iterations (a constant output: distance exactly 0); the flag without LP_FL_ES_GATED, or LP_FL_ES_GATED
+    without LP_FL_ES, is refused."""
+    import torch
+    import bench
+    from lanpaint_amd import _cabi
+    from lanpaint_amd.lanpaint import _DeviceStop
+    dev = torch.device("cuda", 0)
+    S, F, P, E = _cabi.LP_PH_POST_STEADY, _cabi.LP_PH_POST_FIRST, _cabi.LP_PH_PRE_HALF, _cabi.LP_PH_EMIT
+    n = 4
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for close in (0, _cabi.LP_FL_ES_CLOSE):
+        d, keep, n_el = bench.standalone_step(_cabi, "c1_sd15", dev, S | P | E)
+        bufs = keep[0]
+        torch.manual_seed(3)
+        for k in ("x_t", "C"):
+            bufs[k].copy_(torch.randn_like(bufs[k]))
+        ds = _DeviceStop(bufs["x_t"], n)
+        mailbox = torch.zeros(_cabi.LP_ES_TRACE0 + 8 * n, dtype=torch.float64, device=dev)
+        base = d.flags
+        d.es, d.es_partials, d.es_host = ds.state.data_ptr(), ds.partials.data_ptr(), mailbox.data_ptr()
+        for k in range(3):
+            d.es_x0s[k] = ds.x0s[k].data_ptr()
+        d.es_threshold, d.es_patience_eff, d.es_n_steps, d.es_seq_base = 1e-30, 2, n, 1000
+        # a replace-like launch that only resets the stop state (phases EMIT, no flags needed)
+        d.phases, d.flags, d.es_reset = E, base, 1
+        _cabi.check(lib.lp_step(ctypes.byref(d), st), "reset")
+        d.es_reset = 0
+        for i in range(n):
+            last = i == n - 1
+            d.phases = (F if i == 0 else S) | (0 if last else P) | E
+            d.flags = base | _cabi.LP_FL_ES | _cabi.LP_FL_ES_GATED | (close if last else 0)
+            d.es_index, d.rng_offset = i, 10 + i
+            if not stops:
+                bufs["x0"].add_(0.05 * torch.randn_like(bufs["x0"]))
+            _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+        torch.cuda.synchronize()
+        raw = ds.state.cpu().numpy().tobytes()
+        per = ctypes.sizeof(_cabi.LpEsState)
+        slots = [_cabi.LpEsState.from_buffer_copy(raw[k * per:(k + 1) * per]) for k in range(2)]
+        n_ran, total = max(s.n_ran for s in slots), max(s.total_ran for s in slots)     # the slot the loop ended in
+        mb = mailbox.cpu().numpy()
+        res.append(([bufs[k].clone() for k in ("x_t", "C", "x_in")], n_ran, total, int(mb[1]), int(mb[6]),
+                    int(mb.view(np.int64)[0])))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    ran = 3 if stops else n
+    assert res[0][1:] == (ran, ran, ran, ran, 1000 + _cabi.LP_ES_SEQ_DONE), res[0][1:]
+    assert res[1][1:] == res[0][1:], res[1][1:]
+    d.flags = base | _cabi.LP_FL_ES | _cabi.LP_FL_ES_CLOSE                      # CLOSE without GATED
+    assert lib.lp_step(ctypes.byref(d), st) == _cabi.LP_E_INVALID
+    d.flags = base | _cabi.LP_FL_ES_GATED                                        # GATED without ES
+    assert lib.lp_step(ctypes.byref(d), st) == _cabi.LP_E_INVALID
