@@ -121,7 +121,9 @@ typedef struct lp_hyper {
                                           previous x0s and against the drift anchor; iteration 0: x_t after against x_t before);
                                           lp_step then enqueues a one-block kernel that reduces them in a fixed order, applies
                                           the threshold / patience / drift-anchor logic, updates lp_es_state and posts the
-                                          trace record to `es_host`.  Row-table launches only (not LP_FL_PER_ELEMENT).       */
+                                          trace record to `es_host` (a gated loop on a grid of <= 512 blocks instead applies
+                                          the rule at the top of its NEXT launch and enqueues that kernel after the last
+                                          launch only).  Row-table launches only (not LP_FL_PER_ELEMENT).                    */
 #define LP_FL_ES_GATED      (1u << 14) /* with LP_FL_ES, a launch of a loop the host does not watch (hipGraph replay): once
                                           lp_es_state.stopped is set the launch only re-emits x_in from the committed x_t;
                                           otherwise PRE_HALF is TENTATIVE -- x_t is stored in its post-iteration state, the

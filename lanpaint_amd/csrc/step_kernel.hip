@@ -332,7 +332,8 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // ST (with VEC = 4, RNG = 1, one batch row, n_el in (bg, 4 bg]): the lane's four elements are ATen's -- idx,
 // idx + bg, idx + 2 bg, idx + 3 bg -- so ONE Philox4x32 block and its two Box-Muller pairs serve all four, as
 // in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
-// ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES); run-time phase kernel only.
+// ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES): 1 = per-block sums for the decision kernel
+// that follows, 2 = the launch first applies the verdict of the iteration before itself (gated loops, small grids).
 template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, int ES = 0>
 __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const void* a2, const void* a3, const void* a4,
                                                        const void* a5, int32_t a_el_per_row, uint32_t a_flags,
