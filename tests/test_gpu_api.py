@@ -519,3 +519,54 @@ def test_rows_whose_step_size_is_zero_are_identity_updates_and_do_not_disturb_th
     m = mask[0] == 1
     np.testing.assert_allclose(xb[0][m], y[0][m], rtol=0, atol=1e-6)
     np.testing.assert_allclose(xb[0][~m], x[0][~m], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("bits", [False, True])
+def test_nan_in_the_head_an_element_does_not_read_stays_out_of_it(bits):
+    """Documented deviation: the reference blends the two score branches with the mask as a
+    weight (lanpaint.py:182-184), so a NaN in the head an element does NOT use still reaches it (NaN * 0 = NaN) --
+    head 0 at a known element, head 1 at an inpaint element.  With a hard mask the kernels SELECT the branch: such a
+    NaN never enters, and the run equals the one whose backbone output is clean -- pinned here for the fp32 and the
+    bit-packed mask.  (A NaN in the head the element does use propagates in both, of course.)"""
+    import torch
+    from lanpaint_amd import LanPaint, pack_mask
+    shape = (1, 4, 8, 8)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    mask = gc.box_mask(shape)
+    sig = np.float32([1.1])
+    x = (y + noise * sig).astype(np.float32)
+    xi = [rng.standard_normal(shape, dtype=np.float32) for _ in range(5)]
+    known = torch.from_numpy(mask == 1).to(DEV)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+
+    class Poisoned(MODELS["linear_tuple"]):
+        poison = False
+
+        def __call__(self, xin, t, model_options=None, seed=None):
+            h0, h1 = super().__call__(xin, t, model_options=model_options, seed=seed)
+            if self.poison and self.calls <= 3:      # the think iterations; the final call's head 0 is blended with
+                #                                      the mask as a weight by reference and kernel alike
+                h0 = torch.where(known, torch.full_like(h0, float("nan")), h0)       # head 0 is unused where known
+                h1 = torch.where(~known, torch.full_like(h1, float("nan")), h1)      # head 1 is unused where inpainted
+            return h0, h1
+
+    def run(poison):
+        it = iter([tt(d) for d in xi])
+        model = Poisoned()
+        model.poison = poison
+        eng = LanPaint(model, 3, 15.0, 5.0, 1.0, 0.2, rng=lambda like: next(it))
+        m = tt(mask)
+        xx = tt(x)
+        s = tt(sig)
+        out = eng(xx, tt(y), tt(noise), s, pack_mask(m) if bits else m, gc.times_from_sigma(s, False), None, 0)
+        torch.cuda.synchronize()
+        return xx.cpu().numpy(), out.cpu().numpy()
+
+    xc, oc = run(False)
+    xp, op = run(True)
+    assert np.isfinite(xp).all()
+    np.testing.assert_array_equal(xp, xc)
+    # `out` is the final head-0 prediction re-projected: known elements take y, inpaint elements the clean part of head 0
+    np.testing.assert_array_equal(op, oc)
