@@ -1013,16 +1013,13 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
         // gated loop on a latency-bound latent: the stop rule of iteration i - 1 rides in launch i (every block redoes the
         // small reduction), one closing lp_es_decide_kernel after the last launch.  Larger grids keep the one-block kernel
         // per iteration: re-reading nblocks x 48 B in every block would cost more than the launch it saves.
-        // (The folded kernel is its own instantiation, VEC = 1 only: its extra live state costs the streaming sizes
-        // occupancy they need and it never applies there.)
+        // (The folded kernel is its own instantiation: its extra live state would cost the streaming sizes occupancy
+        // they need.  step_dispatch picks 16 B per lane for early-stop launches of 128 K - 512 K elements so that those
+        // grids fit the fold as well.)
         const unsigned nblocks = grid.x * grid.y;
-        const bool fold = VEC == 1 && (d.flags & LP_FL_ES_GATED) && nblocks <= 2u * static_cast<unsigned>(block) && !t.es_no_fold;
-        if constexpr (VEC == 1) {
-            if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
-            else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
-        } else {
-            hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
-        }
+        const bool fold = (d.flags & LP_FL_ES_GATED) && nblocks <= 2u * static_cast<unsigned>(block) && !t.es_no_fold;
+        if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+        else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         const bool close = fold && (d.flags & LP_FL_ES_CLOSE) && d.es_index + 1 == d.es_n_steps;
         if ((d.phases & kPost) && !t.es_no_decide && !close && (!fold || d.es_index + 1 == d.es_n_steps)) {
             if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
@@ -1162,6 +1159,14 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     const Tune& t = tune();
     const int64_t small = t.small_elems ? t.small_elems : (512 * 1024);
     bool vec4 = can_vec4 && d.n_el > small;
+    if ((d.flags & LP_FL_ES) && can_vec4 && !vec4) {
+        // Early stop: a loop whose table of per-block sums has <= 512 rows takes its verdict inside the next launch
+        // instead of a one-block kernel per iteration (launch()).  One element per lane gets there up to 128 K
+        // elements; 16 B per lane carries it to 512 K (SDXL batch 4: 9.5 -> 5 us per gated iteration).  The rule looks
+        // at the shape only, so the watched (eager) and the gated (captured) loop sum the same blocks: same bits.
+        const int64_t per_row1 = (d.el_per_row + kBlock - 1) / kBlock, per_row4 = (d.el_per_row / 4 + kBlock - 1) / kBlock;
+        if (per_row1 * d.rows > 2 * kBlock && per_row4 * d.rows <= 2 * kBlock) vec4 = true;
+    }
     if (t.vec == 4) vec4 = can_vec4;
     if (t.vec == 1) vec4 = false;
     const hipError_t err = vec4 ? launch_phase<4>(d, stream, timer) : launch_phase<1>(d, stream, timer);

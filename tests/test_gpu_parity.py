@@ -342,13 +342,15 @@ def test_early_stop_inside_a_replayed_graph_equals_the_host_watched_loop(name, r
         assert any(r[2] < n for r in res[True])
 
 
-@pytest.mark.parametrize("shape", [(1, 4, 160, 160), (1, 4, 256, 256), (1, 4, 384, 384), (3, 4, 96, 96)],
-                         ids=["fold_two_rows_per_thread", "vec1_decide_kernel", "vec4_decide_kernel", "fold_batch_rows"])
+@pytest.mark.parametrize("shape", [(1, 4, 160, 160), (1, 4, 256, 256), (1, 3, 301, 301), (1, 4, 384, 384), (3, 4, 96, 96)],
+                         ids=["fold_two_rows_per_thread", "fold_16B_lanes", "vec1_decide_kernel", "vec4_decide_kernel",
+                              "fold_batch_rows"])
 def test_early_stop_graph_equals_eager_at_every_launch_geometry(shape):
     """The gated (captured) loop against the watched (eager) one at the sizes that switch the early-stop machinery:
     102 400 elements = 400 blocks, the verdict folded into the next launch with TWO rows of block sums per thread;
-    262 144 = 1 024 blocks of the 4 B/lane kernel and 589 824 of the 16 B/lane kernel, where a one-block kernel decides
-    and a stopped loop takes the emit-only exit; a batch whose rows share the fold.  torch's stream on both sides, so:
+    262 144 elements, which an early-stop loop runs at 16 B per lane so that its 256 blocks fit the fold too; 271 803
+    (odd: 4 B per lane, 1 062 blocks) and 589 824 (16 B per lane, 576 blocks), where a one-block kernel decides and a
+    stopped loop takes the emit-only exit; a batch whose rows share the fold.  torch's stream on both sides, so:
     the same iteration count, the same trace, bitwise the same x / out over replays that stop on different iterations."""
     import torch
     from lanpaint_amd import LanPaint, pack_mask
