@@ -549,10 +549,11 @@ def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase):
     assert not torch.equal(res[0][0], x_t0) and torch.isfinite(res[0][0]).all()
 
 
+@pytest.mark.parametrize("n", [1, 2, 4])
 @pytest.mark.parametrize("stops", [False, True])
-def test_self_closing_gated_loop_through_the_c_abi(lib, stops):
+def test_self_closing_gated_loop_through_the_c_abi(lib, stops, n):
     """LP_FL_ES_CLOSE straight through lp_step: a gated loop of four launches on a latent small enough for the folded
-    verdict.  Without the flag the last launch is followed by the closing decision kernel, with it the launch accounts
+    verdict (also loops of one and two launches).  Without the flag the last launch is followed by the closing decision kernel, with it the launch accounts
     its own iteration and posts "done" itself -- same x_t / C / x_in bits, same n_ran and running count in the state and
     in the mailbox, for a loop that runs to its end (the backbone output moves every iteration) and for one that stops
     after three iterations (a constant output: distance exactly 0); the flag without LP_FL_ES_GATED, or LP_FL_ES_GATED
@@ -563,7 +564,6 @@ def test_self_closing_gated_loop_through_the_c_abi(lib, stops):
     from lanpaint_amd.lanpaint import _DeviceStop
     dev = torch.device("cuda", 0)
     S, F, P, E = _cabi.LP_PH_POST_STEADY, _cabi.LP_PH_POST_FIRST, _cabi.LP_PH_PRE_HALF, _cabi.LP_PH_EMIT
-    n = 4
     st = torch.cuda.current_stream().cuda_stream
     res = []
     for close in (0, _cabi.LP_FL_ES_CLOSE):
@@ -601,7 +601,7 @@ def test_self_closing_gated_loop_through_the_c_abi(lib, stops):
                     int(mb.view(np.int64)[0])))
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
-    ran = 3 if stops else n
+    ran = min(3, n) if stops else n          # (patience: the constant output stops the loop after three iterations)
     assert res[0][1:] == (ran, ran, ran, ran, 1000 + _cabi.LP_ES_SEQ_DONE), res[0][1:]
     assert res[1][1:] == res[0][1:], res[1][1:]
     d.flags = base | _cabi.LP_FL_ES | _cabi.LP_FL_ES_CLOSE                      # CLOSE without GATED
