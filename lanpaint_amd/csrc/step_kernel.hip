@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     // launch, so reading the descriptor from it is a cold scalar load -- one DRAM round trip, ~0.3 us of the ~1 us a
     // think step spends on the chip at SDXL size (scripts/shader_clock.py) -- and whatever is needed to ISSUE the
     // first-touch loads of the step should not sit behind it.  Fourteen dwords hold six pointers, the row length and
-    // the flags (see step_args()): x_t, C and the two heads always; on the latency-bound sizes (VEC = 1) the
+    // the flags (LP_STEP_ARGS below): x_t, C and the two heads always; on the latency-bound sizes (VEC = 1) the
     // coefficient table and the replayed graph's generator state, whose loads start the two longest dependent chains
     // (state -> Philox rounds; table -> arithmetic), on the streaming sizes y and the mask (the region-aware decision
     // waits for the mask).  The rest of the descriptor arrives while those loads fly.  (Older firmware runs the
