@@ -106,3 +106,16 @@ def test_missing_library_fails_loudly(tmp_path):
     import pytest
     with pytest.raises(ImportError, match="no CPU / PyTorch fallback"):
         _cabi.load(str(tmp_path / "nope.so"))
+
+
+def test_profiling_variant_builds_and_keeps_the_abi(tmp_path):
+    """The -DLP_SHADER_CLOCK build (scripts/shader_clock.py: shader-clock stamps inside the step kernels) compiles for
+    gfx950 and is the same library from the outside: same exports, same ABI version.  (Built into build/, never the
+    library the package loads by default.)"""
+    from lanpaint_amd import build as lpbuild
+    out = lpbuild.build(shader_clock=True, verbose=False)
+    assert os.path.exists(out) and os.path.abspath(out) != os.path.abspath(_cabi.LIB_PATH)
+    lib = _cabi.load(out)
+    assert lib.lp_abi_version() == _cabi.ABI_VERSION
+    for n in _declared_functions():
+        assert hasattr(lib, n)
