@@ -994,10 +994,9 @@ class LanPaint:
         if abt.numel() not in (1, rows) or VE_Sigma.numel() not in (1, rows) or replace_sigma.numel() not in (1, rows):
             per_el = True
         st.abt, st.current_times = abt, current_times
-        if flow:
-            t_model = self.remove_none_dims(self.add_none_dims(Flow_t))
-        else:
-            t_model = self.remove_none_dims(self.add_none_dims(current_times[0]))
+        t_src = Flow_t if flow else current_times[0]
+        # (a [B] tensor goes through add_none_dims / remove_none_dims unchanged: six view ops the host can skip)
+        t_model = t_src if t_src.ndim == 1 else self.remove_none_dims(self.add_none_dims(t_src))
 
         # ---- per-call descriptor --------------------------------------------------
         st.base_flags = base_flags = (LP_FL_FLOW if flow else 0) | m_flag
@@ -1020,8 +1019,8 @@ class LanPaint:
             d.abt_el, d.ve_el, d.rsig_el = abt_el.data_ptr(), ve_el.data_ptr(), rs_el.data_ptr()
             d.coef = None
         else:
-            ve_r, abt_r, rs_r = _as_f32c(VE_Sigma.reshape(-1)), _as_f32c(abt.reshape(-1)), _as_f32c(replace_sigma.reshape(-1))
-            tm_r = _as_f32c(t_model.reshape(-1))
+            flat = lambda t: _as_f32c(t if t.ndim == 1 else t.reshape(-1))       # noqa: E731
+            ve_r, abt_r, rs_r, tm_r = flat(VE_Sigma), flat(abt), flat(replace_sigma), flat(t_model)
             keep += [ve_r, abt_r, rs_r, tm_r]
             # the coefficient table is written by the replace launch itself (LP_PH_COEFFS: lp_coeffs folded in)
             d.t_ve, d.t_abt, d.t_rsig, d.t_model = ve_r.data_ptr(), abt_r.data_ptr(), rs_r.data_ptr(), tm_r.data_ptr()
@@ -1041,14 +1040,13 @@ class LanPaint:
 
         # ---- replace-step source (lanpaint.py:84-94) --------------------------------
         ms = self.inner_model.inner_model.model_sampling
-        s_b = self.add_none_dims(replace_sigma)
         d.noise_scale = 1.0
         d.known = None
         d.noise = nz.data_ptr()
-        if s_b.numel() == 1:
+        if replace_sigma.numel() == 1:
             kind, ns = _noise_scaling_kind(ms)
             if kind == "callback":
-                known = _as_f32c(ms.noise_scaling(s_b, nz, y))
+                known = _as_f32c(ms.noise_scaling(self.add_none_dims(replace_sigma), nz, y))
                 keep.append(known)
                 d.replace_kind, d.known = LP_REPLACE_KNOWN, known.data_ptr()
             elif kind == "ve":
