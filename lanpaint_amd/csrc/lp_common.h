@@ -157,12 +157,13 @@ enum : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 struct Strided {
     int64_t e[4];      // element index per slot, clamped to n - 1
     bool ok[4];        // slot inside the tensor
-    __device__ __forceinline__ Strided(int64_t i, int64_t s, int64_t n) {
+    // slots base + i + k s that fall into [lo, hi) (one batch row's part of one round of ATen's grid-stride loop)
+    __device__ __forceinline__ Strided(int64_t i, int64_t s, int64_t base, int64_t lo, int64_t hi) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t t = i + k * s;
-            ok[k] = t < n;
-            e[k] = ok[k] ? t : n - 1;
+            const int64_t t = base + i + k * s;
+            ok[k] = t >= lo && t < hi;
+            e[k] = ok[k] ? t : lo;
         }
     }
 };

@@ -329,9 +329,11 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // masks, a uint8 mask goes through the PH = 0 kernel.
 // RNG: in-kernel generator fixed at compile time in the hot variants (0 = Philox2x32 pair, 1 = torch's randn
 // stream reproduced exactly) or 2 = read d.rng_kind at run time.
-// ST (with VEC = 4, RNG = 1, one batch row, n_el in (bg, 4 bg]): the lane's four elements are ATen's -- idx,
-// idx + bg, idx + 2 bg, idx + 3 bg -- so ONE Philox4x32 block and its two Box-Muller pairs serve all four, as
-// in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
+// ST (with VEC = 4, RNG = 1, n_el > bg): the lane's four elements are ATen's -- idx, idx + bg, idx + 2 bg,
+// idx + 3 bg of one round of its grid-stride loop -- so ONE Philox4x32 block and its two Box-Muller pairs serve all
+// four, as in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
+// Batches and tensors of several rounds: one blockIdx.y per (round, batch row crossing it), each block working on the
+// elements that belong to both with that row's coefficients.
 // ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES): 1 = per-block sums for the decision kernel
 // that follows, 2 = the launch first applies the verdict of the iteration before itself (gated loops, small grids).
 template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, int ES = 0>
@@ -369,7 +371,31 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     d.el_per_row = a_el_per_row; d.flags = a_flags;
     static_assert(!ES || (!ST && !PER_EL && (PH & LP_PH_REPLACE) == 0), "early stop: think-step launches of the row-table modes");
     constexpr bool es_fold = ES == 2;               // the verdict of iteration i - 1 rides in launch i (small grids)
-    const int row = blockIdx.y;
+    int row = blockIdx.y;
+    // ST: blockIdx.y enumerates (round of ATen's grid-stride loop, batch row crossing that round); the block works on the
+    // part [st_lo, st_hi) of the flat tensor that belongs to both, with that row's coefficients
+    int64_t st_base = 0, st_lo = 0, st_hi = 0;
+    uint32_t st_round = 0;
+    if constexpr (ST) {
+        const int64_t span = 4 * static_cast<int64_t>(d.rng_bg), epr = d.el_per_row;
+        const uint32_t rounds = d.rng_inc >> 2, per_round = gridDim.y / rounds;
+        st_round = blockIdx.y / per_round;
+        st_base = static_cast<int64_t>(st_round) * span;
+        row = static_cast<int>(st_base / epr) + static_cast<int>(blockIdx.y - st_round * per_round);
+        const int64_t row_lo = static_cast<int64_t>(row) * epr, row_hi = row_lo + epr;
+        st_lo = row_lo > st_base ? row_lo : st_base;
+        st_hi = row_hi < st_base + span ? row_hi : st_base + span;
+        if (row >= d.rows || st_lo >= st_hi) return;
+        // a row that only clips a corner of the round touches a few lanes' slots: blocks without any leave at once
+        const int64_t i0 = st_base + static_cast<int64_t>(blockIdx.x) * kBlock, i1 = i0 + kBlock;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t s0 = i0 + k * static_cast<int64_t>(d.rng_bg), s1 = i1 + k * static_cast<int64_t>(d.rng_bg);
+            any = any || (s0 < st_hi && s1 > st_lo);
+        }
+        if (!any) return;
+    }
     const uint32_t fl = d.flags;
     bool es_gated = false, es_idle = false;
     int es_prev = -1, es_anchor = -1, es_write = 0;
@@ -496,7 +522,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     float es_p[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
         const auto i = [&] {
-            if constexpr (ST) return Strided(g, static_cast<int64_t>(d.rng_bg), d.n_el);
+            if constexpr (ST) return Strided(g, static_cast<int64_t>(d.rng_bg), st_base, st_lo, st_hi);
             else return row_base + g * VEC;
         }();
 
@@ -603,8 +629,9 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 const uint64_t off_pre = seq + (draw_post ? d.rng_inc : 0u);
                 if constexpr (ST) {
                     static_assert(!ST || VEC == 4, "the strided layout is four elements per lane");
-                    if (draw_post) torch_normal4(static_cast<uint32_t>(g), seed, seq, xi_a);
-                    if (draw_pre) torch_normal4(static_cast<uint32_t>(g), seed, off_pre, xi_b);
+                    // (round q of the grid-stride loop: Philox counter offset / 4 + q)
+                    if (draw_post) torch_normal4(static_cast<uint32_t>(g), seed, seq + 4ull * st_round, xi_a);
+                    if (draw_pre) torch_normal4(static_cast<uint32_t>(g), seed, off_pre + 4ull * st_round, xi_b);
                 } else {
                     const bool small = d.n_el <= static_cast<int64_t>(d.rng_bg);     // one ATen thread per element
 #pragma unroll
@@ -987,6 +1014,17 @@ static const Tune& tune() {
     return t;
 }
 
+// ST launches: blockIdx.y = round * per_round + j, j-th batch row crossing that round of 4 bg elements (at most
+// ceil(4 bg / el_per_row) + 1 of them, never more than there are rows); 0 = not representable
+static unsigned st_segments(const lp_step_desc& d) {
+    const int64_t span = 4 * static_cast<int64_t>(d.rng_bg);
+    const int64_t rounds = (d.n_el + span - 1) / span;
+    int64_t per_round = (span + d.el_per_row - 1) / d.el_per_row + 1;
+    if (per_round > d.rows) per_round = d.rows;
+    const int64_t gy = rounds * per_round;
+    return (gy > 0 && gy <= 65535 && static_cast<int64_t>(d.rng_inc) == 4 * rounds) ? static_cast<unsigned>(gy) : 0u;
+}
+
 // the preloaded leading arguments of lp_step_kernel<VEC, ...> (see its head) followed by the descriptor
 #define LP_STEP_ARGS(d)                                                                                          \
     static_cast<void*>((d).x_t), static_cast<void*>((d).C),                                                      \
@@ -1008,7 +1046,9 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     // <= 2048 blocks anyway.
     if (bx < 1) bx = 1;
     if (bx > 0x7fffffff) return hipErrorInvalidValue;
-    const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(d.rows));
+    unsigned gy = static_cast<unsigned>(d.rows);
+    if constexpr (ST) gy = st_segments(d);            // (round, row) pairs, see the kernel head
+    const dim3 grid(static_cast<unsigned>(bx), gy);
     if constexpr (ES != 0) {
         // gated loop on a latency-bound latent: the stop rule of iteration i - 1 rides in launch i (every block redoes the
         // small reduction), one closing lp_es_decide_kernel after the last launch.  Larger grids keep the one-block kernel
@@ -1067,9 +1107,9 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
                     : launch<VEC, MODE_ROW, R | E | LP_PH_COEFFS>(d, stream, timer);
     const bool rng_torch = d.rng_kind == LP_RNG_TORCH;
     // ATen's element-to-thread layout pays off when a Philox block really serves several elements of this tensor
-    const bool strided = VEC == 4 && rng_torch && d.rows == 1 && !d.xi_post && !d.xi_pre &&
-                         d.n_el > static_cast<int64_t>(d.rng_bg) && d.n_el <= 4 * static_cast<int64_t>(d.rng_bg) &&
-                         d.rng_inc == 4;
+    // (batch rows: as long as a row covers at least half a round most lanes still use two or more values of their block)
+    const bool strided = VEC == 4 && rng_torch && !d.xi_post && !d.xi_pre && d.n_el > static_cast<int64_t>(d.rng_bg) &&
+                         (d.rows == 1 || d.el_per_row >= 2 * static_cast<int64_t>(d.rng_bg)) && st_segments(d) != 0;
 #define LP_HOT(MODE_, PH_)                                                                                   \
     (strided ? (x0_half ? launch<4, MODE_, PH_, 2, 1, true>(d, stream, timer) : launch<4, MODE_, PH_, 4, 1, true>(d, stream, timer)) \
      : x0_half ? (rng_torch ? launch<VEC, MODE_, PH_, 2, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 2, 0>(d, stream, timer)) \
