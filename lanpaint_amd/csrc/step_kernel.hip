@@ -566,9 +566,24 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 need_x0 = __ballot(nib != 0xFu) != 0ull;
             }
         }
+        // ST: the same decision per SLOT -- the 64 elements one wave holds in slot k are consecutive.  A slot nobody in
+        // the wave reads a stream for has that stream's load pointed at one shared element (a cache line instead of
+        // four, no branch); what it returns is never used (the table path selects by the mask bit).
+        auto i_x0 = i, i_kn = i;
+        if constexpr (ST && HARD && (PH & kPost) != 0) {
+            if (!given && d.x0_big != d.x0 && !(fl & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP))) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const bool bit = ((m_raw.w[k] >> (static_cast<uint32_t>(elem_index(i, k)) & 31u)) & 1u) != 0u;
+                    const bool ok = elem_ok(i, k);
+                    if (__ballot(ok && !bit) == 0ull) i_x0.e[k] = st_lo;
+                    if (__ballot(ok && bit) == 0ull) i_kn.e[k] = st_lo;
+                }
+            }
+        }
         if (post) {
-            if (need_x0) load_raw_w<VEC, X0W>(d.x0, x0dt, i, x0_raw);
-            if (!(d.x0_big == d.x0 || given) && need_known) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i, x0b_raw);
+            if (need_x0) load_raw_w<VEC, X0W>(d.x0, x0dt, i_x0, x0_raw);
+            if (!(d.x0_big == d.x0 || given) && need_known) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i_kn, x0b_raw);
         }
         // ---- from here on the descriptor proper is needed (the first wait for the argument segment) ----
         if constexpr (SMALL) load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
@@ -576,7 +591,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
         const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
         if (post) {
-            if (!given && need_known) load_f32<VEC>(d.y, i, yv);
+            if (!given && need_known) load_f32<VEC>(d.y, i_kn, yv);
             if (host_post) load_f32<VEC>(d.xi_post, i, xi_a);
             if (has_corr) load_f32<VEC>(d.corr_el, i, corr);
         }

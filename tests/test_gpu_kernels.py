@@ -512,12 +512,14 @@ def test_torch_normal_reproduces_torch_randn_bit_for_bit(lib, n):
     assert lib.lp_torch_normal(out.data_ptr(), x.numel(), seed, off + 1, bg, st) < 0      # offsets come in fours
 
 
+@pytest.mark.parametrize("rng", ["philox", "torch"])
 @pytest.mark.parametrize("kind", ["temporal", "box", "blob"])
 @pytest.mark.parametrize("phase", ["steady", "first", "last"])
-def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase):
+def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase, rng):
     """Bit-packed mask, streaming size (VEC = 4): waves whose 256 mask bits are all 0 / all 1 skip the streams their
     region does not read (x0_BIG + y / x0).  Same launch with LP_FL_NO_REGION_SKIP: bitwise equal x_t, C, x_in --
-    on a mask of large uniform regions (temporal), one with mixed waves only (box: 52-element runs) and a disc."""
+    on a mask of large uniform regions (temporal), one with mixed waves only (box: 52-element runs) and a disc.
+    rng = "torch": the ATen-strided kernels, which take the decision per slot (64 consecutive elements of a wave)."""
     import torch
     import bench
     from lanpaint_amd import _cabi
@@ -532,6 +534,11 @@ def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase):
     finally:
         bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
     bufs = keep[0]
+    if rng == "torch":
+        from lanpaint_amd import LanPaint
+        d.rng_kind = _cabi.LP_RNG_TORCH
+        d.rng_bg, d.rng_inc = LanPaint._randn_policy(dev, n_el)
+        d.rng_seed = 99
     st = torch.cuda.current_stream().cuda_stream
     x_t0, c0 = bufs["x_t"].clone(), bufs["C"].clone()
     res = []
@@ -540,7 +547,7 @@ def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase):
         bufs["C"].copy_(c0)
         bufs["x_in"].zero_()
         d.flags = (d.flags & ~_cabi.LP_FL_NO_REGION_SKIP) | extra
-        d.rng_offset = 7
+        d.rng_offset = 8 if rng == "torch" else 7
         _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
         torch.cuda.synchronize()
         res.append([bufs[k].clone() for k in ("x_t", "C", "x_in")])
