@@ -449,6 +449,8 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
             "graph_burst_us_per_launch": burst_us,
             "graph_burst_GBps": bytes_per_launch / burst_us / 1e3,
             "kernel": steady_kernel_name(args.workload, "philox", args.mask_format),
+            "kernel_rng": "philox (the roofline launches are the Philox2x32 variant of the step kernel whatever --rng the "
+                          "timed region ran with)",
             "algorithmic_bytes_per_launch": bytes_per_launch, "mean_launch_us": busy["mean_launch_us"],
             "median_launch_us": busy["median_launch_us"], "min_launch_us": busy["min_launch_us"],
             "launches_timed": busy["launches_timed"],
