@@ -779,8 +779,9 @@ def test_kernel_instantiation_matrix_is_consistent(shape, flow):
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 24, 20), (2, 4, 258, 262), (1, 4, 521, 301), (2, 4, 520, 520), (1, 4, 800, 800),
-                                   (2, 16, 21, 60, 104)],
-                         ids=["vec1", "vec4", "strided", "strided_rows", "strided_rounds", "strided_video_batch"])
+                                   (2, 16, 21, 60, 104), (3, 4, 548, 548), (5, 2, 729, 729)],
+                         ids=["vec1", "vec4", "strided", "strided_rows", "strided_rounds", "strided_video_batch",
+                              "strided_three_rows", "five_rows_4B_lanes"])
 @pytest.mark.parametrize("mode", ["eager", "graph", "early_stop"])
 def test_in_kernel_torch_stream_equals_randn_like_tensors(shape, mode):
     """rng="torch" generates the reference's noise (torch.randn_like(x_t), POST draw then PRE draw) inside the step
@@ -794,11 +795,13 @@ def test_in_kernel_torch_stream_equals_randn_like_tensors(shape, mode):
     y = torch.randn(shape, device="cuda")
     noise = torch.randn(shape, device="cuda")
     mask = (torch.rand(shape, device="cuda") < 0.5).float()
-    sigmas = [torch.tensor([3.0, 2.0], device="cuda"), torch.tensor([1.2, 0.8], device="cuda"),
-              torch.tensor([0.5, 0.3], device="cuda")]
+    sigmas = [torch.tensor([3.0, 2.0, 2.5, 1.7, 2.2], device="cuda"), torch.tensor([1.2, 0.8, 1.0, 0.9, 1.1], device="cuda"),
+              torch.tensor([0.5, 0.3, 0.4, 0.35, 0.45], device="cuda")]
     sigmas = [s_[:shape[0]] for s_ in sigmas]       # "strided": one batch row, 627 k elements > ATen's block * grid;
     # "strided_rows" / "_video_batch": two rows whose boundary cuts through a round of ATen's grid-stride loop (2.16 M and
-    # 4.19 M elements, two rounds), "strided_rounds": one row of 2.56 M elements = two rounds
+    # 4.19 M elements, two rounds), "strided_rounds": one row of 2.56 M elements = two rounds, "strided_three_rows": 3.6 M
+    # elements in rows of 1.2 M (every round holds parts of two or three rows); "five_rows_4B_lanes": rows of 1 062 882
+    # elements (not a multiple of 4: the 4 B-per-lane kernels, one Philox block per element, 5.3 M elements = 3 rounds)
     kw = dict(graph=True) if mode == "graph" else dict(EarlyStopThreshold=1e-7, EarlyStopPatience=1) if mode == "early_stop" else {}
     res = {}
     for rng in ("torch-eager", "torch"):
