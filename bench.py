@@ -174,14 +174,19 @@ def run_gpu(args):
     from lanpaint_amd import distributed as lpd
 
     rank, world, local_rank = lpd.env_world()
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
+        # (main() starts the ranks itself when no launcher did; getting here means a launcher disagrees with --gpus)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
-    dev_index = local_rank % max(1, torch.cuda.device_count())   # identity on an N-GPU node; lets a 1-GPU box rehearse N > 1
+    n_dev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % n_dev                      # identity on an N-GPU node; lets a 1-GPU box rehearse N > 1
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    lpd.init(args.dist_backend, dev)                    # "nccl" IS RCCL on ROCm; no-op at world size 1
+    backend = args.dist_backend
+    if world > 1 and backend == "nccl" and n_dev < world:
+        # RCCL refuses two ranks on one device ("Duplicate GPU detected"): a box with fewer GPUs than ranks can only
+        # rehearse the N > 1 path over gloo.  The line says so (dist.backend / dist.backend_requested).
+        backend = "gloo"
+    lpd.init(backend, dev)                              # "nccl" IS RCCL on ROCm; no-op at world size 1
 
     # Per-dispatch event timing of the dominant kernel, taken FIRST in the process: the same burst repeated after
     # graph captures / other streams exist reads ~1.2 us higher at the video-latent size (11.4 vs 10.2 us) although
@@ -213,8 +218,9 @@ def run_gpu(args):
     sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), lpd.replica_seed(args.seed, rank), dev, tt)
+    bcast = {}
     if world > 1:      # all replicas inpaint the same image with the same mask: ONE packed RCCL broadcast at setup
-        job = lpd.broadcast_job({"mask": mask, "y": y} if rank == 0 else None, src=0, device=dev)
+        job = lpd.broadcast_job({"mask": mask, "y": y} if rank == 0 else None, src=0, device=dev, stats=bcast)
         mask, y = job["mask"], job["y"]
         x0 = (float(sig_np[0]) * noise + (1 - float(sig_np[0])) * y) if flow else (y + noise * float(sig_np[0]))
     if len(shape) == 5 and (args.mask or "temporal") == "temporal" and rank == 0:
@@ -262,6 +268,19 @@ def run_gpu(args):
     assert torch.isfinite(x_last).all(), "bench produced non-finite latents"
 
     tmax, iters_total = lpd.reduce_throughput(elapsed, iters_local, dev)
+    # who took part: every rank reports its device, its own clock and its own iteration count (the evidence that the
+    # collective backend really carried `world` ranks and that each of them ran the full K steps)
+    dist_info = lpd.gather_rank_reports({
+        "rank": rank, "device": f"cuda:{dev_index}", "device_name": torch.cuda.get_device_name(dev),
+        "pci_bus_id": _pci_bus_id(dev_index), "pid": os.getpid(), "steps": args.steps, "iterations": int(iters_local),
+        "elapsed_s": elapsed, "it_s": iters_local / elapsed, "final_checksum": float(x_last.double().sum().item())})
+    if dist_info is not None and rank == 0:
+        dist_info.update({"backend_requested": args.dist_backend, "broadcast_bytes": bcast.get("bytes"),
+                          "broadcast_ms": bcast.get("ms"), "launcher": os.environ.get("LANPAINT_BENCH_LAUNCHER", "external"),
+                          "collectives_in_timed_region": 0,
+                          "note": "weak scaling: every rank runs the whole workload on its own replica (seed + rank); one packed "
+                                  "broadcast of mask + known latent at set-up, no collective inside the timed loop; value = "
+                                  "sum of the ranks' iterations / slowest rank's time"})
 
     # run-to-run spread of the same measurement: further blocks of K steps, each bracketed like the timed region
     # (the headline `value` stays the first block -- exactly K steps, as the contract says)
@@ -295,17 +314,16 @@ def run_gpu(args):
             extras = extra_lines(args, dev)
         except Exception as e:
             extras = {"extras_error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            cpu = cpu_baseline(args.workload, args.cpu_seconds)
-        except Exception as e:
-            cpu = {"error": repr(e)}
-
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
+    if not args.no_cpu_baseline:     # rank 0 only, after the process group is gone: ~12 s of host time nobody waits for
+        try:
+            cpu = cpu_baseline(args.workload, args.cpu_seconds)
+        except Exception as e:
+            cpu = {"error": repr(e)}
     n_el = int(np.prod(shape))
     kind = args.mask or ("temporal" if len(shape) == 5 else "box")
     mask_desc = {"box": "50% box mask", "blob": "centred disc mask",
@@ -334,6 +352,7 @@ def run_gpu(args):
         "roofline_hbm_bound_shape": large,
         "roofline_hbm_past_l3": past_l3,
         "cpu_baseline": cpu,
+        "dist": dist_info,
     }
     line.update(extras)
     print(json.dumps(line), flush=True)
@@ -777,6 +796,64 @@ def cpu_baseline(workload, budget_s):
     return out
 
 
+def _pci_bus_id(index):
+    try:
+        p = torch.cuda.get_device_properties(index)
+        return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_environments(n, port, base=None):
+    """The environment of each of the `n` ranks `python bench.py --gpus n` starts when no launcher did: what
+    torch.distributed.run would export (one process per GPU, rendezvous on 127.0.0.1)."""
+    envs = []
+    for r in range(n):
+        env = dict(os.environ if base is None else base)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "LANPAINT_BENCH_LAUNCHER": "bench.py self-spawn"})
+        envs.append(env)
+    return envs
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves -- one
+    child process per GPU running this very file, rank 0's stdout (the JSON line) passed through -- and wait for all
+    of them.  A rank that fails takes the others down (by PID) and the exit code is its code."""
+    import subprocess
+    envs = rank_environments(n, _free_port())
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                              stdout=None if r == 0 else subprocess.DEVNULL) for r, env in enumerate(envs)]
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -798,11 +875,15 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo only to rehearse the N > 1 path on a box with fewer GPUs than ranks")
+                    help="nccl = RCCL (default).  With fewer GPUs than ranks RCCL cannot run (duplicate device) and the "
+                         "ranks fall back to gloo by themselves; the line's dist.backend says which one carried the run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")
     ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be the launcher (the torch.distributed.run form keeps working -- it sets WORLD_SIZE)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     global MASK_FORMAT, MASK_KIND
     MASK_FORMAT, MASK_KIND = args.mask_format, args.mask
     run_gpu(args)

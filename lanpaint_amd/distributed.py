@@ -60,11 +60,12 @@ def _pack_header(tensors: Dict[str, torch.Tensor]):
 
 
 def broadcast_job(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0,
-                  device: Optional[torch.device] = None, group=None) -> Dict[str, torch.Tensor]:
+                  device: Optional[torch.device] = None, group=None, stats: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """Broadcast the tensors every replica shares (prepared mask, known latent `y`, cond tensors)
     from `src` to all ranks: one tiny object broadcast for the layout, then ONE collective over a
     single packed byte buffer (xGMI is per-link bound: one large transfer, not many small ones).
-    Non-src ranks may pass None.  Returns {name: tensor} on `device` on every rank."""
+    Non-src ranks may pass None.  Returns {name: tensor} on `device` on every rank.  `stats` (optional dict) receives
+    {"bytes": size of the packed buffer, "ms": wall time of the one data collective on this rank, "backend"}."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return {k: (t.to(device) if device is not None else t) for k, t in (tensors or {}).items()}
     rank = dist.get_rank(group)
@@ -86,7 +87,15 @@ def broadcast_job(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0,
     if rank == src:
         for (name, _shape, _dtype), off, sz in zip(layout, offsets, sizes):
             buf[off:off + sz] = tensors[name].contiguous().view(-1).view(torch.uint8).to(buf_dev)
+    import time
+    if buf.is_cuda:
+        torch.cuda.synchronize(buf.device)
+    t0 = time.perf_counter()
     dist.broadcast(buf, src=src, group=group)
+    if buf.is_cuda:
+        torch.cuda.synchronize(buf.device)
+    if stats is not None:
+        stats.update({"bytes": int(total), "ms": 1e3 * (time.perf_counter() - t0), "backend": dist.get_backend(group)})
     out = {}
     for (name, shape, dtype), off, sz in zip(layout, offsets, sizes):
         out[name] = buf[off:off + sz].view(getattr(torch, dtype)).reshape(shape).clone()
@@ -104,6 +113,34 @@ def reduce_throughput(elapsed_s: float, units: int, device: Optional[torch.devic
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()), int(round(n.item()))
+
+
+def collective_library_version() -> Optional[str]:
+    """Version of the library behind the "nccl" backend (RCCL on ROCm), or None."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(int(x)) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
+
+
+def gather_rank_reports(report: dict, group=None) -> Optional[dict]:
+    """Every rank contributes one small dict; rank 0 gets the evidence block of a multi-rank run:
+    {backend, world_size, ranks_reporting, device_per_rank, rccl_version, per_rank_it_s, per_rank}.  None at world
+    size 1 (no process group).  One object all-gather, outside any timed region."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return None
+    world = dist.get_world_size(group)
+    reports = [None] * world
+    dist.all_gather_object(reports, report, group=group)
+    reports = [r for r in reports if isinstance(r, dict)]
+    reports.sort(key=lambda r: r.get("rank", 0))
+    backend = dist.get_backend(group)
+    return {"backend": backend, "world_size": world, "ranks_reporting": len(reports),
+            "device_per_rank": [r.get("device") for r in reports],
+            "distinct_devices": len({(r.get("device"), r.get("pci_bus_id")) for r in reports}),
+            "rccl_version": collective_library_version() if backend == "nccl" else None,
+            "per_rank_it_s": [r.get("it_s") for r in reports], "per_rank": reports}
 
 
 def all_reduce_stop_sums(acc: torch.Tensor, group=None) -> torch.Tensor:

@@ -48,6 +48,17 @@ def raw_stream(device) -> int:
         return torch.cuda.current_stream(device).cuda_stream
 
 
+def tensor_version(t: torch.Tensor) -> int:
+    """`t._version` for the per-tensor caches (noise verdict, packed mask, ring), or -1 for an INFERENCE tensor:
+    ComfyUI runs its nodes under torch.inference_mode(), whose tensors do not track a version counter (reading it
+    raises).  Such a tensor is identified by object identity (weak reference) and address alone -- the caches hold
+    per-job constants (the run's noise, the job's mask) that nobody rewrites in place between sigma calls."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def _as_f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.to(torch.float32).contiguous()
@@ -182,7 +193,8 @@ class _DeviceStop:
         """Mask-edge ring weight (earlystop.py:32-49; 4-D latents only) of the dense fp32 `mask`, computed once per
         mask tensor object `key` and version."""
         c = self.ring
-        if c is None or c[0]() is not key or c[1] != key._version:
+        ver = (tensor_version(key), key.data_ptr())
+        if c is None or c[0]() is not key or c[1] != ver:
             ring = None
             if mask.dim() == 4:
                 ring = torch.empty_like(mask)
@@ -191,7 +203,7 @@ class _DeviceStop:
                     _cabi.check(_cabi.load().lp_boundary_ring(mask.data_ptr(), ring.data_ptr(), b * ch, h, w,
                                                               torch.cuda.current_stream(mask.device).cuda_stream),
                                 "lp_boundary_ring")
-            self.ring = c = (weakref.ref(key), key._version, ring)
+            self.ring = c = (weakref.ref(key), ver, ring)
         return c[2]
 
     def wait(self, seq, device):
@@ -467,8 +479,9 @@ class LanPaint:
         cached per tensor OBJECT and version (a weak reference, not the address: the caching allocator
         recycles addresses), so it is paid once per sampling run."""
         c = self._noise_check
-        if c is None or c[0]() is not noise or c[1] != noise._version:
-            self._noise_check = c = (weakref.ref(noise), noise._version, bool(torch.mean(torch.abs(noise)) < 1e-8))
+        ver = (tensor_version(noise), noise.data_ptr())
+        if c is None or c[0]() is not noise or c[1] != ver:
+            self._noise_check = c = (weakref.ref(noise), ver, bool(torch.mean(torch.abs(noise)) < 1e-8))
         return c[2]
 
     def _draw(self, like):

@@ -27,7 +27,7 @@ import torch
 
 from . import _cabi
 from .blend import MaskBlend, gaussian_kernel_2d, merge_video_with_mask  # noqa: F401
-from .lanpaint import LanPaint, pack_mask, raw_stream
+from .lanpaint import LanPaint, pack_mask, raw_stream, tensor_version
 from .types import FusedCFGHeads
 
 try:                                    # ComfyUI present (or stubbed by tests)
@@ -295,13 +295,14 @@ class KSamplerX0Inpaint:
         """nodes.py:281-283, computed once per mask tensor OBJECT + version (weak reference: a
         denoise_mask_function may hand back a fresh tensor at a recycled address every step)."""
         c = self._mask_cache
-        if c is None or c[0]() is not denoise_mask or c[1] != denoise_mask._version:
+        ver = (tensor_version(denoise_mask), denoise_mask.data_ptr())
+        if c is None or c[0]() is not denoise_mask or c[1] != ver:
             if denoise_mask.is_cuda:
                 # binary by construction: the think loop streams 1 bit / element for it (one ballot launch)
                 latent_mask = pack_mask(denoise_mask, denoise_mask=True)
             else:
                 latent_mask = 1 - (denoise_mask > 0.5).float()
-            self._mask_cache = c = (weakref.ref(denoise_mask), denoise_mask._version, latent_mask)
+            self._mask_cache = c = (weakref.ref(denoise_mask), ver, latent_mask)
         return c[2]
 
     def __call__(self, x, sigma, denoise_mask, model_options={}, seed=None, **kwargs):

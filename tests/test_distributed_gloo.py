@@ -33,12 +33,14 @@ def _worker(rank, world, port, q):
                   "cond": torch.randn(1, 77, 32, generator=g).to(torch.bfloat16),
                   "pooled": torch.randn(1, 7, generator=g).to(torch.float16),
                   "ids": torch.arange(5, dtype=torch.int64)}
-    got = D.broadcast_job(shared, src=0)
+    stats = {}
+    got = D.broadcast_job(shared, src=0, stats=stats)
     digest = {k: (tuple(v.shape), str(v.dtype), float(v.double().sum())) for k, v in got.items()}
     t, n = D.reduce_throughput(1.0 + rank, 150)
     acc = torch.tensor([[1.0 + rank, 2.0, 3.0, 4.0], [0.5, 0.5, 0.5, 0.5]], dtype=torch.float64)
     D.all_reduce_stop_sums(acc)
-    q.put((rank, digest, t, n, acc.tolist(), D.replica_seed(7, rank), D.shard_rows(32, world, rank)))
+    rep = D.gather_rank_reports({"rank": rank, "device": f"cpu:{rank}", "pci_bus_id": None, "it_s": 100.0 * (rank + 1)})
+    q.put((rank, digest, t, n, acc.tolist(), D.replica_seed(7, rank), D.shard_rows(32, world, rank), stats, rep))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -55,7 +57,12 @@ def test_two_rank_gloo_setup_and_reductions():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    (r0, d0, t0, n0, a0, s0, sh0), (r1, d1, t1, n1, a1, s1, sh1) = res
+    (r0, d0, t0, n0, a0, s0, sh0, st0, rep0), (r1, d1, t1, n1, a1, s1, sh1, st1, rep1) = res
+    # the evidence block bench.py prints at N > 1: who took part, over which backend, how much the set-up broadcast moved
+    assert st0["bytes"] == st1["bytes"] > 0 and st0["backend"] == "gloo" and st0["ms"] >= 0.0
+    assert rep0 == rep1 and rep0["backend"] == "gloo" and rep0["world_size"] == rep0["ranks_reporting"] == 2
+    assert rep0["device_per_rank"] == ["cpu:0", "cpu:1"] and rep0["per_rank_it_s"] == [100.0, 200.0]
+    assert rep0["distinct_devices"] == 2 and rep0["rccl_version"] is None
     assert d0 == d1 and set(d0) == {"mask", "y", "cond", "pooled", "ids"}      # every rank holds the same job
     assert d0["cond"][1] == "torch.bfloat16" and d0["ids"][1] == "torch.int64"
     assert t0 == t1 == 2.0 and n0 == n1 == 300                                 # max time, summed units
@@ -78,3 +85,17 @@ def test_shard_rows_and_single_process_identities():
     acc = torch.ones(2, 4, dtype=torch.float64)
     assert D.all_reduce_stop_sums(acc) is acc
     assert D.env_world()[1] >= 1
+    assert D.gather_rank_reports({"rank": 0}) is None            # no process group: no evidence block
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` without torch.distributed.run must not die on plumbing: the environment each
+    self-started rank gets is what the launcher would export, rendezvous on 127.0.0.1."""
+    import bench
+    envs = bench.rank_environments(4, 29511, base={"KEEP": "1"})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] == [e["LOCAL_RANK"] for e in envs]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29511"
+               and e["KEEP"] == "1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    assert 1024 < bench._free_port() < 65536
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "spawn_ranks(args.gpus" in src and "launch with torch.distributed.run" not in src

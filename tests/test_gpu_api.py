@@ -378,9 +378,11 @@ def test_ksampler_x0_inpaint_matches_oracle(flow):
     assert torch.equal(out, 0.9 * x)
 
 
-@pytest.mark.parametrize("flow", [False, True])
-def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow):
-    """The replayed node path (replace step enqueued before the host knows n_eff, mailbox read, graph picked
+@pytest.mark.parametrize("flow,inference", [(False, False), (True, False), (False, True)])
+def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference):
+    """(`inference`: the whole run inside torch.inference_mode(), as ComfyUI executes its nodes -- inference tensors
+    do not track `_version`, which the per-tensor caches of the engine and the sampler callable used to read.)
+    The replayed node path (replace step enqueued before the host knows n_eff, mailbox read, graph picked
     afterwards: engine.begin_call / finish_call) against eager launches: same n_eff sequence as the reference's rule
     (nodes.py:286-299) and bitwise equal trajectories under a torch seed, over repeated passes of a schedule whose
     n_eff ramps through every value."""
@@ -401,12 +403,16 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow):
             self.calls += 1
             return 0.9 * x, 0.8 * x
 
+    import contextlib
     res = {}
     for graph in (False, True):
+      with (torch.inference_mode() if inference else contextlib.nullcontext()):
         model = M(_FlowSampling() if flow else _DummySampling())
         model.model_type = nodes.ModelType.FLOW if flow else "EPS"
         k = nodes.KSamplerX0Inpaint(model, tt(sig))
         k.latent_image, k.noise = tt(y), tt(noise)
+        if inference:
+            assert k.noise.is_inference()
         k.PaintMethod = LanPaint(model, n_think, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, MinStepFrac=1.0, rng="torch", graph=graph)
         k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 1.0
         dm, mo = tt(denoise_mask), {}

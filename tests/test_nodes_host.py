@@ -228,3 +228,27 @@ def test_aten_randn_policy_matches_what_torch_consumed_on_the_mi355x(hip_lib):
     assert aten_randn_policy(2096640, *mi355x) == (524288, 4)               # Wan latent: the grid cap, 4 values per thread
     assert aten_randn_policy(4 * 2096640 + 3, *mi355x) == (524288, 16)
     assert aten_randn_policy(16 * 2096640, *mi355x) == (524288, 64)
+
+
+def test_per_tensor_caches_work_on_inference_tensors(nodes):
+    """ComfyUI runs its nodes under torch.inference_mode(): inference tensors raise on `._version`.  The caches keyed on
+    a tensor (the run's noise verdict lanpaint.py:51, the binarised mask nodes.py:281-283) must identify such a tensor
+    by object + address instead of crashing on the first sigma call."""
+    import torch
+    from lanpaint_amd import LanPaint
+    from lanpaint_amd.lanpaint import tensor_version
+    with torch.inference_mode():
+        noise = torch.randn(1, 4, 8, 8)
+        zero = torch.zeros(1, 4, 8, 8)
+        dm = (torch.rand(1, 4, 8, 8) > 0.5).float()
+        assert noise.is_inference() and tensor_version(noise) == -1
+        with pytest.raises(RuntimeError):
+            noise._version
+        eng = LanPaint(lambda *a, **k: None, 5, 15.0, 5.0, 1.0, 0.2)
+        assert eng._noise_is_zero(noise) is False and eng._noise_is_zero(noise) is False     # second call: cache hit
+        assert eng._noise_is_zero(zero) is True
+        k = nodes.KSamplerX0Inpaint(None, torch.linspace(10, 0, 5))
+        m1 = k._latent_mask(dm)
+        assert k._latent_mask(dm) is m1 and torch.equal(m1, 1 - (dm > 0.5).float())
+        assert k._latent_mask(dm.clone()) is not m1
+    assert tensor_version(torch.zeros(2)) == 0
