@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 10
+#define LP_ABI_VERSION 11
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -327,8 +327,35 @@ typedef struct lp_call_desc {
     const lp_step_desc*  replace;       /* LP_PH_REPLACE | LP_PH_EMIT launch, or NULL           */
     void*                graph_exec;    /* hipGraphExec_t of the captured think loop, or NULL   */
     const lp_final_desc* final;         /* lp_finalize descriptor, or NULL                      */
+    const struct lp_graph_binding* replace_binding;
+                                        /* non-NULL: the replace launch is the FIRST NODE of `graph_exec`
+                                           (lp_graph_bind_replace): `replace` is not launched, its pointers and
+                                           scalars are written into that node's arguments
+                                           (hipGraphExecKernelNodeSetParams) before the graph launch -- the whole
+                                           sigma call is then ONE hipGraphLaunch with nothing eager in front       */
 } lp_call_desc;
 int lp_replay_call(const lp_call_desc* call, void* stream);
+
+/* One hipGraphLaunch per sigma call (round 3).  A sigma call captured WITH its replace launch (lanpaint.py:81-99,
+ * the first node of the graph) needs that node's per-call arguments -- the sampler's x, the noise, sigma / times,
+ * this call's `out`, generator state -- refreshed before every replay.  lp_graph_bind_replace finds the node in the
+ * captured hipGraph_t (its single root; checked against the captured descriptor) and records what
+ * hipGraphExecKernelNodeSetParams needs; lp_replay_call then patches instead of launching (replace_binding).
+ * hipGraphExecKernelNodeSetParams only affects launches enqueued AFTER it (checked on the MI355X with the GPU held
+ * busy: scripts/experiments/graph_setparams.hip), so calls may be queued back to back.
+ * lp_graph_clone_tail: the same graph WITHOUT that first node, instantiated -- for a caller that enqueues the replace
+ * launch early (KSamplerX0Inpaint does not know the inner-step count yet, nodes.py:286-299) and the rest afterwards.
+ * lp_graph_release destroys what lp_graph_clone_tail returned.                                                  */
+typedef struct lp_graph_binding {
+    void*    node;                      /* hipGraphNode_t of the captured replace launch                           */
+    void*    func;                      /* its kernel                                                              */
+    uint32_t grid[3], block[3];
+    uint32_t shared_bytes;
+    uint32_t reserved;
+} lp_graph_binding;
+int lp_graph_bind_replace(void* graph, const lp_step_desc* captured_replace, lp_graph_binding* out);
+int lp_graph_clone_tail(void* graph, void** tail_graph_out, void** tail_exec_out);
+int lp_graph_release(void* tail_graph, void* tail_exec);
 
 /* K1a  sigma -> (VE_sigma, abt, flow_t) per batch row plus the two scalars the inner-step rule needs,
  * in ONE launch.  Replaces the ~15 eager scalar ops + 2 host syncs of KSamplerX0Inpaint.__call__

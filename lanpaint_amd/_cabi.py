@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -84,6 +84,11 @@ class LpFinalDesc(C.Structure):
     ]
 
 
+class LpGraphBinding(C.Structure):
+    _fields_ = [("node", C.c_void_p), ("func", C.c_void_p), ("grid", C.c_uint32 * 3), ("block", C.c_uint32 * 3),
+                ("shared_bytes", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class LpCallDesc(C.Structure):
     _fields_ = [
         ("hyper", C.POINTER(LpHyper)),
@@ -96,6 +101,7 @@ class LpCallDesc(C.Structure):
         ("replace", C.POINTER(LpStepDesc)),
         ("graph_exec", C.c_void_p),
         ("final", C.POINTER(LpFinalDesc)),
+        ("replace_binding", C.POINTER(LpGraphBinding)),
     ]
 
 
@@ -129,6 +135,9 @@ EXPORTS = {
     "lp_wmse_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_void_p]),
     "lp_replay_call": (C.c_int, [C.POINTER(LpCallDesc), C.c_void_p]),
+    "lp_graph_bind_replace": (C.c_int, [C.c_void_p, C.POINTER(LpStepDesc), C.POINTER(LpGraphBinding)]),
+    "lp_graph_clone_tail": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "lp_graph_release": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lp_pack_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_reshape_mask": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]),
 }

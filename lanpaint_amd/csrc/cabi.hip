@@ -5,6 +5,7 @@
 
 namespace lp {
 int step_dispatch(const lp_step_desc* d, hipStream_t stream, void* timer);
+int replace_node_update(const lp_step_desc* d, hipGraphExec_t exec, const lp_graph_binding* b);
 int timer_create(void** out);
 int timer_destroy(void* h);
 int timer_elapsed_ns(void* h, double* ns);
@@ -98,10 +99,63 @@ int lp_replay_call(const lp_call_desc* c, void* stream) {
         rc = lp::coeffs_dispatch(c->hyper, c->ve_sigma, c->ve_stride, c->abt, c->abt_stride, c->replace_sigma,
                                  c->rs_stride, nullptr, 0, c->t_model, c->t_stride, c->rows, c->coef_table, s);
     if (rc != LP_OK) return rc;
-    if (c->replace) rc = lp::step_dispatch(c->replace, s, nullptr);
+    if (c->replace && c->replace_binding) {     // the replace launch is node 0 of the graph: refresh its arguments
+        if (!c->graph_exec) return LP_E_INVALID;
+        rc = lp::replace_node_update(c->replace, static_cast<hipGraphExec_t>(c->graph_exec), c->replace_binding);
+    } else if (c->replace) {
+        rc = lp::step_dispatch(c->replace, s, nullptr);
+    }
     if (rc != LP_OK) return rc;
     if (c->graph_exec && hipGraphLaunch(static_cast<hipGraphExec_t>(c->graph_exec), s) != hipSuccess) return LP_E_LAUNCH;
     return c->final ? lp::finalize_dispatch(c->final, s) : LP_OK;    // NULL: lp_finalize is a node of the graph
+}
+
+int lp_graph_bind_replace(void* graph, const lp_step_desc* captured, lp_graph_binding* out) {
+    if (!graph || !captured || !out) return LP_E_INVALID;
+    hipGraph_t g = static_cast<hipGraph_t>(graph);
+    size_t n_root = 0;
+    if (hipGraphGetRootNodes(g, nullptr, &n_root) != hipSuccess || n_root != 1) return LP_E_UNSUPPORTED;
+    hipGraphNode_t root = nullptr;
+    if (hipGraphGetRootNodes(g, &root, &n_root) != hipSuccess || !root) return LP_E_UNSUPPORTED;
+    hipGraphNodeType ty;
+    if (hipGraphNodeGetType(root, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) return LP_E_UNSUPPORTED;
+    hipKernelNodeParams p{};
+    if (hipGraphKernelNodeGetParams(root, &p) != hipSuccess || !p.func || !p.kernelParams) return LP_E_UNSUPPORTED;
+    // the node must be the launch of `captured`: leading arguments x_t, C, x (LP_STEP_ARGS of a replace launch) and
+    // the descriptor it carries by value
+    void* const* kp = p.kernelParams;
+    const lp_step_desc* dn = static_cast<const lp_step_desc*>(kp[8]);
+    if (*static_cast<void* const*>(kp[0]) != captured->x_t || *static_cast<const void* const*>(kp[2]) != captured->x ||
+        !dn || dn->phases != captured->phases || !(dn->phases & LP_PH_REPLACE) || dn->n_el != captured->n_el)
+        return LP_E_UNSUPPORTED;
+    out->node = root; out->func = p.func;
+    out->grid[0] = p.gridDim.x; out->grid[1] = p.gridDim.y; out->grid[2] = p.gridDim.z;
+    out->block[0] = p.blockDim.x; out->block[1] = p.blockDim.y; out->block[2] = p.blockDim.z;
+    out->shared_bytes = p.sharedMemBytes; out->reserved = 0;
+    return LP_OK;
+}
+
+int lp_graph_clone_tail(void* graph, void** tail_graph_out, void** tail_exec_out) {
+    if (!graph || !tail_graph_out || !tail_exec_out) return LP_E_INVALID;
+    hipGraph_t clone = nullptr;
+    if (hipGraphClone(&clone, static_cast<hipGraph_t>(graph)) != hipSuccess) return LP_E_LAUNCH;
+    size_t n_root = 0;
+    hipGraphNode_t root = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphGetRootNodes(clone, nullptr, &n_root) == hipSuccess && n_root == 1 &&
+        hipGraphGetRootNodes(clone, &root, &n_root) == hipSuccess && root && hipGraphDestroyNode(root) == hipSuccess &&
+        hipGraphInstantiate(&exec, clone, nullptr, nullptr, 0) == hipSuccess) {
+        *tail_graph_out = clone; *tail_exec_out = exec;
+        return LP_OK;
+    }
+    (void)hipGraphDestroy(clone);
+    return LP_E_UNSUPPORTED;
+}
+
+int lp_graph_release(void* tail_graph, void* tail_exec) {
+    if (tail_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(tail_exec));
+    if (tail_graph) (void)hipGraphDestroy(static_cast<hipGraph_t>(tail_graph));
+    return LP_OK;
 }
 
 int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n) {

@@ -1233,6 +1233,33 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     return err == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 
+// The replace launch as node 0 of a replayed graph: write this call's descriptor into the node's arguments.  The
+// argument list is LP_STEP_ARGS of a replace launch (PH & LP_PH_REPLACE): x_t, C, x, known | noise, y, mask, row length,
+// flags, the descriptor by value.  Which instantiation / grid the node runs was fixed at capture; the caller keeps
+// shape, flags, phases and pointer alignment what they were (the engine's identity pre-check).
+int replace_node_update(const lp_step_desc* dp, hipGraphExec_t exec, const lp_graph_binding* b) {
+    if (!dp || !exec || !b || !b->node || !b->func) return LP_E_INVALID;
+    lp_step_desc d = *dp;
+    if (!(d.phases & LP_PH_REPLACE) || !d.x || !d.x_t) return LP_E_INVALID;
+    void* a0 = d.x_t;
+    void* a1 = d.C;
+    const void* a2 = d.x;
+    const void* a3 = d.replace_kind == LP_REPLACE_KNOWN ? static_cast<const void*>(d.known) : static_cast<const void*>(d.noise);
+    const void* a4 = d.y;
+    const void* a5 = d.mask;
+    int32_t epr = static_cast<int32_t>(d.el_per_row);
+    uint32_t fl = d.flags;
+    void* args[9] = {&a0, &a1, &a2, &a3, &a4, &a5, &epr, &fl, &d};
+    hipKernelNodeParams p{};
+    p.func = b->func;
+    p.gridDim = dim3(b->grid[0], b->grid[1], b->grid[2]);
+    p.blockDim = dim3(b->block[0], b->block[1], b->block[2]);
+    p.sharedMemBytes = b->shared_bytes;
+    p.kernelParams = args;
+    p.extra = nullptr;
+    return hipGraphExecKernelNodeSetParams(exec, static_cast<hipGraphNode_t>(b->node), &p) == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
 int timer_create(void** out) {
     if (!out) return LP_E_INVALID;
     Timer* t = new Timer();

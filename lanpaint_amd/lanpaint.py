@@ -250,6 +250,16 @@ class _CapturedCall:
         self.alive = True             # still in the engine's graph table
         self.siblings = {}            # n_steps -> the capture of the same call shape for that count (finish_call)
         self.times_seen = ()          # the (VE sigma, abt, flow t) tuples that passed the identity pre-check
+        self.binding = None           # lp_graph_binding: the replace launch is node 0 of the graph (ONE hipGraphLaunch per call)
+        self.tail_handles = None      # (hipGraph_t, hipGraphExec_t) of the same graph without node 0 (begin_call / finish_call)
+
+    def __del__(self):
+        h, self.tail_handles = self.tail_handles, None
+        if h is not None:
+            try:
+                _cabi.load().lp_graph_release(h[0], h[1])
+            except Exception:
+                pass
 
 
 class LanPaint:
@@ -713,7 +723,7 @@ class LanPaint:
                 and nz.dtype == f32 and nz.shape == x.shape and x.is_contiguous() and sigma.is_contiguous()
                 and nz.is_contiguous()
                 and x.device.index == torch.cuda.current_device() and i[16] == self._override_state()
-                and i[17] == self._hyper_key() and (x.data_ptr() & 15) == 0
+                and i[17] == self._hyper_key() and (x.data_ptr() & 15) == 0 and (nz.data_ptr() & 15) == 0
                 and not (isinstance(model_options, dict) and "lanpaint_semantic_stop" in model_options))
 
     @staticmethod
@@ -780,11 +790,17 @@ class LanPaint:
                 self._graphs.popitem(last=False)[1].alive = False
         else:
             self._graphs.move_to_end(key)
+        srcs = (x, sigma, current_times[0], current_times[1], current_times[2], self.noise)
+        fast = cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape \
+            and (x.data_ptr() & 15) == 0 and (self.noise.data_ptr() & 15) == 0
+        if not fast and cap.binding is not None:
+            # the capture holds its own replace launch (node 0), which only takes dense fp32 16-byte-aligned caller
+            # tensors: this call's do not qualify, so it runs as eager launches
+            self._last_cap = None
+            return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
         self._iterations_run += cap.ran
         self.last_inner_steps = cap.ran
-        srcs = (x, sigma, current_times[0], current_times[1], current_times[2], self.noise)
-        if cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape \
-                and (x.data_ptr() & 15) == 0:
+        if fast:
             if not isinstance(model_options, dict) or "lanpaint_semantic_stop" not in model_options:
                 cap.ident = (self.latent_image, latent_mask, model_options, x.shape, n_steps, seed, self.rng,
                              self.latent_image.data_ptr(), latent_mask.data_ptr(), getattr(latent_mask, "_lp_bits", None),
@@ -864,10 +880,23 @@ class LanPaint:
             state = self._rng_counters[dev] = torch.zeros(4, dtype=torch.int64, device=dev)
         return state
 
-    def _capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
+    def _capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
+                 replace_in_graph=None):
+        """Capture one sigma call.  `replace_in_graph` (default: on, LANPAINT_AMD_REPLACE_IN_GRAPH=0 turns it off): the
+        replace launch is captured too, as the FIRST node, and every replay refreshes that node's arguments (the caller's
+        x / noise / sigma / times, this call's out, generator state) with hipGraphExecKernelNodeSetParams -- the whole
+        sigma call is then ONE hipGraphLaunch with nothing eager in front of it (lp_replay_call, replace_binding).  Needs the
+        raw graph handles and a call the steady-state path takes (dense fp32 tensors, a fusable replace form); anything
+        else is captured the round-2 way, with the replace launch outside the graph."""
         dev = x.device
+        if replace_in_graph is None:
+            replace_in_graph = os.environ.get("LANPAINT_AMD_REPLACE_IN_GRAPH", "1") != "0"
+        raw_ok = self.rng in ("philox", "torch") and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0"
+        replace_in_graph = bool(replace_in_graph and raw_ok)
         counter = self._rng_state(dev)
         cap = _CapturedCall(counter)
+        if replace_in_graph:
+            cap.graph = torch.cuda.CUDAGraph(keep_graph=True)      # the hipGraph_t stays: node 0 has to be found in it
         # captures that differ only in the step count (KSamplerX0Inpaint's n_eff ramp) share ONE workspace: sigma
         # calls are serialised on the stream, and the n_steps-independent replace launch can then be enqueued
         # before the count is known (begin_call / finish_call)
@@ -895,8 +924,14 @@ class LanPaint:
             st = self._prologue(xw, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
                                 ws=cap.ws)
             self._epilogue(st, self._think_and_final_model(st, model_options, seed))
+            # the state the captured launches start from.  With the replace launch inside the graph it is only
+            # described here (descriptor snapshot) and enqueued as the first captured launch below.
             st = self._prologue(xw, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
-                                ws=cap.ws)
+                                ws=cap.ws, defer_launch=replace_in_graph)
+            if replace_in_graph and not (st.k0_desc is not None and st.replace_kind_static and st.xc is st.input_x
+                                         and (st.xc.data_ptr() & 15) == 0 and (self.noise.data_ptr() & 15) == 0):
+                replace_in_graph = False           # not a call the steady-state path takes: the replace stays outside
+                self._launch_step_desc(st.k0_desc, st.stream)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # did the warm-up (backbone included) draw from torch's generator?  Then only torch's own replay() keeps
@@ -910,6 +945,14 @@ class LanPaint:
             self._graph_blocked = True
             self._es_opts = es_user
             return None
+        if torch_rng_used and replace_in_graph:
+            # (the graph has to go through torch's replay(), which knows nothing of node arguments: capture again the
+            # round-2 way)
+            torch.cuda.set_rng_state(rng_state, dev)
+            self._iterations_run = it0
+            self._es_opts = es_user
+            return self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
+                                 replace_in_graph=False)
         self._iterations_run = it0
         self._capturing, self._cap_offset = counter, 0
         try:
@@ -917,13 +960,15 @@ class LanPaint:
             # in the default "global" mode those would invalidate this thread's capture
             f = _cabi.LpFinalDesc()
             with torch.cuda.graph(cap.graph, stream=side, capture_error_mode="thread_local"):
+                if replace_in_graph:
+                    self._launch_step_desc(st.k0_desc, self._stream(dev))
                 cap.final = self._think_and_final_model(st, model_options, seed)
                 dense_ok = self._fill_final_desc(f, st, cap.final, st.out)
                 if self.rng == "philox":
                     f.rng_bump_ptr, f.rng_bump = counter.data_ptr(), self._cap_offset
                 if dense_ok and st.out is not None:
                     # the finalise is the last node of the graph: it takes the caller's x and this call's `out`
-                    # from the table the (un-captured) replace launch of the same call publishes
+                    # from the table the replace launch of the same call publishes
                     f.io_table = counter.data_ptr() + 16
                     _cabi.check(self._lib.lp_finalize(ctypes.byref(f), self._stream(dev)), "lp_finalize")
                     cap.final_in_graph = True
@@ -935,7 +980,7 @@ class LanPaint:
         cap.ran = self._iterations_run - it0
         self._iterations_run = it0
         cap.keep = st                              # descriptor-side tensors referenced by the baked launches
-        # descriptors of the three launches that stay outside the graph, for the steady-state replay path
+        # descriptors of the launches whose arguments change from call to call, for the steady-state replay path
         cap.rows, cap.flow = st.rows, st.flow
         cap.hyper = _cabi.LpHyper.from_buffer_copy(self._hyper)
         cap.k0_desc = st.k0_desc
@@ -943,8 +988,28 @@ class LanPaint:
         cap.model_options = model_options
         cap.es, cap.n_steps = st.es, st.n_steps
         cap.fast = bool(dense_ok and st.k0_desc is not None and st.replace_kind_static and st.xc is st.input_x)
+        if replace_in_graph:
+            ok = cap.fast and cap.final_in_graph
+            if ok:
+                try:
+                    cap.graph.instantiate()
+                    raw_graph = int(cap.graph.raw_cuda_graph())
+                    cap.raw_exec = int(cap.graph.raw_cuda_graph_exec()) or None
+                    b = _cabi.LpGraphBinding()
+                    ok = cap.raw_exec is not None and self._lib.lp_graph_bind_replace(
+                        raw_graph, ctypes.byref(cap.k0_desc), ctypes.byref(b)) == _cabi.LP_OK
+                    if ok:
+                        cap.binding = b
+                        tg, te = ctypes.c_void_p(), ctypes.c_void_p()
+                        if self._lib.lp_graph_clone_tail(raw_graph, ctypes.byref(tg), ctypes.byref(te)) == _cabi.LP_OK:
+                            cap.tail_handles = (tg.value, te.value)
+                except Exception:
+                    ok = False
+            if not ok:       # not a steady-state call after all, or this runtime does not give the handles: round-2 layout
+                return self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX,
+                                     IS_FLOW, replace_in_graph=False)
         if cap.fast:
-            if self.rng in ("philox", "torch") and not torch_rng_used and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0":
+            if cap.binding is None and raw_ok and not torch_rng_used:
                 try:
                     cap.raw_exec = int(cap.graph.raw_cuda_graph_exec()) or None
                 except Exception:
@@ -953,7 +1018,12 @@ class LanPaint:
             c.replace = ctypes.pointer(cap.k0_desc)
             c.final = None if cap.final_in_graph else ctypes.pointer(f)
             c.rows, c.coef_table, c.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.raw_exec
-            if cap.raw_exec is not None and cap.final_in_graph:
+            if cap.binding is not None:
+                c.replace_binding = ctypes.pointer(cap.binding)
+                if cap.tail_handles is not None:
+                    t = cap.tail = _cabi.LpCallDesc()  # the graph minus node 0: its replace launch went ahead (begin_call)
+                    t.rows, t.coef_table, t.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.tail_handles[1]
+            elif cap.raw_exec is not None and cap.final_in_graph:
                 t = cap.tail = _cabi.LpCallDesc()      # the graph alone: its replace launch went ahead (begin_call)
                 t.rows, t.coef_table, t.graph_exec = st.rows, cap.ws.coef.data_ptr(), cap.raw_exec
         cap.key = key
@@ -973,7 +1043,10 @@ class LanPaint:
         return self._epilogue(st, final)
 
     # ---- prologue: per-call descriptor, coefficient table, replace step ------------------------------------
-    def _prologue(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=None, ds=None):
+    def _prologue(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW, ws=None, ds=None,
+                  out=None, defer_launch=False):
+        """`out`: the tensor the call returns, when the caller has it already.  `defer_launch`: build the descriptor of the
+        replace launch (st.k0_desc) but do not enqueue it -- the capture enqueues it as the first node of the graph."""
         lib, d = self._lib, self._desc
         st = _CallState()
         st.input_x = x
@@ -1101,7 +1174,7 @@ class LanPaint:
         st.out = None
         if ws.static_io and not per_el:
             # a replayed call: its lp_finalize may be a node of the graph; this launch tells it where x and out live
-            st.out = torch.empty_like(xc)
+            st.out = out if out is not None else torch.empty_like(xc)
             d.io_table_out = self._rng_state(xc.device).data_ptr() + 16
             d.io_table_val[0], d.io_table_val[1] = xc.data_ptr(), st.out.data_ptr()
         # inner early stop evaluated on the device (default metric, row-table call): this launch resets the state
@@ -1118,7 +1191,8 @@ class LanPaint:
             for k in range(3):
                 d.es_x0s[k] = ds.x0s[k].data_ptr()
             d.es_ring = ring.data_ptr() if ring is not None else None
-        self._launch_step(stream)
+        if not defer_launch:
+            self._launch_step(stream)
         st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
         st.k0_desc = _cabi.LpStepDesc.from_buffer_copy(d) if ws.static_io else None
         d.io_table_out = None          # the think-loop launches share this descriptor

@@ -285,6 +285,50 @@ def test_graph_replay_outputs_are_fresh_tensors_that_stay_valid():
         np.testing.assert_array_equal(a, b)
 
 
+def test_one_graph_launch_per_sigma_call_sees_each_calls_own_arguments(monkeypatch):
+    """Round 3: the replace launch is node 0 of the captured call and every replay rewrites that node's arguments
+    (hipGraphExecKernelNodeSetParams) instead of launching it eagerly.  The update must only affect launches enqueued
+    AFTER it: with the GPU held busy, sixteen sigma calls on sixteen different x tensors are queued back to back -- each
+    must read ITS x / sigma and write ITS out -- and the result must equal both eager launches and the round-2 layout
+    (replace outside the graph, LANPAINT_AMD_REPLACE_IN_GRAPH=0) bit for bit."""
+    import torch
+    from lanpaint_amd import LanPaint
+    dev, shape, n_calls = "cuda", (2, 4, 32, 32), 16
+    g = np.random.default_rng(31)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    y, noise = tt(g.standard_normal(shape, dtype=np.float32)), tt(g.standard_normal(shape, dtype=np.float32))
+    mask = tt(gc.box_mask(shape))
+    sigs = [torch.full((2,), 0.5 + 0.1 * k, device=dev) for k in range(n_calls)]
+    times = [gc.times_from_sigma(s, False) for s in sigs]
+    x_src = [tt(g.standard_normal(shape, dtype=np.float32)) for _ in range(n_calls)]
+
+    def run(graph, in_graph, busy):
+        monkeypatch.setenv("LANPAINT_AMD_REPLACE_IN_GRAPH", "1" if in_graph else "0")
+        torch.manual_seed(9)
+        eng = LanPaint(MODELS["linear_tuple"](), 3, 15.0, 5.0, 1.0, 0.2, rng="torch", graph=graph)
+        xs = [t.clone() for t in x_src]
+        eng(xs[0].clone(), y, noise, sigs[0], mask, times[0], None, 0)          # capture + first replay
+        torch.manual_seed(9)
+        torch.cuda.synchronize()
+        if busy:
+            torch.cuda._sleep(int(40e6))                                          # ~20 ms: the host runs far ahead
+        outs = [eng(xs[k], y, noise, sigs[k], mask, times[k], None, 0) for k in range(n_calls)]
+        torch.cuda.synchronize()
+        if graph:
+            cap = next(iter(eng._graphs.values()))
+            assert (cap.binding is not None) == in_graph and cap.fast and cap.final_in_graph
+            assert (cap.tail is not None)
+        return [o.cpu().numpy() for o in outs], [x.cpu().numpy() for x in xs]
+
+    eager = run(False, True, False)
+    one_launch = run(True, True, True)
+    round2 = run(True, False, True)
+    for a, b, c in zip(eager[0] + eager[1], one_launch[0] + one_launch[1], round2[0] + round2[1]):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
+    assert not np.array_equal(one_launch[0][0], one_launch[0][1])
+
+
 # ------------------------------------------------------------------ inner early stop decided on the device
 @pytest.mark.parametrize("name", sorted(EARLYSTOP))
 @pytest.mark.parametrize("rng", ["torch", "philox"])
