@@ -195,18 +195,10 @@ def run_gpu(args):
     if rank == 0:
         try:
             if world == 1 and not args.no_large_shape:
-                # 1.2 GB per launch: nothing of it survives in the 256 MiB Infinity Cache between launches.
-                # Every operand streamed (what SURVEY.md 8d's 36 B / element describes) ...
-                pre_past = measure_hbm_bound_shape(_cabi, dev, workload="x_wan_b16", launches=24, every_stream=True)
-                # ... and as shipped: waves whose mask bits are uniform skip the streams their region never reads
-                ra = measure_hbm_bound_shape(_cabi, dev, workload="x_wan_b16", launches=24)
-                pre_past["region_aware_streams"] = {
-                    k: ra[k] for k in ("mean_launch_us", "rocprofv3_mean_launch_us", "duration_used_us", "traffic", "achieved",
-                                       "frac", "hbm_side_GBps")}
-                pre_past["region_aware_streams"]["note"] = (
-                    "same launch with the wave-uniform stream skipping on (the default): fewer bytes than the algorithmic "
-                    "36 B / element have to move, so `achieved` (algorithmic bytes / duration) can exceed what HBM delivers; "
-                    "hbm_side_GBps = PMC traffic / duration is the HBM-side rate")
+                # 1.2 GB per launch: nothing of it survives in the 256 MiB Infinity Cache between launches.  Every operand
+                # streamed (what SURVEY.md 8d's 36 B / element describes) and as shipped (waves whose mask bits are uniform
+                # skip the streams their region never reads), interleaved, three clocks each
+                pre_past = measure_past_l3(_cabi, dev)
                 torch.cuda.empty_cache()
             if world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
                 pre_large = measure_hbm_bound_shape(_cabi, dev)      # the bandwidth-bound shape is the sensitive one
@@ -355,7 +347,18 @@ def run_gpu(args):
         "dist": dist_info,
     }
     line.update(extras)
-    print(json.dumps(line), flush=True)
+    emit_line(line)
+
+
+def _latest_profile_json(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.basename(files[-1])
+    except Exception:
+        return None, None
 
 
 def pmc_traffic(workload):
@@ -363,12 +366,9 @@ def pmc_traffic(workload):
     WRITE_SIZE in separate passes, gfx950 x2 read correction) -- a committed measurement
     (profiles/r*_pmc_traffic.json, produced by scripts/gpu_profile.sh), not something bench.py can
     collect on itself.  None when no profile covers this workload."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None
+    data, _f = _latest_profile_json("r*_pmc_traffic.json")
     try:
-        entry = json.load(open(files[-1])).get(workload)
+        entry = (data or {}).get(workload)
         return int(entry["traffic_bytes_per_launch"]) if entry else None
     except Exception:
         return None
@@ -378,15 +378,38 @@ def rocprof_duration(workload):
     """Mean per-dispatch duration (us) of the steady kernel on this workload's shape as rocprofv3 --kernel-trace
     measured it (profiles/r*_kernel_durations.json, written by scripts/collect_profiles.py from the committed
     kernel-trace summaries).  None when no profile covers the workload."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_durations.json")))
-    if not files:
-        return None
+    data, _f = _latest_profile_json("r*_kernel_durations.json")
     try:
-        entry = json.load(open(files[-1])).get(workload)
+        entry = (data or {}).get(workload)
         return float(entry["mean_us"]) if entry else None
     except Exception:
         return None
+
+
+def committed_profile(workload):
+    """What profiles/ holds for this shape, as a cross-reference NEXT TO this run's own measurement (never folded into
+    it): the rocprofv3 --kernel-trace mean per dispatch and the PMC bytes per launch, with the files they come from."""
+    dur, f_dur = _latest_profile_json("r*_kernel_durations.json")
+    pmc, f_pmc = _latest_profile_json("r*_pmc_traffic.json")
+    d, t = (dur or {}).get(workload), (pmc or {}).get(workload)
+    return {"rocprofv3_mean_launch_us": d.get("mean_us") if d else None, "rocprofv3_source": d.get("source") if d else None,
+            "kernel_durations_file": f_dur, "pmc_traffic_bytes_per_launch": t.get("traffic_bytes_per_launch") if t else None,
+            "pmc_traffic_file": f_pmc,
+            "note": "committed rocprofv3 measurements of the same launch (other box, under the profiler); this run's numbers "
+                    "are the event-timer ones"}
+
+
+def roofline_fields(bytes_alg, duration_us, traffic):
+    """The bandwidth statement of one launch: algorithmic bytes / duration (`achieved`, `frac_algorithmic`) and
+    the counter-side rate -- min(algorithmic, PMC-measured) bytes / duration (`frac_counter`): a fraction of peak on
+    bytes the kernel does not move is not a bandwidth fraction."""
+    achieved = bytes_alg / (duration_us * 1e-6) / 1e9
+    moved = min(bytes_alg, traffic) if traffic else None
+    counter = (moved / (duration_us * 1e-6) / 1e9) if moved else None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "frac_algorithmic": achieved / HBM_PEAK_GBPS, "frac_counter": (counter / HBM_PEAK_GBPS) if counter else None,
+            "counter_side_GBps": counter, "frac_counter_vs_6290": (counter / 6290.0) if counter else None,
+            "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg, "duration_used_us": duration_us}
 
 
 def steady_kernel_name(workload, rng, mask_format):
@@ -451,30 +474,27 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
     # rocprofv3 -- is the same event pair per dispatch with the launches back to back: that one is `achieved`.
     if not busy or "error" in busy:
         busy = measure_hbm_bound_shape(_cabi, x0.device, workload=args.workload, launches=120)
-    # two readings of the same per-dispatch duration: this run's event pairs and the committed rocprofv3 trace;
-    # `achieved` / `frac` use the LARGER (more conservative) of the two
-    prof_us = rocprof_duration(args.workload)
-    mean_us = max(busy["mean_launch_us"], prof_us or 0.0)
-    achieved = bytes_per_launch / (mean_us * 1e-6) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
-            "duration_used_us": mean_us, "event_mean_launch_us": busy["mean_launch_us"], "rocprofv3_mean_launch_us": prof_us,
-            "frac_from_event_timer": bytes_per_launch / (busy["mean_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-            "note": "latency-bound shape: 2.4 MB per launch is cache resident, the dispatch is launch latency "
-                    "(see roofline_hbm_bound_shape / roofline_hbm_past_l3 for the bandwidth-bound regime)"
-                    if n_el <= 512 * 1024 else None,
-            "eager_replay_mean_us": float(durs.mean()) * 1e6, "eager_replay_median_us": float(np.median(durs)) * 1e6,
-            "eager_replay_min_us": float(durs.min()) * 1e6, "eager_replay_launches_timed": len(durs),
-            "graph_burst_us_per_launch": burst_us,
-            "graph_burst_GBps": bytes_per_launch / burst_us / 1e3,
-            "kernel": steady_kernel_name(args.workload, "philox", args.mask_format),
-            "kernel_rng": "philox (the roofline launches are the Philox2x32 variant of the step kernel whatever --rng the "
-                          "timed region ran with)",
-            "algorithmic_bytes_per_launch": bytes_per_launch, "mean_launch_us": busy["mean_launch_us"],
-            "median_launch_us": busy["median_launch_us"], "min_launch_us": busy["min_launch_us"],
-            "launches_timed": busy["launches_timed"],
-            "timer": "hipExtLaunchKernelGGL start/stop events per dispatch (kernel begin->end) on the launch stream; "
-                     "mean over back-to-back launches of the steady kernel on buffers of this workload's shape"}
+    out = roofline_fields(bytes_per_launch, busy["mean_launch_us"], pmc_traffic(args.workload))
+    out.update({
+        "regime": busy.get("regime"),
+        "note": "latency-bound shape: 2.4 MB per launch is cache resident, the dispatch is launch latency "
+                "(see roofline_hbm_bound_shape / roofline_hbm_past_l3 for the bandwidth-bound regime)"
+                if n_el <= 512 * 1024 else None,
+        "eager_replay_mean_us": float(durs.mean()) * 1e6, "eager_replay_median_us": float(np.median(durs)) * 1e6,
+        "eager_replay_min_us": float(durs.min()) * 1e6, "eager_replay_launches_timed": len(durs),
+        "graph_burst_us_per_launch": burst_us,
+        "graph_burst_GBps": bytes_per_launch / burst_us / 1e3,
+        "kernel": steady_kernel_name(args.workload, "philox", args.mask_format),
+        "kernel_rng": "philox (the roofline launches are the Philox2x32 variant of the step kernel whatever --rng the "
+                      "timed region ran with)",
+        "storage": "fp32 x_t, C, x0, x0_BIG, y, x_in; mask 1 bit / element",
+        "mean_launch_us": busy["mean_launch_us"], "median_launch_us": busy["median_launch_us"],
+        "min_launch_us": busy["min_launch_us"], "launches_timed": busy["launches_timed"], "warm_burst_s": busy.get("warm_burst_s"),
+        "committed_profile": committed_profile(args.workload),
+        "timer": "hipExtLaunchKernelGGL start/stop events per dispatch (kernel begin->end) on the launch stream, THIS run; "
+                 "mean over back-to-back launches of the steady kernel on buffers of this workload's shape after a warm burst "
+                 "of the same launch"})
+    return out
 
 
 MASK_FORMAT = "bits"          # set from --mask-format; the standalone launches follow the headline's format
@@ -490,7 +510,7 @@ def attach_mask_format(mask, fmt):
     return mask
 
 
-def standalone_step(_cabi, workload, dev, phase=None):
+def standalone_step(_cabi, workload, dev, phase=None, model_dtype=None):
     """A self-contained steady-state lp_step launch on synthetic buffers of `workload`'s shape
     (used for the HBM-bound supplementary roofline and by scripts/microbench_step.py)."""
     import ctypes
@@ -499,6 +519,9 @@ def standalone_step(_cabi, workload, dev, phase=None):
     n_el, rows = int(np.prod(shape)), shape[0]
     g = torch.Generator(device=dev).manual_seed(0)
     bufs = {k: torch.randn(shape, device=dev, generator=g) for k in ("x", "y", "noise", "x_t", "C", "x0", "x0b", "x_in")}
+    if model_dtype is not None:          # a half-precision backbone: its two heads arrive, and x_in leaves, in that dtype
+        for k in ("x0", "x0b", "x_in"):
+            bufs[k] = bufs[k].to(model_dtype)
     mask = torch.from_numpy(make_mask(shape, MASK_KIND)).to(dev)
     h = _cabi.LpHyper()
     h.lambda_, h.beta, h.step_size, h.min_step_frac = HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"], 0.0
@@ -523,18 +546,23 @@ def standalone_step(_cabi, workload, dev, phase=None):
     elif MASK_FORMAT == "u8":
         d.mask, d.flags = mask._lp_u8.data_ptr(), d.flags | _cabi.LP_FL_MASK_U8
     d.x_t, d.C, d.x0, d.x0_big, d.x_in = (bufs[k].data_ptr() for k in ("x_t", "C", "x0", "x0b", "x_in"))
+    if model_dtype is not None:
+        half = model_dtype == torch.bfloat16
+        d.flags |= (_cabi.LP_FL_X0_BF16 | _cabi.LP_FL_XIN_BF16) if half else (_cabi.LP_FL_X0_F16 | _cabi.LP_FL_XIN_F16)
     d.rng_seed = 1
     keep = (bufs, mask, coef, sig, ve, abt)
     return d, keep, n_el
 
 
-def graph_burst_us_per_launch(_cabi, workload, dev, reps=200, replays=20):
+def graph_burst_us_per_launch(_cabi, workload, dev, reps=200, replays=20, every_stream=False, model_dtype=None):
     """Un-profiled steady-state cost of one launch: `reps` launches of the steady kernel captured in a
     hipGraph on synthetic buffers of the workload's shape, replayed; wall time / launches (kernel +
     the dependent-launch boundary; a bare torch elementwise kernel costs ~1.66 us this way)."""
     import ctypes
     lib = _cabi.load()
-    d, keep, _n = standalone_step(_cabi, workload, dev)
+    d, keep, _n = standalone_step(_cabi, workload, dev, model_dtype=model_dtype)
+    if every_stream:
+        d.flags |= _cabi.LP_FL_NO_REGION_SKIP
 
     def launches(n):
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -560,20 +588,30 @@ def graph_burst_us_per_launch(_cabi, workload, dev, reps=200, replays=20):
     return us
 
 
-def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60, every_stream=False):
-    """Supplementary evidence: the same steady-state kernel on the video-latent shape (75 MB of
-    algorithmic traffic per launch -- the regime where the kernel is bandwidth bound, not launch
-    bound), launched back to back through lp_step_timed."""
+def warm_burst(lib, d, stream, dev, seconds):
+    """Untimed launches of the very launch about to be timed, for `seconds`: the first launches of a process (or after
+    an idle gap) run while the chip's clocks are still ramping -- 24 launches timed first in the process read 8-21 %
+    longer than rocprofv3's mean over a thousand at the 1.2 GB shape."""
     import ctypes
-    lib = _cabi.load()
-    d, keep, n_el = standalone_step(_cabi, workload, dev)
-    if every_stream:
-        d.flags |= _cabi.LP_FL_NO_REGION_SKIP
-    st = torch.cuda.current_stream(dev).cuda_stream
-    for k in range(10):
-        d.rng_offset = k
-        _cabi.check(lib.lp_step(ctypes.byref(d), st))
-    lead = 16                                     # dispatches that start on an idle chip, not counted
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(32):
+            d.rng_offset = n
+            n += 1
+            _cabi_check(lib.lp_step(ctypes.byref(d), stream))
+        torch.cuda.synchronize(dev)
+    return n
+
+
+def _cabi_check(rc):
+    from lanpaint_amd import _cabi
+    _cabi.check(rc)
+
+
+def timed_burst(_cabi, lib, d, stream, dev, launches, lead=16):
+    """Per-dispatch durations (s) of `launches` back-to-back launches from ONE host call (`lead` more in front, not
+    counted: they start on an idle chip)."""
+    import ctypes
     timers = (ctypes.c_void_p * (launches + lead))()
     for k in range(launches + lead):
         t = ctypes.c_void_p()
@@ -581,7 +619,7 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60, every_st
         timers[k] = t
     d.rng_offset = 100
     torch.cuda.synchronize(dev)
-    _cabi.check(lib.lp_step_timed_burst(ctypes.byref(d), st, timers, launches + lead))   # one host call: GPU stays busy
+    _cabi.check(lib.lp_step_timed_burst(ctypes.byref(d), stream, timers, launches + lead))   # one host call: GPU stays busy
     torch.cuda.synchronize(dev)
     durs = []
     for t in timers:
@@ -589,26 +627,84 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=60, every_st
         _cabi.check(lib.lp_timer_elapsed_ns(ctypes.c_void_p(t), ctypes.byref(ns)))
         durs.append(ns.value * 1e-9)
         lib.lp_timer_destroy(ctypes.c_void_p(t))
-    durs = np.asarray(durs[lead:])
-    bytes_per_launch = BYTES_PER_EL_STEADY * n_el
+    return np.asarray(durs[lead:])
+
+
+def shape_regime(n_el, streams=9):
+    working_set = streams * 4 * n_el                  # the nine fp32 streams of the steady launch
+    regime = ("past the 256 MiB Infinity Cache: every byte comes from / goes to HBM" if working_set > 2 * 256 * 2 ** 20 else
+              "L3-resident: the working set fits the 256 MiB Infinity Cache, the rates are fabric-side, not DRAM-side"
+              if working_set > 32 * 2 ** 20 else "cache resident (L2): launch-latency bound")
+    return working_set, regime
+
+
+def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=100, every_stream=False, warm_s=0.3, model_dtype=None):
+    """Supplementary evidence: the same steady-state kernel on the video-latent shape (75 MB of
+    algorithmic traffic per launch -- the regime where the kernel is bandwidth bound, not launch
+    bound), launched back to back through lp_step_timed after a warm burst of the same launch."""
+    lib = _cabi.load()
+    d, keep, n_el = standalone_step(_cabi, workload, dev, model_dtype=model_dtype)
+    if every_stream:
+        d.flags |= _cabi.LP_FL_NO_REGION_SKIP
+    st = torch.cuda.current_stream(dev).cuda_stream
+    warmed = warm_burst(lib, d, st, dev, warm_s)
+    durs = timed_burst(_cabi, lib, d, st, dev, launches)
+    bytes_per_el = BYTES_PER_EL_STEADY if model_dtype is None else BYTES_PER_EL_STEADY - 6     # bf16 x0, x0_BIG in, x_in out
+    bytes_per_launch = bytes_per_el * n_el
     shape = WORKLOADS[workload][0]
     del keep
-    prof_key = workload + ("_every_stream" if every_stream else "")
-    event_us, prof_us = float(durs.mean()) * 1e6, rocprof_duration(prof_key)
-    used_us = max(event_us, prof_us or 0.0)          # the more conservative of this run's events and the committed trace
-    achieved = bytes_per_launch / (used_us * 1e-6) / 1e9
-    working_set = 9 * 4 * n_el                        # the nine fp32 streams of the steady launch
-    regime = ("past the 256 MiB Infinity Cache: every byte comes from / goes to HBM" if working_set > 2 * 256 * 2 ** 20 else
-              "fabric-side: the working set fits the 256 MiB Infinity Cache, part of the traffic is served on-die between "
-              "launches" if working_set > 32 * 2 ** 20 else "cache resident (L2): launch-latency bound")
-    return {"workload": f"{workload}: latent {'x'.join(map(str, shape))}, steady-state lp_step back to back",
-            "regime": regime, "working_set_bytes": working_set,
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "frac_vs_6290": achieved / 6290.0, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "traffic": pmc_traffic(prof_key), "duration_used_us": used_us, "rocprofv3_mean_launch_us": prof_us,
-            "hbm_side_GBps": (pmc_traffic(prof_key) / (used_us * 1e-6) / 1e9) if pmc_traffic(prof_key) else None,
-            "mean_launch_us": event_us, "median_launch_us": float(np.median(durs)) * 1e6,
-            "min_launch_us": float(durs.min()) * 1e6, "launches_timed": int(durs.size)}
+    prof_key = workload + ("_every_stream" if every_stream else "") + ("_bf16" if model_dtype is not None else "")
+    event_us = float(durs.mean()) * 1e6
+    working_set, regime = shape_regime(n_el)
+    out = roofline_fields(bytes_per_launch, event_us, pmc_traffic(prof_key))
+    out.update({"workload": f"{workload}: latent {'x'.join(map(str, shape))}, steady-state lp_step back to back"
+                            + (", every operand streamed (LP_FL_NO_REGION_SKIP)" if every_stream else "")
+                            + (", bf16 heads in / bf16 x_in out" if model_dtype is not None else ""),
+                "regime": regime, "working_set_bytes": working_set, "frac_vs_6290": out["achieved"] / 6290.0,
+                "hbm_side_GBps": out["counter_side_GBps"],
+                "mean_launch_us": event_us, "median_launch_us": float(np.median(durs)) * 1e6,
+                "min_launch_us": float(durs.min()) * 1e6, "launches_timed": int(durs.size), "warm_burst_s": warm_s,
+                "warm_burst_launches": warmed, "committed_profile": committed_profile(prof_key)})
+    return out
+
+
+def measure_past_l3(_cabi, dev, workload="x_wan_b16", launches=100, warm_s=0.3, rounds=2):
+    """The 1.2 GB point, both variants of the launch (every operand streamed / region-aware as shipped), three clocks
+    each, INTERLEAVED on this box: per-dispatch event pairs after a warm burst, the un-profiled graph-burst cost per
+    launch, and the committed rocprofv3 mean for reference."""
+    res = {}
+    for rnd in range(rounds):
+        for every in (True, False):
+            key = "every_stream" if every else "region_aware"
+            m = measure_hbm_bound_shape(_cabi, dev, workload=workload, launches=launches, every_stream=every, warm_s=warm_s)
+            g = graph_burst_us_per_launch(_cabi, workload, dev, reps=50, replays=20, every_stream=every)
+            r = res.setdefault(key, {"event_mean_us": [], "graph_burst_us": [], "last": None})
+            r["event_mean_us"].append(m["mean_launch_us"])
+            r["graph_burst_us"].append(g)
+            r["last"] = m
+            torch.cuda.empty_cache()
+    out = res["every_stream"]["last"]
+    for key in ("every_stream", "region_aware"):
+        r, m = res[key], res[key]["last"]
+        ev, gb = float(np.mean(r["event_mean_us"])), float(np.mean(r["graph_burst_us"]))
+        blk = roofline_fields(m["algorithmic_bytes_per_launch"], ev, m["traffic"])
+        blk.update({"event_mean_us_per_round": r["event_mean_us"], "graph_burst_us_per_round": r["graph_burst_us"],
+                    "event_mean_us": ev, "graph_burst_us_per_launch": gb,
+                    "rocprofv3_mean_launch_us": m["committed_profile"]["rocprofv3_mean_launch_us"],
+                    "event_over_rocprofv3": (ev / m["committed_profile"]["rocprofv3_mean_launch_us"])
+                    if m["committed_profile"]["rocprofv3_mean_launch_us"] else None,
+                    "graph_burst_over_rocprofv3": (gb / m["committed_profile"]["rocprofv3_mean_launch_us"])
+                    if m["committed_profile"]["rocprofv3_mean_launch_us"] else None})
+        if key == "every_stream":
+            out.update(blk)
+            out["mean_launch_us"] = ev
+        else:
+            blk["note"] = ("same launch with the wave-uniform stream skipping on (the default): fewer bytes than the algorithmic "
+                           "36 B / element have to move, so `frac_algorithmic` can exceed what HBM delivers; `frac_counter` "
+                           "(PMC bytes / duration) is the bandwidth fraction")
+            out["region_aware_streams"] = blk
+    out["interleaved"] = f"{rounds} rounds of [every-stream events, every-stream graph burst, region-aware events, region-aware graph burst]"
+    return out
 
 
 def extra_lines(args, dev):
@@ -675,6 +771,18 @@ def extra_lines(args, dev):
                     "evaluated on the device inside every replayed launch, no host read in the loop"}
     except Exception as e:
         out["inner_early_stop_armed"] = {"error": repr(e)}
+    # ---- a half-precision backbone: both heads arrive as bf16 and x_in leaves as bf16 (30 B / element instead of 36);
+    # the production storage widths -- BASELINE configs[1] says bf16 -- at the two bandwidth-bound shapes
+    try:
+        from lanpaint_amd import _cabi as _c
+        out["bf16_heads"] = {
+            wl: measure_hbm_bound_shape(_c, dev, workload=wl, launches=100, model_dtype=torch.bfloat16)
+            for wl in ("c5_wan", "x_wan_b16")}
+        out["bf16_heads"]["note"] = ("steady lp_step launch with LP_FL_X0_BF16 | LP_FL_XIN_BF16 (x0, x0_BIG read and x_in "
+                                     "written as bf16; state x_t, C, y stay fp32): 30 algorithmic bytes per element")
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["bf16_heads"] = {"error": repr(e)}
     # ---- node-default schedule through the sampler-facing callable
     shape, flow, n_sig, n_think = WORKLOADS["c2_sdxl"]
     sig_np = karras_sigmas(n_sig)
@@ -796,6 +904,29 @@ def cpu_baseline(workload, budget_s):
     return out
 
 
+_LINE_FD = None
+
+
+def claim_stdout():
+    """ONE JSON line on stdout, nothing else: libraries write to file descriptor 1 behind Python's back (gloo prints
+    "[Gloo] Rank 0 is connected to ..." there), so fd 1 is pointed at stderr for the whole run and the line goes to the
+    saved descriptor."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _LINE_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, data)
+
+
 def _pci_bus_id(index):
     try:
         p = torch.cuda.get_device_properties(index)
@@ -886,6 +1017,7 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     global MASK_FORMAT, MASK_KIND
     MASK_FORMAT, MASK_KIND = args.mask_format, args.mask
+    claim_stdout()
     run_gpu(args)
 
 

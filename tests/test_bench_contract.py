@@ -36,6 +36,24 @@ def test_pmc_traffic_lookup_reads_committed_profile():
     assert bench.pmc_traffic("no_such_workload") is None
 
 
+def test_roofline_block_is_a_bandwidth_statement():
+    """`frac_algorithmic` (36 B x elements / duration) and `frac_counter` (min(algorithmic, PMC) bytes / duration) side by
+    side; a committed profile is quoted next to the live number with its file name, never folded into it."""
+    import bench
+    r = bench.roofline_fields(36 * 65536, 4.0, 2167808)
+    assert abs(r["achieved"] - 36 * 65536 / 4e-6 / 1e9) < 1e-6 and r["frac"] == r["frac_algorithmic"] == r["achieved"] / 8000.0
+    assert abs(r["frac_counter"] - 2167808 / 4e-6 / 1e9 / 8000.0) < 1e-12 and r["bound"] == "hbm" and r["peak"] == 8000.0
+    r2 = bench.roofline_fields(100, 1.0, 250)               # counters above the algorithmic bytes: re-reads do not earn credit
+    assert r2["frac_counter"] == r2["frac_algorithmic"]
+    assert bench.roofline_fields(100, 1.0, None)["frac_counter"] is None
+    c = bench.committed_profile("c2_sdxl")
+    assert c["kernel_durations_file"].startswith("r") and c["pmc_traffic_file"].startswith("r")
+    assert c["rocprofv3_mean_launch_us"] > 0 and c["pmc_traffic_bytes_per_launch"] > 0
+    assert bench.committed_profile("nope")["rocprofv3_mean_launch_us"] is None
+    assert "L3-resident" in bench.shape_regime(2096640)[1] and "past the 256 MiB" in bench.shape_regime(33546240)[1]
+    assert "L2" in bench.shape_regime(65536)[1]
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "lanpaint_amd")
     for dirpath, _, files in os.walk(pkg):
