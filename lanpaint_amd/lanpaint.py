@@ -29,6 +29,7 @@ import os
 import weakref
 from collections import OrderedDict
 from functools import partial
+from time import perf_counter
 
 import torch
 
@@ -264,6 +265,7 @@ class _CapturedCall:
 
 class LanPaint:
     MAX_GRAPHS = 16          # captured sigma calls kept per engine (one per distinct n_steps / tensor set)
+    AUTO_MAX_BACKBONE_HOST_US = 100.0   # graph="auto": only loops whose backbone call costs the host less than this are captured
 
     # ------------------------------------------------------------------ construction
     def __init__(self, Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX=False, IS_FLOW=False,
@@ -276,12 +278,19 @@ class LanPaint:
              or a callable `rng(like) -> Tensor` (tests feed recorded streams).
              Env LANPAINT_AMD_RNG overrides the default.
         philox_seed: Philox key; defaults to the `seed` argument of each call.
-        graph: capture each sigma call (coeffs, replace, N x [backbone, fused step], final
-             backbone call, finalise) into ONE hipGraph and replay it (the loop is launch
-             bound at image-latent sizes).  Needs a capturable backbone (static shapes, no
-             host sync); rng "torch"/"philox" only; ignored (eager launches) when the inner
-             early stop, per-element times or method overrides are in play.
-             Env LANPAINT_AMD_GRAPH=1 turns it on by default.
+        graph: capture each sigma call (replace, N x [backbone, fused step], final backbone call,
+             finalise) into ONE hipGraph and replay it (the loop is launch bound at image-latent
+             sizes).  True needs a capturable backbone (static shapes, no host sync); rng
+             "torch"/"philox" only; ignored (eager launches) when per-element times or method
+             overrides are in play.  Default (None; env LANPAINT_AMD_GRAPH=1 / 0 forces it on / off):
+             "auto" -- the first call of a job runs eagerly and times the backbone on the host; when
+             that is cheap to enqueue (< AUTO_MAX_BACKBONE_HOST_US per call: a launch-bound loop, the
+             case a graph helps) the second call with the same latent_image / mask / model_options
+             objects is captured, the capture is CHECKED against an eager run of the same call
+             (rng="torch": bitwise), and from then on replayed.  A backbone that cannot be captured
+             (host sync inside it), that draws from torch's generator, or whose replay differs from
+             eager keeps the engine eager for good, with a warning.  Expensive backbones are never
+             captured: the Langevin launches are noise next to them.
         model_dtype: torch.bfloat16 / torch.float16 -> the latent handed to the backbone inside the
              think loop is emitted in that dtype by the kernel (no separate cast pass); the state,
              the written-back x and the arithmetic stay fp32.
@@ -309,7 +318,10 @@ class LanPaint:
         self._graph_blocked = False              # the backbone draws from torch's generator inside the loop
         self.philox_seed = philox_seed
         self._philox_offset = 0
-        self.graph = bool(int(os.environ.get("LANPAINT_AMD_GRAPH", "0"))) if graph is None else bool(graph)
+        if graph is None:
+            graph = {"1": True, "0": False}.get(os.environ.get("LANPAINT_AMD_GRAPH", "auto"), "auto")
+        self.graph = "auto" if graph == "auto" else bool(graph)
+        self._auto = None                        # auto mode: [signature of the job, eager calls seen, backbone host s per call]
         if model_dtype not in (None, torch.float32, torch.bfloat16, torch.float16):
             raise ValueError(f"model_dtype must be None, float32, bfloat16 or float16, got {model_dtype}")
         self.model_dtype = None if model_dtype == torch.float32 else model_dtype
@@ -637,7 +649,10 @@ class LanPaint:
             self._iterations_run += cap.ran           # same tensors / shapes / options as the previous call:
             self.last_inner_steps = cap.ran          # skip the key construction, go straight to the replay
             return self._replay_fast(cap, x, sigma, current_times)
-        run = self._call_graphed if self._graph_eligible(x, model_options, sigma, current_times) else self.LanPaint
+        graphed = self._graph_eligible(x, model_options, sigma, current_times)
+        if graphed and self.graph == "auto":
+            graphed = self._auto_ready(x, latent_mask, model_options)
+        run = self._call_graphed if graphed else self.LanPaint
         if x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):
                 return run(x, sigma, latent_mask, current_times, n_steps, model_options, seed, self.IS_FLUX,
@@ -765,6 +780,66 @@ class LanPaint:
             return False
         return x.dtype == torch.float32 and x.numel() > 0
 
+    def _auto_ready(self, x, latent_mask, model_options):
+        """graph="auto": has this job been seen running eagerly, with a backbone cheap enough on the host for the loop to
+        be launch bound?  The first call with a new (latent_image, mask, model_options, shape) starts the record (and
+        runs eagerly: its plain loop times the backbone calls); later calls of the same job ask it."""
+        a = self._auto
+        if a is not None and a[0][0] is self.latent_image and a[0][1] is latent_mask and a[0][2] is model_options \
+                and a[0][3] == x.shape and a[0][4] == x.device:
+            if self._es_opts is not None:
+                return False             # (the inner early stop is captured on request only: graph=True)
+            return a[1] >= 1 and 1e6 * a[2] < self.AUTO_MAX_BACKBONE_HOST_US
+        # [signature, eager calls seen, cheapest per-call mean of the backbone's host time so far (s)]
+        self._auto = [(self.latent_image, latent_mask, model_options, x.shape, x.device), 0, float("inf")]
+        return False
+
+    def _auto_capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
+        """graph="auto": capture, but never let a backbone that cannot be captured take the call down, and take nothing
+        on trust -- the first replay is compared with eager launches of the same call before the capture is used."""
+        import warnings
+        dev = x.device
+        saved = (self._iterations_run, torch.cuda.get_rng_state(dev), self._es_opts, self._torch_consumed, self._philox_offset)
+
+        def give_up(why):
+            self._capturing = None
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:
+                pass
+            self._iterations_run, _, self._es_opts, self._torch_consumed, self._philox_offset = saved
+            torch.cuda.set_rng_state(saved[1], dev)
+            self._graph_blocked = True
+            cap = self._graphs.pop(key, None)
+            if cap is not None:
+                cap.alive = False
+            self._last_cap = None
+            warnings.warn("lanpaint_amd: graph='auto' stays with eager launches for this engine: " + why)
+            return None
+
+        try:
+            cap = self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+        except Exception as e:                       # e.g. a host sync inside the backbone while the stream is capturing
+            return give_up("the backbone could not be captured (%s: %s)" % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+        if cap is None or self.rng != "torch":
+            return cap
+        # one replay and one eager run of this very call on copies of x, from the same generator state: they must agree
+        # bit for bit (same kernels, same noise stream), or something in the backbone does not survive capture
+        try:
+            xa, xb = x.clone(), x.clone()
+            out_a = self._run_capture(cap, xa, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+            torch.cuda.set_rng_state(saved[1], dev)
+            self._last_cap = None
+            out_b = self.LanPaint(xb, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+            same = bool(torch.equal(out_a, out_b)) and bool(torch.equal(xa, xb))
+        except Exception as e:
+            return give_up("checking the capture against eager launches failed (%s)" % type(e).__name__)
+        if not same:
+            return give_up("a replayed sigma call does not reproduce the eager one (the backbone keeps state the graph does not see)")
+        self._iterations_run, _, _, self._torch_consumed, self._philox_offset = saved
+        torch.cuda.set_rng_state(saved[1], dev)
+        return cap
+
     def _call_graphed(self, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
         """One sigma call with its think loop replayed as a hipGraph.  Only the part BETWEEN the replace step
         and the finalise is captured (N x [backbone, fused step] + the final backbone call): the prologue
@@ -783,13 +858,18 @@ class LanPaint:
             cap.alive = False
             cap = None
         if cap is None:
-            cap = self._capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+            capture = self._auto_capture if self.graph == "auto" else self._capture
+            cap = capture(key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
             if cap is None:          # not capturable after all (see _capture): the eager path
                 return self.LanPaint(x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
             while len(self._graphs) > self.MAX_GRAPHS:       # bound the static memory held by stale captures
                 self._graphs.popitem(last=False)[1].alive = False
         else:
             self._graphs.move_to_end(key)
+        return self._run_capture(cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW)
+
+    def _run_capture(self, cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
+        """Replay `cap` for this call's tensors."""
         srcs = (x, sigma, current_times[0], current_times[1], current_times[2], self.noise)
         fast = cap.fast and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs) and self.noise.shape == x.shape \
             and (x.data_ptr() & 15) == 0 and (self.noise.data_ptr() & 15) == 0
@@ -1232,15 +1312,25 @@ class LanPaint:
         elif stopper is not None:
             ran = self._loop_unfused(st, n_steps, model_options, seed, stopper)
         else:
+            auto = self._auto if (self.graph == "auto" and self._capturing is None) else None
+            bb_s = 0.0
             for i in range(n_steps):
                 last = i == n_steps - 1
-                alive = self._set_model_output(d, self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed),
-                                               base_flags | self._emit(st, last), shape)
+                if auto is not None:         # host cost of enqueueing one backbone call (graph="auto" decides on it)
+                    t_bb = perf_counter()
+                    output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
+                    bb_s += perf_counter() - t_bb
+                else:
+                    output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
+                alive = self._set_model_output(d, output, base_flags | self._emit(st, last), shape)
                 d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
                 self._set_xi(d, ws.x_t, want_pre=not last)
                 self._launch_step(stream)
                 del alive
             ran = n_steps
+            if auto is not None and n_steps > 0:
+                auto[1] += 1
+                auto[2] = min(auto[2], bb_s / n_steps)
         self._iterations_run += ran
         self.last_inner_steps = ran
         x_model = st.x_final if self.model_dtype is None else st.x_final.to(self.model_dtype)
