@@ -102,9 +102,14 @@ def run_case(name):
                       tuple(_t(t) for t in case["times"]), mo, 0, n_steps=case["n_steps"], **kw)
         finally:
             torch.randn_like = orig
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), x_out=x.numpy(), out=out.numpy(),
-                            n_draws=np.int64(len(used)), model_calls=np.int64(model.calls),
-                            xi_seed=np.int64(case["xi_seed"]), shape=np.asarray(case["shape"], dtype=np.int64))
+        common = dict(n_draws=np.int64(len(used)), model_calls=np.int64(model.calls), xi_seed=np.int64(case["xi_seed"]),
+                      shape=np.asarray(case["shape"], dtype=np.int64))
+        if case["digest"]:      # the tensors are MiBs: store slice sums + sampled elements (golden_cases.digest)
+            dx, do = gc.digest(x.numpy(), case["xi_seed"] + 1), gc.digest(out.numpy(), case["xi_seed"] + 2)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **common,
+                                **{f"x_{k}": v for k, v in dx.items()}, **{f"out_{k}": v for k, v in do.items()})
+        else:
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), x_out=x.numpy(), out=out.numpy(), **common)
         return len(used), model.calls
     with XiRecorder() as rec:
         out = eng(x, _t(case["y"]), _t(case["noise"]), _t(case["sigma"]), _t(case["mask"]),
@@ -148,6 +153,48 @@ def run_schedule(name):
         rec_d[f"xi_{i}"] = d
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec_d)
     return len(rec.draws)
+
+
+def run_node_schedule(name):
+    """The reference's OWN KSamplerX0Inpaint.__call__ (nodes.py:229-315; ComfyUI stubbed as its tests stub it) driving the
+    reference engine over a whole schedule with the node defaults; xi from a numpy seed fed to torch.randn_like.
+    Stored: the inner-step count the callable chose at every sigma (backbone calls - 1), every denoised, the final x."""
+    ref = _import_ref_nodes()
+    sc = gc.build_node_schedule(name)
+    h, flow = sc["hyper"], sc["flow"]
+    model = MODELS["linear_tuple"](flow=flow)
+    model.model_type = ref.ModelType.FLOW if flow else "EPS"
+    sig = sc["sigmas"]
+    k = ref.KSamplerX0Inpaint(model, _t(sig))
+    k.latent_image, k.noise = _t(sc["y"]), _t(sc["noise"])
+    k.PaintMethod = RefLanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], IS_FLUX=False,
+                                IS_FLOW=flow, MinStepFrac=h["MinStepFrac"])
+    k.LanPaint_early_stop, k.LanPaint_min_step_frac = h["EarlyStop"], h["MinStepFrac"]
+    draws = iter(gc.seeded_xi(sc["xi_seed"], sc["shape"], 256))
+    used, orig = [], torch.randn_like
+
+    def fed(t, *a, **kw):
+        used.append(1)
+        return torch.from_numpy(next(draws)).to(t.dtype)
+    torch.randn_like = fed
+    x, dm = _t(sc["x"].copy()), _t(sc["denoise_mask"])
+    b = sc["shape"][0]
+    n_eff, denoised = [], []
+    try:
+        for i in range(len(sig) - 1):
+            s = torch.full((b,), float(sig[i]), dtype=torch.float32)
+            calls = model.calls
+            den = k(x, s, dm, model_options={}, seed=0)
+            n_eff.append(model.calls - calls - 1)
+            denoised.append(den.numpy().copy())
+            x = x + (x - den) / float(sig[i]) * float(sig[i + 1] - sig[i])
+    finally:
+        torch.randn_like = orig
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), sigmas=sig, n_eff=np.asarray(n_eff, dtype=np.int64),
+                        denoised=np.stack(denoised), x_final=x.numpy(), n_draws=np.int64(len(used)),
+                        model_calls=np.int64(model.calls), xi_seed=np.int64(sc["xi_seed"]),
+                        shape=np.asarray(sc["shape"], dtype=np.int64))
+    return n_eff, len(used)
 
 
 def coefficient_kat():
@@ -242,7 +289,11 @@ def blend_kat():
 
 
 def main():
-    only = sys.argv[1:]                   # `make_golden.py name ...` regenerates just those single-call cases
+    only = sys.argv[1:]                   # `make_golden.py name ...` regenerates just those cases
+    for name in gc.NODE_SCHEDULES:
+        if name in only:
+            n_eff, nd = run_node_schedule(name)
+            print(f"{name:24s} draws={nd} n_eff={n_eff}")
     for name in gc.CASES:
         if only and name not in only:
             continue
@@ -252,6 +303,9 @@ def main():
         return
     for name in gc.SCHEDULES:
         print(f"{name:24s} draws={run_schedule(name)}")
+    for name in gc.NODE_SCHEDULES:
+        n_eff, nd = run_node_schedule(name)
+        print(f"{name:24s} draws={nd} n_eff={n_eff}")
     coefficient_kat()
     boundary_kat()
     blend_kat()

@@ -47,6 +47,9 @@ def build_case(name):
     elif c.get("mask") == "checker":
         idx = np.indices(shape).sum(axis=0)
         mask = (idx % 2).astype(np.float32)
+    elif c.get("mask") == "temporal":          # video latent [B, C, F, H, W]: the leading frames stay known (BASELINE C5)
+        mask = np.zeros(shape, dtype=np.float32)
+        mask[:, :, : c.get("known_frames", shape[2] // 2)] = 1.0
     elif c.get("mask") == "blob":
         mask = np.ones(shape, dtype=np.float32)
         h, w = shape[-2], shape[-1]
@@ -62,7 +65,29 @@ def build_case(name):
                 x=x, y=y, noise=noise, mask=mask,
                 times=(ve.astype(np.float32), abt.astype(np.float32), flow_t.astype(np.float32)),
                 hyper=hyper, model=c.get("model", "linear_tuple"), n_steps=c.get("n_steps", None),
-                model_options=c.get("model_options", None), audio=c.get("audio", None), xi_seed=c.get("xi_seed", None))
+                model_options=c.get("model_options", None), audio=c.get("audio", None), xi_seed=c.get("xi_seed", None),
+                digest=bool(c.get("digest", False)))
+
+
+DIGEST_SAMPLES = 4096
+
+
+def digest(a, sample_seed):
+    """Compact stand-in for a full-size output (a digest fixture stores this instead of the tensor): float64 sums and
+    sums of squares per leading-axes slice (batch row; per frame as well for video latents) and DIGEST_SAMPLES elements at
+    seeded positions.  An error anywhere in the tensor moves a slice sum; the samples pin individual values."""
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    idx = np.random.default_rng(sample_seed).choice(flat.size, size=min(DIGEST_SAMPLES, flat.size), replace=False)
+    idx.sort()
+    a64 = a.astype(np.float64)
+    if a.ndim == 5:       # [B, C, F, H, W] -> per (row, frame)
+        sums = a64.sum(axis=(1, 3, 4))
+        sq = (a64 ** 2).sum(axis=(1, 3, 4))
+    else:
+        sums = a64.reshape(a.shape[0], -1).sum(axis=1)
+        sq = (a64.reshape(a.shape[0], -1) ** 2).sum(axis=1)
+    return dict(sums=sums, sumsq=sq, samples=flat[idx].astype(np.float32), sample_idx=idx.astype(np.int64))
 
 
 def seeded_xi(xi_seed, shape, n):
@@ -99,6 +124,12 @@ CASES = {
     "ve_sd15_full":    dict(shape=(1, 4, 64, 64), sigma=[2.5], seed=35, xi_seed=4244),          # C1 = SD1.5 1x4x64x64
     "ve_sdxl_full":    dict(shape=(1, 4, 128, 128), sigma=[1.0], seed=33, xi_seed=4242),
     "flow_flux_full":  dict(shape=(1, 16, 64, 64), sigma=[0.6], flow=True, seed=34, xi_seed=4243),
+    # C3 = SDXL batch of 4 (per-row sigma: the reference's row broadcast, lanpaint.py:23-29, and its flow-form replace step
+    # for per-row sigma, :89-92) and C5 = Wan 1x16x21x60x104 video latent with the temporal mask, both at FULL size from the
+    # reference; stored as digests (slice sums + 4 096 sampled elements) because the tensors are 1 MiB / 8 MiB each
+    "ve_sdxl_b4_full": dict(shape=(4, 4, 128, 128), sigma=[2.0, 0.7, 5.0, 1.2], seed=36, xi_seed=4245, digest=True),
+    "flow_wan_full":   dict(shape=(1, 16, 21, 60, 104), sigma=[0.6], flow=True, seed=37, xi_seed=4246, digest=True,
+                            mask="temporal", known_frames=8),
     # flow / flux (Flux, Wan, SD3 notation)
     "flow_basic":      dict(shape=(1, 16, 4, 4), sigma=[0.7], flow=True, seed=20),
     "flow_flux_flag":  dict(shape=(1, 16, 4, 4), sigma=[0.5], flux=True, seed=21),
@@ -130,6 +161,30 @@ SCHEDULES = {
     "sched_ve_batch2":  dict(shape=(2, 4, 8, 8), flow=False, n_sigmas=4, sigma_max=10.0, sigma_min=0.1,
                              hyper=dict(NSteps=2, MinStepFrac=1.0), seed=42),
 }
+
+
+# the sampler-facing callable (reference nodes.py:221-315) over a whole schedule with the NODE defaults: MinStepFrac = 1.0,
+# LanPaint_EarlyStop = 1 -> n_eff = round(NSteps (1 - abt)) ramping 5 ... 0 (nodes.py:286-299)
+NODE_SCHEDULES = {
+    "node_ve_karras12": dict(shape=(2, 4, 16, 16), flow=False, n_sigmas=12, sigma_max=14.6146, sigma_min=0.0292, seed=50,
+                             xi_seed=4250),
+    "node_flow12":      dict(shape=(1, 16, 8, 8), flow=True, n_sigmas=12, seed=51, xi_seed=4251),
+}
+NODE_DEFAULTS = dict(NSteps=5, Friction=15.0, Lambda=5.0, Beta=1.0, StepSize=0.2, MinStepFrac=1.0, EarlyStop=1)
+
+
+def build_node_schedule(name):
+    c = dict(NODE_SCHEDULES[name])
+    shape, flow = tuple(c["shape"]), c["flow"]
+    sig = flow_sigmas(c["n_sigmas"]) if flow else karras_sigmas(c["n_sigmas"], c["sigma_min"], c["sigma_max"])
+    rng = np.random.default_rng(c["seed"])
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    x = (sig[0] * noise + (1 - sig[0]) * y).astype(np.float32) if flow else (y + noise * sig[0]).astype(np.float32)
+    # ComfyUI's denoise_mask (1 = inpaint), NOT binary on purpose: the callable thresholds it at 0.5 (nodes.py:281)
+    denoise_mask = (rng.random(shape) > 0.45).astype(np.float32) * np.float32(0.9) + np.float32(0.05)
+    return dict(name=name, shape=shape, flow=flow, sigmas=sig, x=x, y=y, noise=noise, denoise_mask=denoise_mask,
+                hyper=dict(NODE_DEFAULTS), xi_seed=c["xi_seed"])
 
 
 def karras_sigmas(n, sigma_min=0.0292, sigma_max=14.6146, rho=7.0):

@@ -75,6 +75,27 @@ def run_product_case(name, device="cuda", rng="recorded", model_cls=None, sampli
                 golden=g, case=case, model_options=mo)
 
 
+def assert_matches_golden(x, out, g, what, rel=2e-5):
+    """The written-back x and the returned out of one engine call against a golden fixture: the full tensors, or -- for
+    the full-size digest fixtures (golden_cases.digest) -- the sampled elements and the per-slice sums / sums of squares."""
+    if "x_out" in g.files:
+        assert_close(x, g["x_out"], f"{what}: in-place x", rel=rel)
+        assert_close(out, g["out"], f"{what}: out", rel=rel)
+        return
+    for tag, a, salt in (("x", x, 1), ("out", out, 2)):
+        d = gc.digest(a, int(g["xi_seed"]) + salt)
+        assert np.array_equal(d["sample_idx"], g[f"{tag}_sample_idx"]), f"{what}: {tag} sample positions"
+        assert_close(d["samples"], g[f"{tag}_samples"], f"{what}: {tag} sampled elements", rel=rel)
+        scale = max(1.0, float(np.abs(g[f"{tag}_samples"]).max()))
+        n_slice = np.asarray(a).size / g[f"{tag}_sums"].size
+        # per-element error <= rel * scale, independent roundings: a slice sum moves by ~ sqrt(n) of that; one wrong element
+        # (an index, a mask bit, a row's coefficients) moves it by O(scale)
+        tol = 4.0 * rel * scale * np.sqrt(n_slice)
+        err = float(np.abs(d["sums"] - g[f"{tag}_sums"]).max())
+        assert err <= tol, f"{what}: {tag} slice sums off by {err:.3e} > {tol:.3e}"
+        np.testing.assert_allclose(d["sumsq"], g[f"{tag}_sumsq"], rtol=20 * rel, err_msg=f"{what}: {tag} slice sums of squares")
+
+
 def assert_close(a, b, what, rel=2e-5, mse=1e-9):
     """|a-b|_inf <= rel * max(1, |b|_inf) and MSE <= mse (far inside BASELINE's 1e-5)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)

@@ -378,6 +378,49 @@ def test_ksampler_x0_inpaint_matches_oracle(flow):
     assert torch.equal(out, 0.9 * x)
 
 
+@pytest.mark.parametrize("name", sorted(gc.NODE_SCHEDULES))
+def test_ksampler_x0_inpaint_matches_the_reference_sampler_callable(name):
+    """a1 against a reference RUN (no oracle in between): tests/golden/node_*.npz holds what the reference's own
+    KSamplerX0Inpaint.__call__ (nodes.py:229-315) + engine did over a 12-sigma schedule with the node defaults (MinStepFrac
+    1.0, EarlyStop 1): the inner-step count per sigma, every denoised, the final x.  The HIP callable, fed the same xi stream,
+    must choose the same counts (lp_sigma_times + the host rule) and reproduce the trajectory."""
+    import torch
+    from lanpaint_amd import LanPaint
+    from lanpaint_amd import nodes
+    from tests.helpers import load_golden
+    sc = gc.build_node_schedule(name)
+    g = load_golden(name)
+    h, flow, sig = sc["hyper"], sc["flow"], sc["sigmas"]
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    it = iter([tt(d) for d in gc.seeded_xi(int(g["xi_seed"]), sc["shape"], int(g["n_draws"]))])
+
+    class M(_DummyModel):
+        def __call__(self, x, sigma, model_options=None, seed=None):
+            self.calls += 1
+            return 0.9 * x, 0.8 * x
+
+    model = M(_FlowSampling() if flow else _DummySampling())
+    model.model_type = nodes.ModelType.FLOW if flow else "EPS"
+    k = nodes.KSamplerX0Inpaint(model, tt(sig))
+    k.latent_image, k.noise = tt(sc["y"]), tt(sc["noise"])
+    k.PaintMethod = LanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], IS_FLOW=flow,
+                             MinStepFrac=h["MinStepFrac"], rng=lambda like: next(it))
+    k.LanPaint_early_stop, k.LanPaint_min_step_frac = h["EarlyStop"], h["MinStepFrac"]
+    x, dm, mo = tt(sc["x"]), tt(sc["denoise_mask"]), {}
+    n_eff = []
+    for i in range(len(sig) - 1):
+        s = torch.full((sc["shape"][0],), float(sig[i]), dtype=torch.float32, device=DEV)
+        calls = model.calls
+        den = k(x, s, dm, model_options=mo, seed=0)
+        n_eff.append(model.calls - calls - 1)
+        assert k.PaintMethod.last_inner_steps == n_eff[-1]
+        assert_close(den.cpu().numpy(), g["denoised"][i], f"{name}: denoised[{i}]", rel=5e-5)
+        x = x + (x - den) / float(sig[i]) * float(sig[i + 1] - sig[i])
+    assert n_eff == list(g["n_eff"])
+    assert sum(1 for _ in it) == 0 and model.calls == int(g["model_calls"])
+    assert_close(x.cpu().numpy(), g["x_final"], f"{name}: final x", rel=5e-5)
+
+
 @pytest.mark.parametrize("flow,inference", [(False, False), (True, False), (False, True)])
 def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference):
     """(`inference`: the whole run inside torch.inference_mode(), as ComfyUI executes its nodes -- inference tensors

@@ -6,7 +6,8 @@ import pytest
 
 from oracle.lanpaint_oracle import OracleLanPaint
 from tests import golden_cases as gc
-from tests.helpers import assert_close, load_golden, run_oracle_case, xi_list
+from oracle import lanpaint_oracle as orc
+from tests.helpers import assert_close, assert_matches_golden, load_golden, run_oracle_case, xi_list
 from tests.stubs import MODELS
 
 
@@ -16,8 +17,7 @@ def test_oracle_matches_reference_golden(name):
     g = r["golden"]
     assert r["leftover"] == 0, "oracle consumed a different number of xi draws than the reference"
     assert r["model"].calls == int(g["model_calls"])
-    assert_close(r["x"], g["x_out"], f"{name}: in-place x", rel=3e-6)
-    assert_close(r["out"], g["out"], f"{name}: out", rel=3e-6)
+    assert_matches_golden(r["x"], r["out"], g, name, rel=3e-6)
     if "trace_dist" in g.files:
         tr = r["engine"].last_stopper.trace
         assert len(tr) == len(g["trace_dist"])
@@ -44,6 +44,35 @@ def test_oracle_matches_reference_schedule(name):
         x = (x + (x - den) / sig[i] * (sig[i + 1] - sig[i])).astype(np.float32)
     assert sum(1 for _ in it) == 0
     assert_close(x, g["x_final"], f"{name}: final x", rel=2e-5)
+
+
+@pytest.mark.parametrize("name", sorted(gc.NODE_SCHEDULES))
+def test_oracle_matches_the_reference_sampler_callable(name):
+    """a1 pinned by a reference RUN: the fixture holds what the reference's own KSamplerX0Inpaint.__call__ (nodes.py:229-315)
+    did over a schedule with the node defaults -- the inner-step count it chose at every sigma, every denoised, the final x.
+    The oracle's restatement of that callable (sigma -> times, mask threshold + invert, the n_eff rule) must choose the same
+    counts and walk the same trajectory."""
+    sc = gc.build_node_schedule(name)
+    g = load_golden(name)
+    h, flow, sig = sc["hyper"], sc["flow"], sc["sigmas"]
+    it = iter(gc.seeded_xi(int(g["xi_seed"]), sc["shape"], int(g["n_draws"])))
+    model = MODELS["linear_tuple"](flow=flow)
+    eng = OracleLanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], is_flow=flow,
+                         min_step_frac=h["MinStepFrac"], randn=lambda like: next(it))
+    latent_mask = orc.binarize_and_invert(sc["denoise_mask"])
+    x, n_eff = sc["x"].copy(), []
+    for i in range(len(sig) - 1):
+        s = np.full((sc["shape"][0],), sig[i], dtype=np.float32)
+        times = orc.times_from_sigma(s, flow)
+        n = orc.effective_inner_steps(h["NSteps"], sig, float(s.mean()), float(times[1].mean()), h["EarlyStop"], h["MinStepFrac"])
+        n_eff.append(n)
+        den = eng(x, sc["y"], sc["noise"], s, latent_mask, times, None, 0, n_steps=n)
+        assert_close(den, g["denoised"][i], f"{name}: denoised[{i}]", rel=2e-5)
+        x = (x + (x - den) / sig[i] * (sig[i + 1] - sig[i])).astype(np.float32)
+    assert n_eff == list(g["n_eff"])
+    assert sum(1 for _ in it) == 0 and model.calls == int(g["model_calls"])
+    assert_close(x, g["x_final"], f"{name}: final x", rel=2e-5)
+    assert len(set(n_eff)) >= 5 and n_eff[-1] == 0 and max(n_eff) == h["NSteps"]      # the ramp is really exercised
 
 
 def test_oracle_on_torch_backend_matches_numpy():
