@@ -6,7 +6,7 @@ import pytest
 from oracle import c_oracle
 from oracle import lanpaint_oracle as orc
 from tests import golden_cases as gc
-from tests.helpers import assert_close, load_golden, xi_list
+from tests.helpers import assert_close, assert_matches_golden, load_golden, xi_list
 from tests.stubs import MODELS
 
 B1_CASES = [n for n, c in sorted(gc.CASES.items())
@@ -26,8 +26,7 @@ def test_c_oracle_matches_reference_golden(name):
     x = case["x"].copy()
     out = eng(x, case["y"], case["noise"], case["sigma"], case["mask"], case["times"], n_steps=case["n_steps"])
     assert sum(1 for _ in it) == 0
-    assert_close(x, g["x_out"], f"{name}: x", rel=3e-6)
-    assert_close(out, g["out"], f"{name}: out", rel=3e-6)
+    assert_matches_golden(x, out, g, name, rel=3e-6)
 
 
 def test_c_nearest_exact_index_matches_numpy():
