@@ -32,9 +32,14 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=True, shader_clock=False):
+def build(force=False, verbose=True, shader_clock=False, trace=False):
     """`shader_clock`: the profiling variant (-DLP_SHADER_CLOCK, scripts/shader_clock.py) as build/liblanpaint_hip_clk.so;
-    the product library is never built with it."""
+    `trace`: the coverage variant (-DLP_TRACE_INSTANTIATIONS, scripts/instantiation_coverage.py) as
+    build/liblanpaint_hip_trace.so.  The product library is never built with either."""
+    if trace:
+        out = os.path.join(ROOT, "build", "liblanpaint_hip_trace.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        return _compile(out, ["-DLP_TRACE_INSTANTIATIONS"], verbose)
     if shader_clock:
         out = os.path.join(ROOT, "build", "liblanpaint_hip_clk.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -60,4 +65,4 @@ def _compile(out, extra, verbose):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, shader_clock="--shader-clock" in sys.argv)
+    build(force="--force" in sys.argv, shader_clock="--shader-clock" in sys.argv, trace="--trace" in sys.argv)

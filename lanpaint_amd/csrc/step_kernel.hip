@@ -1045,6 +1045,45 @@ static unsigned st_segments(const lp_step_desc& d) {
     return (gy > 0 && gy <= 65535 && static_cast<int64_t>(d.rng_inc) == 4 * rounds) ? static_cast<unsigned>(gy) : 0u;
 }
 
+// ---- coverage build (-DLP_TRACE_INSTANTIATIONS; build/liblanpaint_hip_trace.so, never the product library) ------------
+// Which lp_step_kernel<...> instantiations does a process really launch?  Every launch notes its template arguments; the
+// set is appended to the file LANPAINT_AMD_TRACE_FILE names when the process exits.  scripts/instantiation_coverage.py
+// compares it with the instantiations the product library contains (tests/test_cabi_exports.py keeps the two in step).
+#ifdef LP_TRACE_INSTANTIATIONS
+}  // namespace lp
+#include <cstdio>
+#include <mutex>
+#include <set>
+#include <string>
+namespace lp {
+struct TraceSet {
+    std::mutex mu;
+    std::set<std::string> seen;
+    ~TraceSet() {
+        const char* path = std::getenv("LANPAINT_AMD_TRACE_FILE");
+        if (!path || seen.empty()) return;
+        if (FILE* f = std::fopen(path, "a")) {
+            for (const auto& s : seen) std::fprintf(f, "%s\n", s.c_str());
+            std::fclose(f);
+        }
+    }
+};
+static TraceSet& trace_set() {
+    static TraceSet t;
+    return t;
+}
+static void trace_note(int vec, int mode, unsigned ph, int x0w, int rng, bool st, int es) {
+    char buf[96];
+    std::snprintf(buf, sizeof buf, "%d, %d, %uu, %d, %d, %s, %d", vec, mode, ph, x0w, rng, st ? "true" : "false", es);
+    TraceSet& t = trace_set();
+    std::lock_guard<std::mutex> lock(t.mu);
+    t.seen.insert(buf);
+}
+#define LP_TRACE(es) trace_note(VEC, MODE, PH, X0W, RNG, ST, es)
+#else
+#define LP_TRACE(es)
+#endif
+
 // the preloaded leading arguments of lp_step_kernel<VEC, ...> (see its head) followed by the descriptor
 #define LP_STEP_ARGS(d)                                                                                          \
     static_cast<void*>((d).x_t), static_cast<void*>((d).C),                                                      \
@@ -1078,6 +1117,7 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
         // grids fit the fold as well.)
         const unsigned nblocks = grid.x * grid.y;
         const bool fold = (d.flags & LP_FL_ES_GATED) && nblocks <= 2u * static_cast<unsigned>(block) && !t.es_no_fold;
+        LP_TRACE(fold ? 2 : 1);
         if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         const bool close = fold && (d.flags & LP_FL_ES_CLOSE) && d.es_index + 1 == d.es_n_steps;
@@ -1087,6 +1127,7 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
         }
         return hipGetLastError();
     }
+    LP_TRACE(ES);
     if (timer) {
         hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, timer->start,
                               timer->stop, 0, LP_STEP_ARGS(d));
