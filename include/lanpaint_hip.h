@@ -118,12 +118,13 @@ typedef struct lp_hyper {
                                           one of them unused for a whole wave (measurement / A-B switch)       */
 #define LP_FL_ES            (1u << 13) /* the POST phase of this launch also evaluates the inner early-stop rule ON THE DEVICE
                                           (earlystop.py:238-336): per-block partial sums of the weighted MSEs (x0s against the
-                                          previous x0s and against the drift anchor; iteration 0: x_t after against x_t before);
-                                          lp_step then enqueues a one-block kernel that reduces them in a fixed order, applies
+                                          previous x0s and against the drift anchor; iteration 0: x_t after against x_t before)
+                                          and adds them into the accumulator set of the iteration (es_partials);
+                                          lp_step then enqueues a one-wave kernel that totals the set in a fixed order, applies
                                           the threshold / patience / drift-anchor logic, updates lp_es_state and posts the
-                                          trace record to `es_host` (a gated loop on a grid of <= 512 blocks instead applies
-                                          the rule at the top of its NEXT launch and enqueues that kernel after the last
-                                          launch only).  Row-table launches only (not LP_FL_PER_ELEMENT).                    */
+                                          trace record to `es_host` (a gated loop instead applies the rule at the top of its
+                                          NEXT launch, at any grid size, and enqueues that kernel after the last launch
+                                          only).  Row-table launches only (not LP_FL_PER_ELEMENT).                         */
 #define LP_FL_ES_GATED      (1u << 14) /* with LP_FL_ES, a launch of a loop the host does not watch (hipGraph replay): once
                                           lp_es_state.stopped is set the launch only re-emits x_in from the committed x_t;
                                           otherwise PRE_HALF is TENTATIVE -- x_t is stored in its post-iteration state, the
@@ -136,8 +137,7 @@ typedef struct lp_hyper {
                                           its own iteration (n_ran, total_ran) and posts the call's "done" word itself; the
                                           verdict of the last iteration is never formed -- stopping after the last iteration
                                           changes nothing (earlystop.py:313 only breaks a loop that is over) -- and its trace
-                                          record is not written, so a caller that wants the full trace leaves the flag off.
-                                          Ignored where a one-block kernel decides every iteration anyway (larger grids).  */
+                                          record is not written, so a caller that wants the full trace leaves the flag off.  */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 
@@ -169,6 +169,9 @@ typedef struct lp_es_state {
  * last launch of a gated loop; [1] n_ran, [2] stopped, [3] enabled, [4] threshold_eff, [5] abt_val, [6] total_ran;
  * [LP_ES_TRACE0 + 8 i ..]: record of iteration i = { dist, dist_inpaint, dist_ring, dist_drift (NaN = not
  * evaluated), patience_counter, stopped, 0, 0 }.                                                       */
+#define LP_ES_ACC_SLOTS  64
+#define LP_ES_ACC_SETS   3
+#define LP_ES_ACC_DOUBLES (LP_ES_ACC_SETS * LP_ES_ACC_SLOTS * 8)
 #define LP_ES_SEQ_DONE   0x10000
 #define LP_ES_TRACE0     8
 #define LP_ES_MAILBOX_DOUBLES(n_steps) (LP_ES_TRACE0 + 8 * (n_steps))
@@ -253,7 +256,10 @@ typedef struct lp_step_desc {
     float*       es_x0s[3];      /* the three rotating x0s buffers (== es->x0s_buf, as launch arguments so the kernel
                                     selects one by slot index instead of chasing a pointer through the state)     */
     const float* es_ring;        /* mask-edge ring weight (lp_boundary_ring; 4-D latents), or NULL           */
-    float*       es_partials;    /* device scratch: 2 x 8 floats per block of the launch                     */
+    double*      es_partials;    /* device scratch, LP_ES_ACC_DOUBLES doubles: the accumulator sets the blocks of an
+                                    LP_FL_ES launch add their six sums into (set = es_index mod LP_ES_ACC_SETS, slot =
+                                    block mod LP_ES_ACC_SLOTS).  The es_reset launch clears all of it; launch i clears
+                                    the set of iteration i + 1.                                                     */
     double*      es_host;        /* mailbox, LP_ES_MAILBOX_DOUBLES(es_n_steps) doubles                       */
     double       es_threshold;   /* threshold before the abt scaling (earlystop.py:78-81)                    */
     int64_t      es_seq_base;    /* es_reset: sequence base of this call                                     */

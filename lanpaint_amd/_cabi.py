@@ -73,6 +73,8 @@ class LpEsState(C.Structure):
 
 
 LP_ES_SEQ_DONE, LP_ES_TRACE0 = 0x10000, 8
+LP_ES_ACC_SLOTS, LP_ES_ACC_SETS = 64, 3
+LP_ES_ACC_DOUBLES = LP_ES_ACC_SETS * LP_ES_ACC_SLOTS * 8
 
 
 class LpFinalDesc(C.Structure):

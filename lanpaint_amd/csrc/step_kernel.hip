@@ -144,6 +144,38 @@ __device__ __forceinline__ float ou_general(float x, float tau, float a, float c
 // ---- inner early stop on the device (earlystop.py:58-336, default metric) ----------------------------------
 constexpr int kEsSums = 6;    // { sum w1 dA^2, sum w1, sum w2 dA^2, sum w2, sum w1 dB^2, sum w2 dB^2 }
 
+// Cross-block accumulation of the six sums (round 3): every block adds its fp32 block sums -- as doubles, with
+// device-scope hardware atomics -- into one of LP_ES_ACC_SLOTS slots of the accumulator set of its iteration
+// (d.es_partials: LP_ES_ACC_SETS sets x LP_ES_ACC_SLOTS slots x 8 doubles; slot = block index mod LP_ES_ACC_SLOTS, so an
+// address sees grid / 64 adds, not grid).  Whoever needs the totals of an iteration -- the next launch of a gated loop,
+// lp_es_decide_kernel of a watched one -- sums the 64 slots in a fixed order, one slot per lane, with DPP moves: no
+// per-block table to re-read (which limited the folded verdict to grids of <= 512 blocks) and no one-block kernel between
+// two launches of a replayed loop at any size (C5: 21.5 -> see profiles/r03_microbench_es.log).  The sets rotate: launch i
+// adds into set i % 3, reads set (i - 1) % 3 and clears set (i + 1) % 3, which nobody touches before launch i + 1.
+// A double add of fp32 block sums is exact to ~1e-16 whatever order the atomics land in; the fp32 quotients the stop rule
+// forms from the totals (earlystop.py:55) therefore agree between runs except when a total sits within 1e-16 of an fp32
+// rounding boundary.
+constexpr int kEsSlots = LP_ES_ACC_SLOTS, kEsSets = LP_ES_ACC_SETS;
+static_assert(kEsSlots == kWave, "one accumulator slot per lane of the reducing wave");
+
+__device__ __forceinline__ double* es_acc_set(const lp_step_desc& d, int iteration) {
+    return d.es_partials + static_cast<size_t>(((iteration % kEsSets) + kEsSets) % kEsSets) * kEsSlots * 8;
+}
+
+// lane l holds slot l's six doubles; afterwards EVERY lane holds the six totals as floats (same bits in every wave of
+// every block: fixed DPP order over the slots).  The 64 slot values are rounded to fp32 first and totalled in fp32 -- the
+// precision the reference's own sums have (earlystop.py:52-55), and half the registers of a double tree inside a launch
+// whose operand loads are all in flight at this point.
+__device__ __forceinline__ void es_slot_total(const double (&v)[kEsSums], float (&tot)[kEsSums]) {
+    float f[kEsSums];
+#pragma unroll
+    for (int k = 0; k < kEsSums; ++k) f[k] = static_cast<float>(v[k]);
+    wave_sum_dpp(f);                                              // total valid in lane 63
+#pragma unroll
+    for (int k = 0; k < kEsSums; ++k)
+        tot[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f[k]), kWave - 1));
+}
+
 __device__ __forceinline__ double clamp01(double v) { return v <= 0.0 ? 0.0 : (v >= 1.0 ? 1.0 : v); }
 
 // New sigma call: patience counter, anchor and buffer rotation start over; the abt-scaled threshold
@@ -175,29 +207,6 @@ __device__ __forceinline__ void es_reset_state(const lp_step_desc& d, bool fold)
 __device__ __forceinline__ void es_post_seq(double* host, int64_t seq) {
     __threadfence_system();
     __hip_atomic_store(reinterpret_cast<int64_t*>(host), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// Block-wide fixed-order total of each thread's six partial sums (thread t holds rows t, t + 256, ... of the per-block
-// table): DPP inside the wave, the waves in order through LDS.  Every thread returns the same bits; the folded
-// prologue of the step kernel and lp_es_decide_kernel both come here, so a captured and an eager loop agree exactly.
-// (Blocks of exactly four waves -- the dispatcher launches LP_FL_ES work with 256 threads -- and all 24 LDS words read
-// before the first add: a run-time wave loop made it 18 dependent LDS round trips, 0.9 us by the shader clock.)
-__device__ __forceinline__ void es_block_total(float (&v)[kEsSums], float (&tot)[kEsSums], float (*part)[kEsSums]) {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    wave_sum_dpp(v);
-    if (lane == kWave - 1) {
-#pragma unroll
-        for (int k = 0; k < kEsSums; ++k) part[wave][k] = v[k];
-    }
-    __syncthreads();
-    float p[4][kEsSums];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-#pragma unroll
-        for (int k = 0; k < kEsSums; ++k) p[w][k] = part[w][k];
-    }
-#pragma unroll
-    for (int k = 0; k < kEsSums; ++k) tot[k] = ((p[0][k] + p[1][k]) + p[2][k]) + p[3][k];
 }
 
 // The stop rule of one iteration (earlystop.py:279-313) from the six sums; one thread.  `st` is the state as ONE
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     // folded decision: what its prologue loads (state fields, the previous launch's per-block sums)
     lp_es_state es_lite;
     uint2 es_words[8];
-    float es_fv[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    double es_fv[kEsSums] = {0., 0., 0., 0., 0., 0.};
     if constexpr (ES) {
         es_gated = (fl & LP_FL_ES_GATED) != 0;
         if constexpr (es_fold) {
@@ -427,21 +436,11 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
 #pragma unroll
             for (int k = 0; k < 8; ++k) es_words[k] = sv[k];
             es_keeper = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
-            // thread t: rows t and t + blockDim of the previous launch's sums (the dispatcher folds up to 2 rows per
-            // thread).  Unconditional loads from clamped rows + selects: a predicated load becomes a branch with its
-            // own wait, six round trips in a row.
-            const unsigned nblocks = gridDim.x * gridDim.y;
-            const float* src = d.es_partials + static_cast<size_t>(rd) * nblocks * 8;
-            const unsigned t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
-            const unsigned b0 = t0 < nblocks ? t0 : nblocks - 1, b1 = t1 < nblocks ? t1 : nblocks - 1;
-            float r0[kEsSums], r1[kEsSums];
+            // lane l of every wave: slot l of the previous iteration's accumulator set (48 B; the whole set is 3 KB and
+            // sits in L2 after the first wave of an XCD has touched it)
+            const double* src = es_acc_set(d, d.es_index - 1) + static_cast<size_t>(threadIdx.x & (kWave - 1)) * 8;
 #pragma unroll
-            for (int k = 0; k < kEsSums; ++k) {
-                r0[k] = src[static_cast<size_t>(b0) * 8 + k];
-                r1[k] = src[static_cast<size_t>(b1) * 8 + k];
-            }
-#pragma unroll
-            for (int k = 0; k < kEsSums; ++k) es_fv[k] = (0.0f + (t0 < nblocks ? r0[k] : 0.0f)) + (t1 < nblocks ? r1[k] : 0.0f);
+            for (int k = 0; k < kEsSums; ++k) es_fv[k] = src[k];
         } else {                                     // wave-uniform scalar loads of the device-side stop state
             es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot;
             if (es_gated && d.es->stopped != 0) {    // the loop has stopped: only re-emit x_in from the committed x_t
@@ -624,7 +623,12 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             d.io_table_out[1] = d.io_table_val[1];
         }
         if constexpr (PH == 0 || (PH & LP_PH_REPLACE) != 0) {
-            if (d.es_reset && d.es && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) es_reset_state(d, fold_coeffs);
+            if (d.es_reset && d.es && blockIdx.x == 0 && blockIdx.y == 0) {
+                if (d.es_partials) {                      // every accumulator set starts the call at zero
+                    for (int k = threadIdx.x; k < kEsSets * kEsSlots * 8; k += kBlock) d.es_partials[k] = 0.0;
+                }
+                if (threadIdx.x == 0) es_reset_state(d, fold_coeffs);
+            }
         }
 
         LP_CLK(1)
@@ -695,9 +699,8 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                     es_lite.abt_val = __longlong_as_double(static_cast<long long>(u64(14)));
                 }
                 if (it > 0 && es_lite.stopped == 0) {
-                    __shared__ float fold_part[4][kEsSums];
                     float tot[kEsSums];
-                    es_block_total(es_fv, tot, fold_part);
+                    es_slot_total(es_fv, tot);
                     const bool hp = es_lite.cur_slot >= 0, ha = es_lite.anchor_slot >= 0;
                     es_decide(d, es_lite, tot, hp, ha, it - 1, es_keeper);
                 }
@@ -950,10 +953,10 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     if constexpr (!ES) {
         LP_CLK_FLUSH
     }
-    // ---- early stop: this block's partial sums; lp_es_decide_kernel (next launch) reduces them and applies the rule.
+    // ---- early stop: this block's sums go into the iteration's accumulator set (device-scope atomics, no fence); the
+    // next launch of a gated loop / lp_es_decide_kernel of a watched one totals the 64 slots and applies the rule.
     // (One kernel with a "last block done" ticket needs a device-scope fence per block, i.e. an L2 write-back on
-    // every XCD: measured 30 us per launch at 65 536 elements.  A kernel boundary gives the same visibility for
-    // the price of one more dependent launch, ~2 us.)
+    // every XCD: measured 30 us per launch at 65 536 elements.  A kernel boundary gives the same visibility.)
     if constexpr (ES) {
         if (es_idle || !post) return;
         // fp32 throughout, like the reference's own sums (earlystop.py:52-55), in a fixed order
@@ -965,38 +968,38 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             for (int k = 0; k < kEsSums; ++k) es_part[wave][k] = es_p[k];
         }
         __syncthreads();
+        const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
         if (threadIdx.x < kEsSums) {
-            const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
             const float p0 = es_part[0][threadIdx.x], p1 = es_part[1][threadIdx.x], p2 = es_part[2][threadIdx.x],
                         p3 = es_part[3][threadIdx.x];
-            const float v = ((p0 + p1) + p2) + p3;
-            const size_t base = es_fold ? static_cast<size_t>(d.es_index & 1) * gridDim.x * gridDim.y * 8 : 0;
-            d.es_partials[base + static_cast<size_t>(blk) * 8 + threadIdx.x] = v;
+            const float v = ((p0 + p1) + p2) + p3;                  // the block's sum, fp32, fixed order
+            double* acc = es_acc_set(d, d.es_index) + static_cast<size_t>(blk % kEsSlots) * 8 + threadIdx.x;
+            (void)__hip_atomic_fetch_add(acc, static_cast<double>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the set of the iteration after this one starts from zero (nobody reads or adds to it during this launch)
+        if (blk == 0 && threadIdx.x >= kWave) {
+            double* nxt = es_acc_set(d, d.es_index + 1);
+            for (int k = threadIdx.x - kWave; k < kEsSlots * 8; k += kBlock - kWave) nxt[k] = 0.0;
         }
         LP_CLK(7)
         LP_CLK_FLUSH
     }
 }
 
-// One block: fixed-order reduction of the per-block partial sums of the LP_FL_ES launch before it, then the stop rule.
-// `slot`: which of the two state slots / partial-sum buffers (0 unless it closes a folded loop).
-__global__ __launch_bounds__(256) void lp_es_decide_kernel(const lp_step_desc d, unsigned nblocks, int slot) {
-    // Every load of this kernel is issued up front -- the partial sums, and (thread 0) the whole state as one block
-    // load -- so the launch pays ONE memory round trip, not one per dependent step (state flag -> partials -> state
-    // fields cost ~5.5 us per launch when chained; the data was written by the previous kernel on other XCDs and
-    // comes from HBM).  A stopped loop simply discards what it loaded.
-    float v[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (unsigned b = threadIdx.x; b < nblocks; b += kBlock) {              // thread t: blocks t, t + 256, ...
+// One wave: fixed-order total of the accumulator slots of iteration d.es_index, then the stop rule.
+// `slot`: which of the two state slots (0 unless it closes a folded loop).
+__global__ __launch_bounds__(64) void lp_es_decide_kernel(const lp_step_desc d, int slot) {
+    // Both loads of this kernel are issued up front -- the lane's accumulator slot, and (lane 0) the whole state as one
+    // block load -- so the launch pays ONE memory round trip.  A stopped loop simply discards what it loaded.
+    const double* src = es_acc_set(d, d.es_index) + static_cast<size_t>(threadIdx.x) * 8;
+    double v[kEsSums];
 #pragma unroll
-        for (int k = 0; k < kEsSums; ++k)
-            v[k] += __builtin_nontemporal_load(d.es_partials + (static_cast<size_t>(slot) * nblocks + b) * 8 + k);
-    }
+    for (int k = 0; k < kEsSums; ++k) v[k] = __builtin_nontemporal_load(src + k);
     lp_es_state st;
     if (threadIdx.x == 0) st = d.es[slot];
     const bool gated = (d.flags & LP_FL_ES_GATED) != 0;
-    __shared__ float es_part[4][kEsSums];
     float tot[kEsSums];
-    es_block_total(v, tot, es_part);                                        // fixed order: DPP tree, then the four waves
+    es_slot_total(v, tot);                                                  // fixed order: the DPP tree over the 64 slots
     if (threadIdx.x != 0) return;
     if (gated && st.stopped != 0) {      // stopped loop: its last launch tells the host the call is done
         if (d.es_index + 1 == d.es_n_steps) {
@@ -1109,21 +1112,19 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     if constexpr (ST) gy = st_segments(d);            // (round, row) pairs, see the kernel head
     const dim3 grid(static_cast<unsigned>(bx), gy);
     if constexpr (ES != 0) {
-        // gated loop on a latency-bound latent: the stop rule of iteration i - 1 rides in launch i (every block redoes the
-        // small reduction), one closing lp_es_decide_kernel after the last launch.  Larger grids keep the one-block kernel
-        // per iteration: re-reading nblocks x 48 B in every block would cost more than the launch it saves.
-        // (The folded kernel is its own instantiation: its extra live state would cost the streaming sizes occupancy
-        // they need.  step_dispatch picks 16 B per lane for early-stop launches of 128 K - 512 K elements so that those
-        // grids fit the fold as well.)
-        const unsigned nblocks = grid.x * grid.y;
-        const bool fold = (d.flags & LP_FL_ES_GATED) && nblocks <= 2u * static_cast<unsigned>(block) && !t.es_no_fold;
+        // gated (replayed) loop: the stop rule of iteration i - 1 rides in launch i -- every wave totals the 64 accumulator
+        // slots itself -- and one closing lp_es_decide_kernel follows the last launch unless the loop closes itself
+        // (LP_FL_ES_CLOSE).  Watched (eager) loop: the host waits for every verdict, so a one-wave kernel forms it right
+        // after the launch.  (The folded kernel is its own instantiation: its extra live state would cost the plain
+        // early-stop launch registers it does not need.)
+        const bool fold = (d.flags & LP_FL_ES_GATED) && !t.es_no_fold;
         LP_TRACE(fold ? 2 : 1);
         if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         const bool close = fold && (d.flags & LP_FL_ES_CLOSE) && d.es_index + 1 == d.es_n_steps;
         if ((d.phases & kPost) && !t.es_no_decide && !close && (!fold || d.es_index + 1 == d.es_n_steps)) {
             if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-            hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(256), 0, stream, d, nblocks, fold ? (d.es_index & 1) : 0);
+            hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(kWave), 0, stream, d, fold ? (d.es_index & 1) : 0);
         }
         return hipGetLastError();
     }
@@ -1161,9 +1162,9 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
                     : launch<VEC, MODE_ROW, 0, 0, 2, false, 1>(d, stream, timer);
     }
     if (d.flags & LP_FL_MASK_U8) return launch<VEC, MODE_ROW, 0>(d, stream, timer);   // legacy format: run-time everything
-    if (d.phases == (R | E))                                                         // replace step: no x0 at all
-        return hard ? launch<VEC, MODE_HARD, R | E>(d, stream, timer) : launch<VEC, MODE_ROW, R | E>(d, stream, timer);
-    if (d.phases == (R | E | LP_PH_COEFFS))                                          // ... + the coefficient table
+    // (a replace launch WITHOUT the folded table -- a caller that ran lp_coeffs itself -- and a loop of ONE iteration,
+    // F | E, run through the run-time-phase kernel: rare launches that do not earn instantiations of their own)
+    if (d.phases == (R | E | LP_PH_COEFFS))                                          // replace step + the coefficient table
         return hard ? launch<VEC, MODE_HARD, R | E | LP_PH_COEFFS>(d, stream, timer)
                     : launch<VEC, MODE_ROW, R | E | LP_PH_COEFFS>(d, stream, timer);
     const bool rng_torch = d.rng_kind == LP_RNG_TORCH;
@@ -1180,15 +1181,13 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
             case S | P | E: return LP_HOT(MODE_HARD, S | P | E);   // steady state
             case F | P | E: return LP_HOT(MODE_HARD, F | P | E);   // iteration 0
             case S | E: return LP_HOT(MODE_HARD, S | E);           // last iteration
-            case F | E: return LP_HOT(MODE_HARD, F | E);           // n_steps == 1
-            default: return launch<VEC, MODE_HARD, 0>(d, stream, timer);   // unfused (early stop) etc.
+            default: return launch<VEC, MODE_HARD, 0>(d, stream, timer);   // unfused (early stop), n_steps == 1, etc.
         }
     }
     switch (d.phases) {
         case S | P | E: return LP_HOT(MODE_ROW, S | P | E);
         case F | P | E: return LP_HOT(MODE_ROW, F | P | E);
         case S | E: return LP_HOT(MODE_ROW, S | E);
-        case F | E: return LP_HOT(MODE_ROW, F | E);
         default: return launch<VEC, MODE_ROW, 0>(d, stream, timer);
     }
 #undef LP_HOT
@@ -1260,14 +1259,6 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     const Tune& t = tune();
     const int64_t small = t.small_elems ? t.small_elems : (512 * 1024);
     bool vec4 = can_vec4 && d.n_el > small;
-    if ((d.flags & LP_FL_ES) && can_vec4 && !vec4) {
-        // Early stop: a loop whose table of per-block sums has <= 512 rows takes its verdict inside the next launch
-        // instead of a one-block kernel per iteration (launch()).  One element per lane gets there up to 128 K
-        // elements; 16 B per lane carries it to 512 K (SDXL batch 4: 9.5 -> 5 us per gated iteration).  The rule looks
-        // at the shape only, so the watched (eager) and the gated (captured) loop sum the same blocks: same bits.
-        const int64_t per_row1 = (d.el_per_row + kBlock - 1) / kBlock, per_row4 = (d.el_per_row / 4 + kBlock - 1) / kBlock;
-        if (per_row1 * d.rows > 2 * kBlock && per_row4 * d.rows <= 2 * kBlock) vec4 = true;
-    }
     if (t.vec == 4) vec4 = can_vec4;
     if (t.vec == 1) vec4 = false;
     const hipError_t err = vec4 ? launch_phase<4>(d, stream, timer) : launch_phase<1>(d, stream, timer);

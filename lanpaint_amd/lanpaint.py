@@ -173,9 +173,8 @@ class _DeviceStop:
         raw = torch.frombuffer(bytearray(bytes(init) * 2), dtype=torch.uint8)     # two slots (folded gated loops ping-pong)
         self.state = torch.empty(raw.numel(), dtype=torch.uint8, device=dev)
         self.state.copy_(raw)
-        rows = like.shape[0]
-        blocks = ((like.numel() // rows + 255) // 256) * rows
-        self.partials = torch.empty(2 * blocks * 8, dtype=torch.float32, device=dev)
+        # the accumulator sets the blocks of an early-stop launch add their sums into (LP_ES_ACC_DOUBLES)
+        self.partials = torch.zeros(_cabi.LP_ES_ACC_DOUBLES, dtype=torch.float64, device=dev)
         self.mailbox = torch.zeros(_cabi.LP_ES_TRACE0 + 8 * self.n_cap, dtype=torch.float64).pin_memory()
         self.f64 = self.mailbox.numpy()
         self.i64 = self.mailbox.view(torch.int64).numpy()

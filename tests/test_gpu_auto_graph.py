@@ -22,7 +22,7 @@ def _schedule(eng, seed=321, shape=SHAPE, n_sig=N_SIG):
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     y, noise = tt(g.standard_normal(shape, dtype=np.float32)), tt(g.standard_normal(shape, dtype=np.float32))
     mask = tt(gc.box_mask(shape))
-    sig = gc.karras_sigmas(n_sig + 1)[:-1]
+    sig = gc.karras_sigmas(n_sig)[:-1]
     x = y + noise * float(sig[0])
     torch.manual_seed(seed)
     outs, mo = [], {}

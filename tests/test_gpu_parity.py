@@ -389,11 +389,10 @@ def test_early_stop_inside_a_replayed_graph_equals_the_host_watched_loop(name, r
                          ids=["fold_two_rows_per_thread", "fold_16B_lanes", "vec1_decide_kernel", "vec4_decide_kernel",
                               "fold_batch_rows"])
 def test_early_stop_graph_equals_eager_at_every_launch_geometry(shape):
-    """The gated (captured) loop against the watched (eager) one at the sizes that switch the early-stop machinery:
-    102 400 elements = 400 blocks, the verdict folded into the next launch with TWO rows of block sums per thread;
-    262 144 elements, which an early-stop loop runs at 16 B per lane so that its 256 blocks fit the fold too; 271 803
-    (odd: 4 B per lane, 1 062 blocks) and 589 824 (16 B per lane, 576 blocks), where a one-block kernel decides and a
-    stopped loop takes the emit-only exit; a batch whose rows share the fold.  torch's stream on both sides, so:
+    """The gated (captured) loop against the watched (eager) one across launch geometries: 102 400 elements = 400 blocks,
+    262 144 = 1 024 blocks at 4 B per lane, 271 803 (odd: 1 062 blocks), 589 824 (16 B per lane, 576 blocks), a batch of rows.
+    Every block adds its sums into the iteration's 64-slot accumulator set; the gated loop applies the verdict at the top
+    of its next launch at any of these sizes, the watched one in a one-wave kernel.  torch's stream on both sides, so:
     the same iteration count, the same trace, bitwise the same x / out over replays that stop on different iterations."""
     import torch
     from lanpaint_amd import LanPaint, pack_mask
@@ -428,7 +427,7 @@ def test_early_stop_graph_equals_eager_at_every_launch_geometry(shape):
             assert eng._graphs and all(c.es is not None for c in eng._graphs.values())
     for e, g in zip(res[False], res[True]):
         assert e[2] == g[2] and e[3] == g[3]
-        np.testing.assert_allclose(e[4], g[4], rtol=1e-12)
+        np.testing.assert_allclose(e[4], g[4], rtol=1e-6)      # (double accumulators filled by atomics: order-exact to ~1e-16)
         np.testing.assert_array_equal(e[0], g[0])
         np.testing.assert_array_equal(e[1], g[1])
     ran = [r[2] for r in res[True]]
@@ -914,3 +913,114 @@ def test_in_kernel_torch_stream_on_the_general_paths(name):
         res.append((r["x"], r["out"], torch.cuda.default_generators[0].get_offset(), r["engine"].iterations_run))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+
+
+# ------------------------------------------------------------------ every instantiation the library holds is launched
+# (scripts/instantiation_coverage.py; tests/test_cabi_exports.py checks the committed coverage file against the library)
+@pytest.mark.parametrize("shape", [(2, 4, 24, 20), (2, 4, 258, 262), (1, 4, 521, 301), (2, 4, 520, 520), (1, 4, 384, 384)],
+                         ids=["vec1", "vec4", "strided", "strided_rows", "vec4_one_row"])
+@pytest.mark.parametrize("mask_fmt", ["f32", "bits"])
+@pytest.mark.parametrize("heads", ["f32", "bf16"])
+def test_torch_stream_variants_with_half_heads_and_either_mask_format(shape, mask_fmt, heads):
+    """The in-kernel torch stream (RNG = 1) against explicit torch.randn_like tensors for the storage formats production
+    uses together with it: bf16 backbone heads (X0W = 2) and fp32 / bit-packed masks (MODE 0 / 2), one element and four per
+    lane, ATen-strided lanes and not -- bitwise the same x / out, same generator offset."""
+    import torch
+    import lanpaint_amd
+    from lanpaint_amd import LanPaint
+    dtype = torch.bfloat16 if heads == "bf16" else torch.float32
+
+    class Net:
+        def __init__(self):
+            self.inner_model = self
+            self.model_sampling = MODELS["linear_tuple"](flow=False).inner_model.model_sampling
+
+        def __call__(self, x, t, model_options=None, seed=None):
+            return (0.9 * x + 0.05).to(dtype), (0.7 * x - 0.02).to(dtype)
+
+    torch.manual_seed(0)
+    y = torch.randn(shape, device="cuda")
+    noise = torch.randn(shape, device="cuda")
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    sig = torch.tensor([1.2, 0.8], device="cuda")[:shape[0]]
+    abt = 1 / (1 + sig ** 2)
+    times = (sig.clone(), abt, torch.sqrt(1 - abt) / (torch.sqrt(1 - abt) + torch.sqrt(abt)))
+    res = {}
+    for rng in ("torch-eager", "torch"):
+        eng = LanPaint(Net(), 3, 15.0, 5.0, 1.0, 0.2, rng=rng, graph=False)
+        torch.manual_seed(5)
+        m = lanpaint_amd.pack_mask(mask.clone()) if mask_fmt == "bits" else mask
+        x = (y + noise * 1.2).clone()
+        out = eng(x, y, noise, sig, m, times, {}, 0)
+        res[rng] = (x, out, torch.cuda.default_generators[0].get_offset())
+    a, b = res["torch-eager"], res["torch"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+
+
+@pytest.mark.parametrize("rng", ["torch", "philox"])
+@pytest.mark.parametrize("mask_fmt", ["bits", "f32"])
+def test_early_stop_on_a_streaming_size_latent_in_both_loop_forms(rng, mask_fmt):
+    """The inner early stop at 16 B per lane (589 824 elements), watched (eager) and gated (replayed), with either
+    generator and either mask format: with torch's stream the two loop forms agree bit for bit; Philox streams differ
+    between the forms by construction, there both must run, stop (or not) on a sensible iteration and stay finite."""
+    import torch
+    from lanpaint_amd import LanPaint, pack_mask
+    shape, n = (1, 4, 384, 384), 6
+    g = np.random.default_rng(9)
+    y = g.standard_normal(shape, dtype=np.float32)
+    noise = g.standard_normal(shape, dtype=np.float32)
+    mask = np.ones(shape, dtype=np.float32)
+    mask[..., 96:288, 96:288] = 0.0
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")   # noqa: E731
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(41)
+        eng = LanPaint(MODELS["linear_tuple"](), n, 15.0, 5.0, 1.0, 0.2, rng=rng, philox_seed=3, graph=graph)
+        yg, ng = tt(y), tt(noise)
+        mg = pack_mask(tt(mask)) if mask_fmt == "bits" else tt(mask)
+        runs = []
+        for sg, thr in [(1.0, 0.3), (1.0, 1e-9), (1.4, 0.45)]:
+            sigma = np.full((1,), sg, dtype=np.float32)
+            times = tuple(tt(t) for t in gc.times_from_sigma(sigma, False))
+            mo = {"lanpaint_semantic_stop": {"threshold": thr, "patience": 1}, "lanpaint_semantic_trace": []}
+            x = tt(y + noise * np.float32(sg))
+            it0 = eng.iterations_run
+            out = eng(x, yg, ng, tt(sigma), mg, times, mo, 0)
+            runs.append((x.cpu().numpy(), out.cpu().numpy(), eng.iterations_run - it0,
+                         [t["dist"] for t in mo["lanpaint_semantic_trace"]]))
+        res[graph] = runs
+    for e, gr in zip(res[False], res[True]):
+        assert np.isfinite(e[0]).all() and np.isfinite(gr[0]).all() and 1 <= e[2] <= n and 1 <= gr[2] <= n
+        if rng == "torch":
+            assert e[2] == gr[2]
+            np.testing.assert_allclose(e[3], gr[3], rtol=1e-6)
+            np.testing.assert_array_equal(e[0], gr[0])
+            np.testing.assert_array_equal(e[1], gr[1])
+    assert res[False][1][2] == n and res[True][1][2] == n          # the 1e-9 threshold never stops
+    assert res[True][0][2] < n                                     # 0.3 does
+
+
+def test_per_element_times_on_a_streaming_size_pack():
+    """Per-element times (MiniMax-H3 style AV pack, lanpaint.py:60-74) on a pack large enough for 16 B per lane: in-kernel
+    torch stream against explicit randn_like tensors, bitwise."""
+    import torch
+    from lanpaint_amd import LanPaint
+    shape = (1, 1, 655360)
+    torch.manual_seed(1)
+    y = torch.randn(shape, device="cuda")
+    noise = torch.randn(shape, device="cuda")
+    mask = (torch.rand(shape, device="cuda") < 0.5).float()
+    ai = torch.zeros(shape, device="cuda")
+    ai[..., 400000:] = 1.0
+    flow_t, flow_a = torch.tensor([0.6], device="cuda"), torch.tensor([0.35], device="cuda")
+    tm = lambda t: (t / (1 - t), (1 - t) ** 2 / ((1 - t) ** 2 + t ** 2), t)      # noqa: E731
+    res = []
+    for rng in ("torch-eager", "torch"):
+        torch.manual_seed(8)
+        eng = LanPaint(MODELS["linear_tuple"](flow=True), 3, 15.0, 5.0, 1.0, 0.2, IS_FLOW=True, rng=rng, graph=False)
+        x = (0.6 * noise + 0.4 * y).clone()
+        out = eng(x, y, noise, flow_t, mask, tm(flow_t), {}, 0, current_times_audio=tm(flow_a), audio_indicator=ai,
+                  audio_correction=(1.0 - ai) + 0.8 * ai)
+        res.append((x, out, torch.cuda.default_generators[0].get_offset()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    assert torch.isfinite(res[0][0]).all()
