@@ -289,7 +289,9 @@ typedef struct lp_final_desc {
     float*       out;          /* out*(1-m) + y*m (lanpaint.py:154)                       */
     uint64_t*    rng_bump_ptr; /* optional: *ptr += rng_bump after the launch (graph replay) */
     uint64_t     rng_bump;
-    const uint64_t* io_table;  /* optional device u64[2] (a finalize captured in a hipGraph): x_dst and out are
+    const uint64_t* io_table;  /* optional device u64[2] (a finalize captured in a hipGraph; BOTH published addresses must
+                                  be 16-byte aligned -- the launch is laid out for 16 B per lane before it can see
+                                  them): x_dst and out are
                                   read from io_table[0] / io_table[1] on the device, as the replace launch of the
                                   same sigma call published them (lp_step_desc.io_table_out); the x_dst / out
                                   fields are then ignored.  A zero address in slot 0 skips the write-back.      */
@@ -391,7 +393,7 @@ int lp_step(const lp_step_desc* desc, void* stream);
  * caller-owned handle; lp_timer_elapsed_ns blocks until that launch has finished.     */
 int lp_timer_create(void** timer);
 int lp_timer_destroy(void* timer);
-int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);
+int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);   /* LP_E_UNSUPPORTED for LP_FL_ES launches */
 /* n timed launches of the same descriptor from one host call (rng_offset + i per launch), so the GPU stays
  * busy between them: launched one by one through an FFI the host paces a ~10 us kernel and every dispatch
  * starts on an idle chip (measured 13.0 us instead of the 10.5 us rocprofv3 reports for the same kernel). */

@@ -1238,6 +1238,7 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if ((ph & LP_PH_EMIT) && !d.x_in) return LP_E_INVALID;
     if (d.es_reset && !d.es) return LP_E_INVALID;
     if (d.flags & LP_FL_ES) {
+        if (timer) return LP_E_UNSUPPORTED;      // an early-stop launch may be two kernels: no single event pair describes it
         if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
         if (!d.es_x0s[0] || !d.es_x0s[1] || !d.es_x0s[2]) return LP_E_INVALID;
         if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator

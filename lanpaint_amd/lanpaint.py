@@ -1473,6 +1473,23 @@ class LanPaint:
             self._es_trace(es, ds, i)
             if ds.f64[2] != 0.0:                      # stopped
                 break
+            if i == 0 and ds.f64[3] == 0.0 and not last:
+                # The stopper can never fire in this call (threshold_eff <= 0 at this abt, or nothing to inpaint:
+                # earlystop.py:111-117 -- the reference's from_options returns None and runs its plain loop).  Do the same:
+                # no more verdicts to wait for, no early-stop streams, one fused launch per iteration from here on.
+                d.phases, d.flags = LP_PH_PRE_HALF | LP_PH_EMIT, base_flags | self._emit(st, False)
+                self._set_xi(d, ws.x_t, want_pre=True, want_post=False)
+                self._launch_step(stream)
+                for j in range(1, n_steps):
+                    last_j = j == n_steps - 1
+                    output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
+                    alive = self._set_model_output(d, output, base_flags | self._emit(st, last_j), shape)
+                    d.phases = LP_PH_POST_STEADY | (0 if last_j else LP_PH_PRE_HALF) | LP_PH_EMIT
+                    self._set_xi(d, ws.x_t, want_pre=not last_j)
+                    self._launch_step(stream)
+                    del alive
+                ds.seen_total += 1                # (the device counted iteration 0 only)
+                return n_steps
         if not gated:
             ds.seen_total += ran                  # this loop's iterations are accounted by its caller
             d.phases, d.flags = LP_PH_EMIT, base_flags | self._emit(st, True)

@@ -119,3 +119,24 @@ def test_profiling_variant_builds_and_keeps_the_abi(tmp_path):
     assert lib.lp_abi_version() == _cabi.ABI_VERSION
     for n in _declared_functions():
         assert hasattr(lib, n)
+
+
+def test_every_step_kernel_instantiation_is_launched_by_a_gpu_test(hip_lib):
+    """lp_step_kernel is one template with seven parameters; the library must hold exactly the instantiations the committed
+    coverage file lists, and the GPU suite must have launched every one of them (profiles/r*_instantiation_coverage.json,
+    written by scripts/instantiation_coverage.py from a run of the suite against the coverage build).  Adding an
+    instantiation without a test that reaches it -- or leaving one behind that nothing launches -- fails here."""
+    import glob
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import instantiation_coverage as ic
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_instantiation_coverage.json")))
+    assert files, "no committed instantiation coverage (scripts/instantiation_coverage.py)"
+    cov = json.load(open(files[-1]))
+    have = ic.product_instantiations(_cabi.LIB_PATH)
+    listed = {i["args"] for i in cov["instantiations"]}
+    assert have == listed, f"library vs coverage file: only in library {sorted(have - listed)}, only in file {sorted(listed - have)}"
+    assert cov["never_launched"] == [], cov["never_launched"]
+    assert set(cov["launched_by_gpu_tests"]) == have
+    assert len(have) <= 100, "the instantiation set grew past what round 3 pruned it to; prune or justify"

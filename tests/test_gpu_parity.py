@@ -1024,3 +1024,31 @@ def test_per_element_times_on_a_streaming_size_pack():
         res.append((x, out, torch.cuda.default_generators[0].get_offset()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
     assert torch.isfinite(res[0][0]).all()
+
+
+def test_armed_early_stop_that_can_never_fire_runs_the_plain_loop():
+    """Nothing to inpaint (mask all known): the reference's LanPaintEarlyStopper.from_options returns None
+    (earlystop.py:115-117) and the plain loop runs.  The watched loop learns the same from the first verdict (enabled = 0)
+    and goes on with the plain fused launches: same draws, same result as an engine without the stopper, full count."""
+    import torch
+    from lanpaint_amd import LanPaint
+    shape, n = (1, 4, 24, 24), 5
+    g = np.random.default_rng(5)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")   # noqa: E731
+    y, noise = tt(g.standard_normal(shape, dtype=np.float32)), tt(g.standard_normal(shape, dtype=np.float32))
+    mask = torch.ones(shape, device="cuda")
+    s = torch.full((1,), 1.1, device="cuda")
+    times = gc.times_from_sigma(s, False)
+    res = []
+    for thr in (0.0, 0.3):
+        torch.manual_seed(12)
+        m = MODELS["linear_tuple"]()
+        eng = LanPaint(m, n, 15.0, 5.0, 1.0, 0.2, EarlyStopThreshold=thr, EarlyStopPatience=1, rng="torch", graph=False)
+        x = (y + noise * 1.1).clone()
+        mo = {"lanpaint_semantic_trace": []}
+        out = eng(x, y, noise, s, mask, times, mo, 0)
+        torch.cuda.synchronize()
+        res.append((x.clone(), out.clone(), eng.iterations_run, m.calls, torch.cuda.default_generators[0].get_offset(),
+                    len(mo["lanpaint_semantic_trace"])))
+    assert res[0][2:] == res[1][2:] == (n, n + 1, res[0][4], 0)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
