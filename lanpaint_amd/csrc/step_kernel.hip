@@ -436,11 +436,14 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
 #pragma unroll
             for (int k = 0; k < 8; ++k) es_words[k] = sv[k];
             es_keeper = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
-            // lane l of every wave: slot l of the previous iteration's accumulator set (48 B; the whole set is 3 KB and
-            // sits in L2 after the first wave of an XCD has touched it)
-            const double* src = es_acc_set(d, d.es_index - 1) + static_cast<size_t>(threadIdx.x & (kWave - 1)) * 8;
+            // lane l of the block's FIRST wave: slot l of the previous iteration's accumulator set (48 B); the other three
+            // waves get the totals through LDS (a launch of 4 096 waves each reading the 3 KB set moved more bytes out of
+            // L2 than the SDXL-batch operands themselves)
+            if (threadIdx.x < kWave) {
+                const double* src = es_acc_set(d, d.es_index - 1) + static_cast<size_t>(threadIdx.x) * 8;
 #pragma unroll
-            for (int k = 0; k < kEsSums; ++k) es_fv[k] = src[k];
+                for (int k = 0; k < kEsSums; ++k) es_fv[k] = src[k];
+            }
         } else {                                     // wave-uniform scalar loads of the device-side stop state
             es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot;
             if (es_gated && d.es->stopped != 0) {    // the loop has stopped: only re-emit x_in from the committed x_t
@@ -698,9 +701,19 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                     es_lite.threshold_eff = __longlong_as_double(static_cast<long long>(u64(12)));
                     es_lite.abt_val = __longlong_as_double(static_cast<long long>(u64(14)));
                 }
-                if (it > 0 && es_lite.stopped == 0) {
+                if (it > 0 && es_lite.stopped == 0) {        // (block-uniform: every wave takes the barrier)
+                    __shared__ float fold_tot[kEsSums];
                     float tot[kEsSums];
-                    es_slot_total(es_fv, tot);
+                    if (threadIdx.x < kWave) {
+                        es_slot_total(es_fv, tot);
+                        if (threadIdx.x == 0) {
+#pragma unroll
+                            for (int k = 0; k < kEsSums; ++k) fold_tot[k] = tot[k];
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < kEsSums; ++k) tot[k] = fold_tot[k];
                     const bool hp = es_lite.cur_slot >= 0, ha = es_lite.anchor_slot >= 0;
                     es_decide(d, es_lite, tot, hp, ha, it - 1, es_keeper);
                 }
@@ -1118,9 +1131,17 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
         // after the launch.  (The folded kernel is its own instantiation: its extra live state would cost the plain
         // early-stop launch registers it does not need.)
         const bool fold = (d.flags & LP_FL_ES_GATED) && !t.es_no_fold;
-        LP_TRACE(fold ? 2 : 1);
-        if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
-        else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+        if constexpr (PH != 0) {
+            // the phase-specialised early-stop kernels exist in their folded form only (the launches a replayed loop
+            // repeats); a fused-phase launch that is not folded (a tuning switch) takes the run-time-phase kernel
+            if (!fold) return launch<VEC, MODE, 0, 0, 2, false, 1>(d, stream, timer);
+            LP_TRACE(2);
+            hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+        } else {
+            LP_TRACE(fold ? 2 : 1);
+            if (fold) hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 2>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+            else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+        }
         const bool close = fold && (d.flags & LP_FL_ES_CLOSE) && d.es_index + 1 == d.es_n_steps;
         if ((d.phases & kPost) && !t.es_no_decide && !close && (!fold || d.es_index + 1 == d.es_n_steps)) {
             if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
