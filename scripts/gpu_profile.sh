@@ -24,12 +24,22 @@ summ /tmp/p_c5b/t_results.db > $OUT/c5_bench_kernel_trace.md 2>&1
 LANPAINT_AMD_NO_REGION_SKIP=1 rocprofv3 --kernel-trace --stats -d /tmp/p_xnoskip -o t -- python $R/scripts/microbench_step.py x_wan_b16 steady 50 > $OUT/xwanb16_noskip_microbench_under_rocprof.log 2>&1
 summ /tmp/p_xnoskip/t_results.db > $OUT/xwanb16_noskip_kernel_trace.md 2>&1
 
+# bf16 heads in / bf16 x_in out (30 B / element): the production storage widths at the two bandwidth-bound shapes
+for wl in c5_wan:c5_bf16 x_wan_b16:xwanb16_bf16; do
+  LANPAINT_AMD_BENCH_DTYPE=bf16 rocprofv3 --kernel-trace --stats -d /tmp/p_${wl#*:} -o t -- python $R/scripts/microbench_step.py ${wl%%:*} steady 50 > $OUT/${wl#*:}_microbench_under_rocprof.log 2>&1
+  summ /tmp/p_${wl#*:}/t_results.db > $OUT/${wl#*:}_kernel_trace.md 2>&1
+done
+
 # ---- HBM-side traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), no other trace domain ----------
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr -d /tmp/p_pmc_c2_$ctr -o t -- python $R/bench.py --steps 2 --warmup 1 --repeats 0 --graph 0 --no-cpu-baseline --no-large-shape --extras 0 > $OUT/c2_pmc_$ctr.log 2>&1
   summ /tmp/p_pmc_c2_$ctr/t_results.db --pmc 2>&1 | grep -A200 "counter | dispatches" | grep -i "lp::\|counter" > $OUT/c2_pmc_$ctr.md
   for wl in c1:c1_sd15 c3:c3_sdxl_b4 c4:c4_flux c5:c5_wan xwanb16:x_wan_b16; do
     rocprofv3 --kernel-trace --pmc $ctr -d /tmp/p_pmc_${wl%%:*}_$ctr -o t -- python $R/scripts/microbench_step.py ${wl#*:} steady 20 > $OUT/${wl%%:*}_pmc_$ctr.log 2>&1
+    summ /tmp/p_pmc_${wl%%:*}_$ctr/t_results.db --pmc 2>&1 | grep -A200 "counter | dispatches" | grep -i "lp::\|counter\|Mul" > $OUT/${wl%%:*}_pmc_$ctr.md
+  done
+  for wl in c5_bf16:c5_wan xwanb16_bf16:x_wan_b16; do
+    LANPAINT_AMD_BENCH_DTYPE=bf16 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/p_pmc_${wl%%:*}_$ctr -o t -- python $R/scripts/microbench_step.py ${wl#*:} steady 20 > $OUT/${wl%%:*}_pmc_$ctr.log 2>&1
     summ /tmp/p_pmc_${wl%%:*}_$ctr/t_results.db --pmc 2>&1 | grep -A200 "counter | dispatches" | grep -i "lp::\|counter\|Mul" > $OUT/${wl%%:*}_pmc_$ctr.md
   done
   LANPAINT_AMD_NO_REGION_SKIP=1 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/p_pmc_xnoskip_$ctr -o t -- python $R/scripts/microbench_step.py x_wan_b16 steady 20 > $OUT/xwanb16_noskip_pmc_$ctr.log 2>&1

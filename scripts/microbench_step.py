@@ -4,7 +4,8 @@ combination captured in a hipGraph, replayed; reports us per launch (kernel + th
 launch boundary) for the current LANPAINT_AMD_TUNE_* environment.
 
     python scripts/microbench_step.py c2_sdxl [steady|first|last|replace] [reps] [philox|torch] [box|temporal|blob]
-(LANPAINT_AMD_NO_REGION_SKIP=1 streams every operand regardless of the mask.)
+(LANPAINT_AMD_NO_REGION_SKIP=1 streams every operand regardless of the mask; LANPAINT_AMD_BENCH_DTYPE=bf16: the two heads
+arrive and x_in leaves as bf16, 30 algorithmic bytes per element.)
 """
 import ctypes
 import os
@@ -30,7 +31,8 @@ def main():
     dev = torch.device("cuda", 0)
     lib = _cabi.load()
     bench.MASK_KIND = sys.argv[5] if len(sys.argv) > 5 else None
-    d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase])
+    half = os.environ.get("LANPAINT_AMD_BENCH_DTYPE") == "bf16"
+    d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase], model_dtype=torch.bfloat16 if half else None)
     bufs = keep[0]
     rng = sys.argv[4] if len(sys.argv) > 4 else "philox"
     if rng == "torch":                          # the device generator's randn stream reproduced in-kernel
@@ -75,10 +77,10 @@ def main():
         g2.replay()
     torch.cuda.synchronize()
     us_mul = (time.perf_counter() - t0) / (n_rep * reps) * 1e6
-    bytes_ = {"steady": 36, "first": 32, "last": 36, "replace": 24}[phase] * n_el
+    bytes_ = ({"steady": 36, "first": 32, "last": 36, "replace": 24}[phase] - (6 if half and phase != "replace" else 0)) * n_el
     env = {k: v for k, v in os.environ.items() if k.startswith("LANPAINT_AMD_TUNE")}
     print(f"{wl} {phase} n_el={n_el} us/launch={us:.3f} ({bytes_ / us / 1e3:.0f} GB/s algorithmic) "
-          f"rng={rng} mask={bench.MASK_KIND or 'default'} region_skip={0 if os.environ.get('LANPAINT_AMD_NO_REGION_SKIP') else 1} torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
+          f"heads={'bf16' if half else 'fp32'} rng={rng} mask={bench.MASK_KIND or 'default'} region_skip={0 if os.environ.get('LANPAINT_AMD_NO_REGION_SKIP') else 1} torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
 
 
 if __name__ == "__main__":
