@@ -121,6 +121,27 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(writer, dim3(1), dim3(64), 0, s, buf + (i & 63), i, d);
         CK(hipGraphLaunch(e_out, s));
     });
+    // ---- C: is the fixed cost of a graph launch tied to re-launching the SAME exec?  Alternate two / four instances of the
+    // same graph; and a graph launched every time on a freshly alternating pair of streams is NOT what a sigma call can do
+    // (stream order is needed), so only the exec is varied.
+    {
+        hipGraphExec_t ex[4];
+        for (int k = 0; k < 4; ++k) CK(hipGraphInstantiate(&ex[k], g_out, nullptr, nullptr, 0));
+        timeit("graph only, 2 exec instances alternating", [&](int i) { CK(hipGraphLaunch(ex[i & 1], s)); });
+        timeit("graph only, 4 exec instances rotating", [&](int i) { CK(hipGraphLaunch(ex[i & 3], s)); });
+        timeit("eager chain + graph, 2 execs alternating", [&](int i) {
+            hipLaunchKernelGGL(chain, dim3(n_el / 256), dim3(256), 0, s, data, n_el);
+            CK(hipGraphLaunch(ex[i & 1], s));
+        });
+        timeit("eager chain + graph, same exec", [&](int i) {
+            hipLaunchKernelGGL(chain, dim3(n_el / 256), dim3(256), 0, s, data, n_el);
+            CK(hipGraphLaunch(e_out, s));
+        });
+    }
+    // ---- D: the same 12 kernels launched eagerly from this C loop (no graph at all)
+    timeit("12 eager chain launches (no graph)", [&](int) {
+        for (int k = 0; k < n_chain; ++k) hipLaunchKernelGGL(chain, dim3(n_el / 256), dim3(256), 0, s, data, n_el);
+    });
     std::printf("done\n");
     return 0;
 }
