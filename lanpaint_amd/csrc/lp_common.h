@@ -217,6 +217,7 @@ template <int V>
 struct Raw {
     uint32_t w[V];
 };
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 
 template <int V>
 __device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, int64_t i, Raw<V>& r) {
@@ -227,8 +228,8 @@ __device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, int
         for (int k = 0; k < V; ++k) r.w[k] = __float_as_uint(t[k]);
     } else {
         const uint16_t* q = static_cast<const uint16_t*>(p) + i;
-        if constexpr (V == 4) {
-            const uint2 t = *reinterpret_cast<const uint2*>(q);
+        if constexpr (V == 4) {      // streaming data like the fp32 path: non-temporal (round 3; bf16 heads past L3)
+            const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2*>(q));
             r.w[0] = t.x; r.w[1] = t.y;
         } else {
 #pragma unroll
@@ -315,7 +316,9 @@ __device__ __forceinline__ void store_any(void* __restrict__ p, int dt, int64_t 
         for (int k = 0; k < V; ++k) h[k] = (dt == DT_BF16) ? f32_to_bf16(v[k]) : f32_to_f16(v[k]);
         uint16_t* q = static_cast<uint16_t*>(p) + i;
         if constexpr (V == 4) {
-            *reinterpret_cast<uint2*>(q) = make_uint2(h[0] | (uint32_t(h[1]) << 16), h[2] | (uint32_t(h[3]) << 16));
+            u2 t;
+            t.x = h[0] | (uint32_t(h[1]) << 16); t.y = h[2] | (uint32_t(h[3]) << 16);
+            __builtin_nontemporal_store(t, reinterpret_cast<u2*>(q));
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) q[k] = h[k];

@@ -605,10 +605,25 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         if ((ph & LP_PH_PRE_HALF) && host_pre) load_f32<VEC>(d.xi_pre, i, xi_b);
         // early stop: the previous x0s, the drift anchor and the ring weight the metric compares against
         float x0p[VEC], anc[VEC], rg[VEC], xi_r[VEC], xt0[VEC], es_b0[VEC], es_b1[VEC], es_b2[VEC];
+        int es_dep_w = 0, es_dep_a = -1;
         const bool es_redo = ES && es_gated && (ph & LP_PH_POST_STEADY);    // redo the tentative half-step of the last launch
         if constexpr (ES) {
             if (post) {
-                if constexpr (es_fold) {      // which two of the three buffers the metric compares against is part of the pending verdict
+                if constexpr (es_fold && VEC == 4) {
+                    // Streaming sizes: bytes count, one more dependent round trip does not.  The state this launch loaded is
+                    // the one BEFORE the pending verdict, and it already fixes what the verdict can select: the previous
+                    // x0s is the buffer the last iteration wrote (its write_slot), the drift anchor afterwards is either
+                    // the old anchor, that same buffer, or none.  So one history read, two while an anchor is held --
+                    // not three (C5: 52 -> 44 B per element; profiles/r03_microbench_es.log).
+                    es_dep_w = __builtin_amdgcn_readfirstlane(static_cast<int>(es_words[2].y));      // write_slot
+                    es_dep_a = __builtin_amdgcn_readfirstlane(static_cast<int>(es_words[2].x));      // anchor_slot
+                    if (d.es_index > 0) {
+                        load_f32<VEC>(es_dep_w == 0 ? d.es_x0s[0] : es_dep_w == 1 ? d.es_x0s[1] : d.es_x0s[2], i, es_b0);
+                        if (es_dep_a >= 0 && es_dep_a != es_dep_w)
+                            load_f32<VEC>(es_dep_a == 0 ? d.es_x0s[0] : es_dep_a == 1 ? d.es_x0s[1] : d.es_x0s[2], i, es_b1);
+                    }
+                } else if constexpr (es_fold) {      // latency-bound sizes: which two of the three buffers the metric compares
+                                                     // against is part of the pending verdict -- read all three, select later
                     load_f32<VEC>(d.es_x0s[0], i, es_b0);
                     load_f32<VEC>(d.es_x0s[1], i, es_b1);
                     load_f32<VEC>(d.es_x0s[2], i, es_b2);
@@ -741,10 +756,18 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 es_prev = es_lite.cur_slot; es_anchor = es_lite.anchor_slot; es_write = es_lite.write_slot;
                 es_idle = es_lite.stopped != 0;      // stopped: only re-emit x_in from the committed x_t (stores below)
                 if (post) {
+                    if constexpr (VEC == 4) {       // es_b0 = the buffer the last iteration wrote (= es_prev), es_b1 = the old anchor
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        x0p[k] = es_prev == 0 ? es_b0[k] : es_prev == 1 ? es_b1[k] : es_b2[k];
-                        anc[k] = es_anchor == 0 ? es_b0[k] : es_anchor == 1 ? es_b1[k] : es_b2[k];
+                        for (int k = 0; k < VEC; ++k) {
+                            x0p[k] = es_b0[k];
+                            anc[k] = es_anchor == es_dep_w ? es_b0[k] : es_b1[k];
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            x0p[k] = es_prev == 0 ? es_b0[k] : es_prev == 1 ? es_b1[k] : es_b2[k];
+                            anc[k] = es_anchor == 0 ? es_b0[k] : es_anchor == 1 ? es_b1[k] : es_b2[k];
+                        }
                     }
                 }
             }
