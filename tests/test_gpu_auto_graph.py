@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 SHAPE, N_SIG, N_THINK = (1, 4, 32, 32), 7, 3
 
 
+@pytest.fixture(autouse=True)
+def _no_forced_mode(monkeypatch):
+    """These tests are about the DEFAULT mode: a suite run with LANPAINT_AMD_GRAPH=1 / 0 must not override it here."""
+    monkeypatch.delenv("LANPAINT_AMD_GRAPH", raising=False)
+
+
 def _schedule(eng, seed=321, shape=SHAPE, n_sig=N_SIG):
     import torch
     dev = "cuda"
