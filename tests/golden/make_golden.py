@@ -197,6 +197,38 @@ def run_node_schedule(name):
     return n_eff, len(used)
 
 
+def run_full_schedule(name):
+    """A BASELINE configuration as a whole schedule through the reference engine (the bench's walk: Euler update between
+    sigmas); xi from a numpy seed fed to torch.randn_like; digests of every FULL_SCHEDULE_STRIDE-th denoised + the final x."""
+    sc = gc.build_full_schedule(name)
+    model = MODELS["linear_tuple"](flow=sc["flow"])
+    eng = ref_engine(dict(hyper=sc["hyper"], flow=sc["flow"]), model)
+    x = _t(sc["x"].copy())
+    y, noise, mask = _t(sc["y"]), _t(sc["noise"]), _t(sc["mask"])
+    sig, b = sc["sigmas"], sc["shape"][0]
+    draws, used, orig = gc.seeded_xi_stream(sc["xi_seed"], sc["shape"]), [], torch.randn_like
+
+    def fed(t, *a, **kw):
+        used.append(1)
+        return torch.from_numpy(next(draws)).to(t.dtype)
+    torch.randn_like = fed
+    rec = {}
+    try:
+        for i in range(len(sig)):
+            s = torch.full((b,), float(sig[i]), dtype=torch.float32)
+            den = eng(x, y, noise, s, mask, gc.times_from_sigma(s, sc["flow"]), None, 0)
+            if i % gc.FULL_SCHEDULE_STRIDE == 0 or i == len(sig) - 1:
+                rec.update({f"den{i}_{k}": v for k, v in gc.digest(den.numpy(), sc["xi_seed"] + 10 + i).items()})
+            if i + 1 < len(sig):
+                x = x + (x - den) / float(sig[i]) * float(sig[i + 1] - sig[i])
+    finally:
+        torch.randn_like = orig
+    rec.update({f"x_{k}": v for k, v in gc.digest(x.numpy(), sc["xi_seed"] + 1).items()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), n_draws=np.int64(len(used)), model_calls=np.int64(model.calls),
+                        xi_seed=np.int64(sc["xi_seed"]), shape=np.asarray(sc["shape"], dtype=np.int64), sigmas=sig, **rec)
+    return len(used), model.calls
+
+
 def coefficient_kat():
     """Known answers straight from the reference's own prepare_step_size + OU closed
     form (float64 of its fp32 outputs), for the per-region coefficient table."""
@@ -294,6 +326,9 @@ def main():
         if name in only:
             n_eff, nd = run_node_schedule(name)
             print(f"{name:24s} draws={nd} n_eff={n_eff}")
+    for name in gc.FULL_SCHEDULES:
+        if name in only:
+            print(f"{name:24s} draws, model calls = {run_full_schedule(name)}")
     for name in gc.CASES:
         if only and name not in only:
             continue
@@ -306,6 +341,8 @@ def main():
     for name in gc.NODE_SCHEDULES:
         n_eff, nd = run_node_schedule(name)
         print(f"{name:24s} draws={nd} n_eff={n_eff}")
+    for name in gc.FULL_SCHEDULES:
+        print(f"{name:24s} draws, model calls = {run_full_schedule(name)}")
     coefficient_kat()
     boundary_kat()
     blend_kat()

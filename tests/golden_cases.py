@@ -187,6 +187,38 @@ def build_node_schedule(name):
                 hyper=dict(NODE_DEFAULTS), xi_seed=c["xi_seed"])
 
 
+# BASELINE.json's configurations as WHOLE schedules from the reference engine (engine driven directly, Euler update between
+# sigmas, stub backbone, 50 % box mask, engine defaults): C1 = SD1.5 20 sigmas x 5, C2 = SDXL 30 x 5 (the headline config),
+# C4 = Flux 28 x 10.  Stored as digests of every FULL_SCHEDULE_STRIDE-th denoised and of the final x.
+FULL_SCHEDULES = {
+    "full_c1_sd15":  dict(shape=(1, 4, 64, 64), flow=False, n_sigmas=20, n_think=5, seed=60, xi_seed=4260),
+    "full_c2_sdxl":  dict(shape=(1, 4, 128, 128), flow=False, n_sigmas=30, n_think=5, seed=61, xi_seed=4261),
+    "full_c4_flux":  dict(shape=(1, 16, 64, 64), flow=True, n_sigmas=28, n_think=10, seed=62, xi_seed=4262),
+}
+FULL_SCHEDULE_STRIDE = 5
+
+
+def build_full_schedule(name):
+    c = dict(FULL_SCHEDULES[name])
+    shape, flow = tuple(c["shape"]), c["flow"]
+    sig = (flow_sigmas(c["n_sigmas"]) if flow else karras_sigmas(c["n_sigmas"]))[:-1]        # the bench's schedule: no trailing 0
+    rng = np.random.default_rng(c["seed"])
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    x = (sig[0] * noise + (1 - sig[0]) * y).astype(np.float32) if flow else (y + noise * sig[0]).astype(np.float32)
+    hyper = dict(HYPER_DEFAULT)
+    hyper["NSteps"] = c["n_think"]
+    return dict(name=name, shape=shape, flow=flow, sigmas=sig, x=x, y=y, noise=noise, mask=box_mask(shape), hyper=hyper,
+                xi_seed=c["xi_seed"], n_draws=len(sig) * (2 * c["n_think"] - 1))
+
+
+def seeded_xi_stream(xi_seed, shape):
+    """Endless generator form of `seeded_xi` (a full schedule draws hundreds of tensors: not worth holding at once)."""
+    g = np.random.default_rng(xi_seed)
+    while True:
+        yield g.standard_normal(shape, dtype=np.float32)
+
+
 def karras_sigmas(n, sigma_min=0.0292, sigma_max=14.6146, rho=7.0):
     ramp = np.linspace(0, 1, n, dtype=np.float64)
     min_inv, max_inv = sigma_min ** (1 / rho), sigma_max ** (1 / rho)

@@ -75,6 +75,22 @@ def run_product_case(name, device="cuda", rng="recorded", model_cls=None, sampli
                 golden=g, case=case, model_options=mo)
 
 
+def assert_digest(a, g, prefix, sample_seed, what, rel=2e-5):
+    """Tensor `a` against the digest stored under `prefix` in fixture `g` (golden_cases.digest): the sampled elements and
+    the per-slice sums / sums of squares."""
+    d = gc.digest(a, sample_seed)
+    assert np.array_equal(d["sample_idx"], g[f"{prefix}_sample_idx"]), f"{what}: sample positions"
+    assert_close(d["samples"], g[f"{prefix}_samples"], f"{what}: sampled elements", rel=rel)
+    scale = max(1.0, float(np.abs(g[f"{prefix}_samples"]).max()))
+    n_slice = np.asarray(a).size / g[f"{prefix}_sums"].size
+    # per-element error <= rel * scale, independent roundings: a slice sum moves by ~ sqrt(n) of that; one wrong element
+    # (an index, a mask bit, a row's coefficients) moves it by O(scale)
+    tol = 4.0 * rel * scale * np.sqrt(n_slice)
+    err = float(np.abs(d["sums"] - g[f"{prefix}_sums"]).max())
+    assert err <= tol, f"{what}: slice sums off by {err:.3e} > {tol:.3e}"
+    np.testing.assert_allclose(d["sumsq"], g[f"{prefix}_sumsq"], rtol=20 * rel, err_msg=f"{what}: slice sums of squares")
+
+
 def assert_matches_golden(x, out, g, what, rel=2e-5):
     """The written-back x and the returned out of one engine call against a golden fixture: the full tensors, or -- for
     the full-size digest fixtures (golden_cases.digest) -- the sampled elements and the per-slice sums / sums of squares."""
@@ -83,17 +99,7 @@ def assert_matches_golden(x, out, g, what, rel=2e-5):
         assert_close(out, g["out"], f"{what}: out", rel=rel)
         return
     for tag, a, salt in (("x", x, 1), ("out", out, 2)):
-        d = gc.digest(a, int(g["xi_seed"]) + salt)
-        assert np.array_equal(d["sample_idx"], g[f"{tag}_sample_idx"]), f"{what}: {tag} sample positions"
-        assert_close(d["samples"], g[f"{tag}_samples"], f"{what}: {tag} sampled elements", rel=rel)
-        scale = max(1.0, float(np.abs(g[f"{tag}_samples"]).max()))
-        n_slice = np.asarray(a).size / g[f"{tag}_sums"].size
-        # per-element error <= rel * scale, independent roundings: a slice sum moves by ~ sqrt(n) of that; one wrong element
-        # (an index, a mask bit, a row's coefficients) moves it by O(scale)
-        tol = 4.0 * rel * scale * np.sqrt(n_slice)
-        err = float(np.abs(d["sums"] - g[f"{tag}_sums"]).max())
-        assert err <= tol, f"{what}: {tag} slice sums off by {err:.3e} > {tol:.3e}"
-        np.testing.assert_allclose(d["sumsq"], g[f"{tag}_sumsq"], rtol=20 * rel, err_msg=f"{what}: {tag} slice sums of squares")
+        assert_digest(a, g, tag, int(g["xi_seed"]) + salt, f"{what}: {tag}", rel=rel)
 
 
 def assert_close(a, b, what, rel=2e-5, mse=1e-9):

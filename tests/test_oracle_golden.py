@@ -7,7 +7,7 @@ import pytest
 from oracle.lanpaint_oracle import OracleLanPaint
 from tests import golden_cases as gc
 from oracle import lanpaint_oracle as orc
-from tests.helpers import assert_close, assert_matches_golden, load_golden, run_oracle_case, xi_list
+from tests.helpers import assert_close, assert_digest, assert_matches_golden, load_golden, run_oracle_case, xi_list
 from tests.stubs import MODELS
 
 
@@ -73,6 +73,34 @@ def test_oracle_matches_the_reference_sampler_callable(name):
     assert sum(1 for _ in it) == 0 and model.calls == int(g["model_calls"])
     assert_close(x, g["x_final"], f"{name}: final x", rel=2e-5)
     assert len(set(n_eff)) >= 5 and n_eff[-1] == 0 and max(n_eff) == h["NSteps"]      # the ramp is really exercised
+
+
+@pytest.mark.parametrize("name", sorted(gc.FULL_SCHEDULES))
+def test_oracle_matches_reference_full_baseline_schedule(name):
+    """BASELINE.json's C1 / C2 / C4 as WHOLE schedules (C2 = the headline configuration: SDXL 1x4x128x128, 30 sigmas x 5)
+    run by the unmodified reference engine; the fixture holds digests of every fifth denoised and of the final x."""
+    sc = gc.build_full_schedule(name)
+    g = load_golden(name)
+    it = gc.seeded_xi_stream(int(g["xi_seed"]), sc["shape"])
+    h, flow, sig = sc["hyper"], sc["flow"], sc["sigmas"]
+    model = MODELS["linear_tuple"](flow=flow)
+    drawn = [0]
+
+    def randn(like):
+        drawn[0] += 1
+        return next(it)
+    eng = OracleLanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], is_flow=flow,
+                         min_step_frac=h["MinStepFrac"], randn=randn)
+    x = sc["x"].copy()
+    for i in range(len(sig)):
+        s = np.full((sc["shape"][0],), sig[i], dtype=np.float32)
+        den = eng(x, sc["y"], sc["noise"], s, sc["mask"], gc.times_from_sigma(s, flow), None, 0)
+        if f"den{i}_sums" in g.files:
+            assert_digest(den, g, f"den{i}", int(g["xi_seed"]) + 10 + i, f"{name}: denoised[{i}]", rel=2e-5)
+        if i + 1 < len(sig):
+            x = (x + (x - den) / sig[i] * (sig[i + 1] - sig[i])).astype(np.float32)
+    assert drawn[0] == int(g["n_draws"]) and model.calls == int(g["model_calls"])
+    assert_digest(x, g, "x", int(g["xi_seed"]) + 1, f"{name}: final x", rel=2e-5)
 
 
 def test_oracle_on_torch_backend_matches_numpy():
