@@ -266,6 +266,7 @@ class KSamplerX0Inpaint:
         self._mask_cache = None          # (weakref(denoise_mask), version, latent_mask): binarised once per run
         self._mailbox = None             # pinned host float32[4]: lp_sigma_times writes {step index, mean(1-abt), seq}
         self._seq = 0
+        self._sched = None               # (schedule tensor object, dense copy, data_ptr, numel, len - 1): looked at once per run
         self._times = None               # (rows, device, [two sets of (VE sigma, abt, flow t, buffer)]): the three time
                                          # tensors of a call are views of one buffer, made once (a view costs the host
                                          # ~1.5 us) and used by alternate calls
@@ -314,7 +315,11 @@ class KSamplerX0Inpaint:
                 and self.sigmas.dtype == torch.float32 and self.sigmas.device == sigma.device):
             # one launch: the three time tensors AND the two scalars of the inner-step rule, the latter straight into
             # pinned host memory (lp_sigma_times_mailbox) -- no blocking device->host copy
-            sig_c, sched = sigma.contiguous(), self.sigmas.contiguous()
+            sc = self._sched
+            if sc is None or sc[0] is not self.sigmas:
+                dense = self.sigmas.contiguous()
+                self._sched = sc = (self.sigmas, dense, dense.data_ptr(), dense.numel(), len(self.sigmas) - 1)
+            sig_c = sigma if sigma.is_contiguous() else sigma.contiguous()
             rows = sig_c.shape[0]
             tm = self._times
             if tm is None or tm[0] != rows or tm[1] != sigma.device:
@@ -329,7 +334,7 @@ class KSamplerX0Inpaint:
             VE_Sigma, abt, Flow_t, buf = tm[2][self._seq & 1]
             mb = self._mailbox_views()[0]
             self._seq = fused_seq = (self._seq % 0x7ffffff0) + 1
-            args = (sig_c.data_ptr(), rows, sched.data_ptr(), sched.numel(), int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
+            args = (sig_c.data_ptr(), rows, sc[2], sc[3], int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
                     mb.data_ptr(), mb.data_ptr() + 8, fused_seq, raw_stream(sigma.device))
             if sigma.device.index == torch.cuda.current_device():     # (the context manager costs the host ~2 us)
                 _cabi.check(_cabi.load().lp_sigma_times_mailbox(*args), "lp_sigma_times_mailbox")
@@ -377,7 +382,7 @@ class KSamplerX0Inpaint:
             else:
                 current_step = torch.argmin(torch.abs(self.sigmas - torch.mean(sigma)))
                 step_f, frac = torch.stack([current_step.to(torch.float32), (1.0 - abt).mean().to(torch.float32)]).tolist()
-            total_steps = len(self.sigmas) - 1
+            total_steps = self._sched[4] if (self._sched is not None and self._sched[0] is self.sigmas) else len(self.sigmas) - 1
             n_eff = self.PaintMethod.n_steps
             if total_steps - int(step_f) <= self.LanPaint_early_stop:
                 n_eff = 0
