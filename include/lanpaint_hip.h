@@ -259,7 +259,8 @@ typedef struct lp_step_desc {
     double*      es_partials;    /* device scratch, LP_ES_ACC_DOUBLES doubles: the accumulator sets the blocks of an
                                     LP_FL_ES launch add their six sums into (set = es_index mod LP_ES_ACC_SETS, slot =
                                     block mod LP_ES_ACC_SLOTS).  The es_reset launch clears all of it; launch i clears
-                                    the set of iteration i + 1.                                                     */
+                                    the set of iteration i + 1.  Ordinary (coarse-grained) device memory: the adds are
+                                    hardware fp64 atomics, which fine-grained / host-coherent allocations do not honour */
     double*      es_host;        /* mailbox, LP_ES_MAILBOX_DOUBLES(es_n_steps) doubles                       */
     double       es_threshold;   /* threshold before the abt scaling (earlystop.py:78-81)                    */
     int64_t      es_seq_base;    /* es_reset: sequence base of this call                                     */
