@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 11
+#define LP_ABI_VERSION 12
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -380,6 +380,44 @@ int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int3
  * the per-sigma inner-step rule, nodes.py:286-299: sigma exists only on the device, in stream order).       */
 int lp_sigma_times_mailbox(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
                            float* times_out, float* scalars_out, int32_t* seq_out, int32_t seq, void* stream);
+
+/* The sampler-facing callable's steady state in ONE host call (round 3).  KSamplerX0Inpaint.__call__ (nodes.py:229-315)
+ * has to learn from the device where sigma sits in the schedule before it can fix the inner-step count (nodes.py:286-299).
+ * lp_node_call enqueues lp_sigma_times_mailbox and the replace launch of the call, polls the pinned mailbox for the two
+ * scalars, applies the reference's rule
+ *     n_eff = 0                                   if total_steps - step <= early_stop
+ *           = n_steps                             if min_step_frac <= 0 or frac >= min_step_frac or n_steps <= 0
+ *           = max(0, round_half_even(n_steps * frac / min_step_frac))        otherwise   (Python's round())
+ * and launches the graph the caller captured for that count (`exec_by_count[n_eff]`: everything of the sigma call after
+ * the replace launch).  Three FFI trips and the Python between them become one; the rule is evaluated in double on the
+ * float32 scalars exactly as the Python expression does.  `launched` = 0 when no graph is known for the count (the
+ * caller finishes the call itself; the replace launch is already enqueued).                                    */
+typedef struct lp_node_call_desc {
+    const float*        sigma;          /* device [rows]                                                          */
+    int32_t             rows;
+    int32_t             schedule_len;
+    const float*        schedule;       /* device [schedule_len]: the sampler's sigmas                            */
+    int32_t             is_flow;
+    int32_t             seq;            /* sequence word this call posts                                          */
+    float*              times_out;      /* device [3][rows]                                                       */
+    float*              scalars_out;    /* PINNED HOST float[2]: { step index, mean(1 - abt) }                    */
+    int32_t*            seq_out;        /* PINNED HOST                                                            */
+    const lp_step_desc* replace;        /* the call's replace launch (LP_PH_REPLACE | ...), NULL = none           */
+    int32_t             n_steps;        /* PaintMethod.n_steps (LanPaint_NumSteps)                                */
+    int32_t             early_stop;     /* LanPaint_EarlyStop                                                     */
+    int32_t             total_steps;    /* len(sigmas) - 1                                                        */
+    int32_t             n_counts;       /* entries of exec_by_count                                               */
+    double              min_step_frac;  /* LanPaint_MinStepFrac                                                   */
+    void* const*        exec_by_count;  /* hipGraphExec_t per inner-step count, NULL entries allowed              */
+    int32_t             spin_limit;     /* polls before falling back to hipStreamSynchronize                      */
+    int32_t             n_eff;          /* out                                                                    */
+    int32_t             launched;       /* out: 1 = exec_by_count[n_eff] was launched                             */
+    float               step_f, frac;   /* out: the two scalars as read from the mailbox                          */
+} lp_node_call_desc;
+int lp_node_call(lp_node_call_desc* call, void* stream);
+/* the rule alone (host arithmetic; tests pin it against the reference's min_step_frac_effective_steps table)   */
+int32_t lp_effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps, int32_t early_stop,
+                                 double min_step_frac);
 
 /* K0 / K_first / K2  the fused step (phases select the work).
  * Replaces: lanpaint.py:94-99 (REPLACE), :159-184 + :212-220 (score split + Coef_C),

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -107,6 +107,15 @@ class LpCallDesc(C.Structure):
     ]
 
 
+class LpNodeCallDesc(C.Structure):
+    _fields_ = [("sigma", C.c_void_p), ("rows", C.c_int32), ("schedule_len", C.c_int32), ("schedule", C.c_void_p),
+                ("is_flow", C.c_int32), ("seq", C.c_int32), ("times_out", C.c_void_p), ("scalars_out", C.c_void_p),
+                ("seq_out", C.c_void_p), ("replace", C.POINTER(LpStepDesc)), ("n_steps", C.c_int32),
+                ("early_stop", C.c_int32), ("total_steps", C.c_int32), ("n_counts", C.c_int32),
+                ("min_step_frac", C.c_double), ("exec_by_count", C.POINTER(C.c_void_p)), ("spin_limit", C.c_int32),
+                ("n_eff", C.c_int32), ("launched", C.c_int32), ("step_f", C.c_float), ("frac", C.c_float)]
+
+
 class LpBlendDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
                 ("k", C.c_int32), ("mask_batch", C.c_int32), ("mask_h", C.c_int32), ("mask_w", C.c_int32),
@@ -140,6 +149,8 @@ EXPORTS = {
     "lp_graph_bind_replace": (C.c_int, [C.c_void_p, C.POINTER(LpStepDesc), C.POINTER(LpGraphBinding)]),
     "lp_graph_clone_tail": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "lp_graph_release": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lp_node_call": (C.c_int, [C.POINTER(LpNodeCallDesc), C.c_void_p]),
+    "lp_effective_inner_steps": (C.c_int32, [C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double]),
     "lp_pack_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_reshape_mask": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]),
 }

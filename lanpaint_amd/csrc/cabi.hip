@@ -1,6 +1,8 @@
 // cabi.hip -- extern "C" surface of liblanpaint_hip.so (declared in include/lanpaint_hip.h).
 // Plain pointers and sizes in, int status out; nothing is allocated, no global state,
 // every launch goes to the caller's stream and nothing here synchronises.
+#include <cmath>
+
 #include "lp_common.h"
 
 namespace lp {
@@ -155,6 +157,46 @@ int lp_graph_clone_tail(void* graph, void** tail_graph_out, void** tail_exec_out
 int lp_graph_release(void* tail_graph, void* tail_exec) {
     if (tail_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(tail_exec));
     if (tail_graph) (void)hipGraphDestroy(static_cast<hipGraph_t>(tail_graph));
+    return LP_OK;
+}
+
+int32_t lp_effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps, int32_t early_stop,
+                                 double min_step_frac) {
+    // nodes.py:286-299 + :134-144, as Python evaluates it: int(step) compare, then doubles and round-half-even
+    if (total_steps - static_cast<int32_t>(step_f) <= early_stop) return 0;
+    const double f = frac;
+    if (min_step_frac <= 0.0 || f >= min_step_frac || n_steps <= 0) return n_steps;
+    const double r = std::nearbyint(static_cast<double>(n_steps) * f / min_step_frac);     // FE_TONEAREST: ties to even
+    return r > 0.0 ? static_cast<int32_t>(r) : 0;
+}
+
+int lp_node_call(lp_node_call_desc* c, void* stream) {
+    if (!c || !c->sigma || !c->schedule || !c->times_out || !c->scalars_out || !c->seq_out || c->rows <= 0) return LP_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    int rc = lp::sigma_times_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
+                                      c->scalars_out, c->seq_out, c->seq, s);
+    if (rc != LP_OK) return rc;
+    if (c->replace) {                        // the part of the call that does not depend on the answer: queued before the wait
+        rc = lp::step_dispatch(c->replace, s, nullptr);
+        if (rc != LP_OK) return rc;
+    }
+    const int32_t want = c->seq;
+    bool seen = false;
+    for (int32_t k = 0; k < c->spin_limit; ++k) {
+        if (__atomic_load_n(c->seq_out, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+    }
+    if (!seen) {                             // a long backlog in front of the kernel: sleep on the stream instead of spinning
+        if (hipStreamSynchronize(s) != hipSuccess) return LP_E_LAUNCH;
+        if (__atomic_load_n(c->seq_out, __ATOMIC_ACQUIRE) != want) return LP_E_LAUNCH;
+    }
+    c->step_f = c->scalars_out[0];
+    c->frac = c->scalars_out[1];
+    c->n_eff = lp_effective_inner_steps(c->n_steps, static_cast<double>(c->step_f), static_cast<double>(c->frac), c->total_steps, c->early_stop, c->min_step_frac);
+    c->launched = 0;
+    if (c->exec_by_count && c->n_eff >= 0 && c->n_eff < c->n_counts && c->exec_by_count[c->n_eff]) {
+        if (hipGraphLaunch(static_cast<hipGraphExec_t>(c->exec_by_count[c->n_eff]), s) != hipSuccess) return LP_E_LAUNCH;
+        c->launched = 1;
+    }
     return LP_OK;
 }
 

@@ -250,6 +250,7 @@ class _CapturedCall:
         self.alive = True             # still in the engine's graph table
         self.siblings = {}            # n_steps -> the capture of the same call shape for that count (finish_call)
         self.times_seen = ()          # the (VE sigma, abt, flow t) tuples that passed the identity pre-check
+        self.node_table = None        # (exec array by inner-step count, captures, -, graphs seen, options): lp_node_call's table
         self.binding = None           # lp_graph_binding: the replace launch is node 0 of the graph (ONE hipGraphLaunch per call)
         self.tail_handles = None      # (hipGraph_t, hipGraphExec_t) of the same graph without node 0 (begin_call / finish_call)
 
@@ -715,6 +716,70 @@ class LanPaint:
         self.last_inner_steps = cap.ran
         _cabi.check(self._lib.lp_replay_call(ctypes.byref(cap.tail), stream), "lp_replay_call")
         return out
+
+    def node_call(self, x, latent_image, noise, sigma, latent_mask, current_times, model_options, seed, nd):
+        """The steady state of KSamplerX0Inpaint.__call__ in ONE trip through the FFI (lp_node_call): sigma -> times and
+        the two scalars of the inner-step rule, the replace launch of this call, the wait for the scalars, the rule
+        (nodes.py:286-299), and the launch of the graph captured for the resulting count.  `nd` is the caller's
+        LpNodeCallDesc with the sigma / schedule / mailbox / rule fields filled in.  Returns (out, n_eff), or None when the
+        call is not a steady-state replay (nothing enqueued: the caller takes its ordinary path)."""
+        cap0 = self._last_cap
+        if cap0 is None or cap0.tail is None or self.model_dtype is not None or not x.is_cuda:
+            return None
+        self.img_dim_size = len(x.shape)
+        self.latent_image, self.noise = latent_image, noise
+        self.audio_indicator = self.current_times_audio = self.audio_correction = None
+        self._noise_regenerated = self._noise_is_zero(noise)
+        if not self._same_call(cap0, x, sigma, latent_mask, current_times, cap0.ident[4], model_options, seed):
+            return None
+        table = cap0.node_table
+        if table is None or table[3] != len(self._graphs) or table[4] is not model_options:
+            table = self._node_table(cap0, nd.n_steps, model_options)
+        stream = self._stream(x.device)
+        ve, abt = current_times[0], current_times[1]
+        out = torch.empty_like(x)
+        k0 = cap0.k0_desc
+        k0.x, k0.noise = x.data_ptr(), noise.data_ptr()
+        k0.t_ve, k0.t_abt, k0.t_rsig = ve.data_ptr(), abt.data_ptr(), sigma.data_ptr()
+        k0.t_model = (current_times[2] if cap0.flow else ve).data_ptr()
+        k0.io_table_val[0], k0.io_table_val[1] = k0.x, out.data_ptr()
+        off = 0
+        if self.rng == "torch":
+            gen = self._generator(x.device)
+            off = gen.get_offset()
+            k0.rng_state_val[0], k0.rng_state_val[1] = off, gen.initial_seed()
+        nd.replace, nd.exec_by_count, nd.n_counts = table[2], table[0], len(table[1])
+        _cabi.check(self._lib.lp_node_call(ctypes.byref(nd), stream), "lp_node_call")
+        n_eff = nd.n_eff
+        if not nd.launched:
+            # no capture for this count yet: the ordinary path captures it (and re-enqueues the replace step, which reads
+            # the same untouched x and publishes the same generator state)
+            cap0.node_table = None
+            return self(x, latent_image, noise, sigma, latent_mask, current_times, model_options, seed, n_steps=n_eff), n_eff
+        cap = table[1][n_eff]
+        if self.rng == "torch" and cap.launches:
+            self._generator(x.device).set_offset(off + cap.launches)
+            self._torch_consumed += cap.launches
+        self._iterations_run += cap.ran
+        self.last_inner_steps = cap.ran
+        return out, n_eff
+
+    def _node_table(self, cap0, n_max, model_options):
+        """hipGraphExec_t of the tail graph captured for every inner-step count 0 .. n_max of this call shape (NULL where
+        none exists yet), as the array lp_node_call indexes; holds the captures alive."""
+        caps = []
+        for n in range(int(n_max) + 1):
+            cap = cap0 if cap0.ident[4] == n else cap0.siblings.get(n)
+            if cap is None or not cap.alive:
+                cap = self._graphs.get(cap0.key[:2] + (n,) + cap0.key[3:])
+                if cap is not None and (cap.tail is None or cap.model_options is not model_options or cap.ws is not cap0.ws):
+                    cap = None
+                if cap is not None:
+                    cap0.siblings[n] = cap
+            caps.append(cap if (cap is not None and cap.tail is not None) else None)
+        arr = (ctypes.c_void_p * len(caps))(*[(c.tail.graph_exec if c is not None else None) for c in caps])
+        cap0.node_table = (arr, caps, ctypes.pointer(cap0.k0_desc), len(self._graphs), model_options)
+        return cap0.node_table
 
     # ------------------------------------------------------------------ hipGraph replay of one sigma call
     def _same_call(self, cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed):

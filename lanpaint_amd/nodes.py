@@ -266,6 +266,7 @@ class KSamplerX0Inpaint:
         self._mask_cache = None          # (weakref(denoise_mask), version, latent_mask): binarised once per run
         self._mailbox = None             # pinned host float32[4]: lp_sigma_times writes {step index, mean(1-abt), seq}
         self._seq = 0
+        self._node_desc = None           # LpNodeCallDesc of the one-call steady state (lp_node_call)
         self._sched = None               # (schedule tensor object, dense copy, data_ptr, numel, len - 1): looked at once per run
         self._times = None               # (rows, device, [two sets of (VE sigma, abt, flow t, buffer)]): the three time
                                          # tensors of a call are views of one buffer, made once (a view costs the host
@@ -334,6 +335,31 @@ class KSamplerX0Inpaint:
             VE_Sigma, abt, Flow_t, buf = tm[2][self._seq & 1]
             mb = self._mailbox_views()[0]
             self._seq = fused_seq = (self._seq % 0x7ffffff0) + 1
+            pm = getattr(self, "PaintMethod", None)
+            if (denoise_mask is not None and self.audio_indicator is None and "denoise_mask_function" not in model_options
+                    and getattr(pm, "_last_cap", None) is not None and sigma.device.index == torch.cuda.current_device()
+                    and type(self.LanPaint_early_stop) is int and type(pm.n_steps) is int):
+                # Steady state of a replayed run: sigma -> times, the replace launch, the wait for the device's answer, the
+                # inner-step rule and the launch of the graph for that count are ONE call into the library (lp_node_call)
+                nd = self._node_desc
+                if nd is None:
+                    nd = self._node_desc = _cabi.LpNodeCallDesc()
+                    nd.spin_limit = 200000
+                nd.sigma, nd.rows, nd.schedule, nd.schedule_len = sig_c.data_ptr(), rows, sc[2], sc[3]
+                nd.is_flow, nd.seq, nd.times_out = int(bool(IS_FLUX or IS_FLOW)), fused_seq, buf.data_ptr()
+                nd.scalars_out, nd.seq_out = mb.data_ptr(), mb.data_ptr() + 8
+                nd.n_steps, nd.early_stop, nd.total_steps = int(pm.n_steps), int(self.LanPaint_early_stop), sc[4]
+                nd.min_step_frac = float(getattr(self, "LanPaint_min_step_frac", 1.0))
+                res = pm.node_call(x, self.latent_image, self.noise, sigma, self._latent_mask(denoise_mask),
+                                   (VE_Sigma, abt, Flow_t), model_options, seed, nd)
+                if res is not None:
+                    out = res[0]
+                    step_i = model_options.get("i", kwargs.get("i", 0))          # preview hook, nodes.py:304-313
+                    if step_i % 2 == 0:
+                        cb = model_options.get("callback", None)
+                        if cb is not None:
+                            cb({"i": step_i, "denoised": out, "x": x})
+                    return out
             args = (sig_c.data_ptr(), rows, sc[2], sc[3], int(bool(IS_FLUX or IS_FLOW)), buf.data_ptr(),
                     mb.data_ptr(), mb.data_ptr() + 8, fused_seq, raw_stream(sigma.device))
             if sigma.device.index == torch.cuda.current_device():     # (the context manager costs the host ~2 us)

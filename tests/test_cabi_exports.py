@@ -75,7 +75,15 @@ def test_struct_layout_matches_c(tmp_path):
     fields_es = [f for f, _ in _cabi.LpEsState._fields_]
     for f in fields_es:
         prog.append(f'printf("%zu ", offsetof(lp_es_state, {f}));')
-    prog.append('printf("%zu %d %d\\n", sizeof(lp_es_state), LP_ES_SEQ_DONE, LP_ES_TRACE0); return 0;}')
+    prog.append('printf("%zu %d %d\\n", sizeof(lp_es_state), LP_ES_SEQ_DONE, LP_ES_TRACE0);')
+    fields_node = [f for f, _ in _cabi.LpNodeCallDesc._fields_]
+    fields_bind = [f for f, _ in _cabi.LpGraphBinding._fields_]
+    for f in fields_node:
+        prog.append(f'printf("%zu ", offsetof(lp_node_call_desc, {f}));')
+    prog.append('printf("%zu\\n", sizeof(lp_node_call_desc));')
+    for f in fields_bind:
+        prog.append(f'printf("%zu ", offsetof(lp_graph_binding, {f}));')
+    prog.append('printf("%zu %d\\n", sizeof(lp_graph_binding), LP_ES_ACC_DOUBLES); return 0;}')
     src = tmp_path / "layout.c"
     src.write_text("\n".join(prog))
     exe = tmp_path / "layout"
@@ -89,6 +97,10 @@ def test_struct_layout_matches_c(tmp_path):
         [ctypes.sizeof(_cabi.LpCallDesc)]
     assert [int(v) for v in lines[4].split()] == [getattr(_cabi.LpEsState, f).offset for f in fields_es] + \
         [ctypes.sizeof(_cabi.LpEsState), _cabi.LP_ES_SEQ_DONE, _cabi.LP_ES_TRACE0]
+    assert [int(v) for v in lines[5].split()] == [getattr(_cabi.LpNodeCallDesc, f).offset for f in fields_node] + \
+        [ctypes.sizeof(_cabi.LpNodeCallDesc)]
+    assert [int(v) for v in lines[6].split()] == [getattr(_cabi.LpGraphBinding, f).offset for f in fields_bind] + \
+        [ctypes.sizeof(_cabi.LpGraphBinding), _cabi.LP_ES_ACC_DOUBLES]
 
 
 def test_engine_refuses_cpu_tensors(hip_lib):

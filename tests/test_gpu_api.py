@@ -458,6 +458,14 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
             assert k.noise.is_inference()
         k.PaintMethod = LanPaint(model, n_think, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, MinStepFrac=1.0, rng="torch", graph=graph)
         k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 1.0
+        one_call = {"n": 0}
+        node_call = k.PaintMethod.node_call
+
+        def counted(*a, **kw):                       # the one-FFI-trip steady state (lp_node_call) must be what replays take
+            r = node_call(*a, **kw)
+            one_call["n"] += r is not None
+            return r
+        k.PaintMethod.node_call = counted
         dm, mo = tt(denoise_mask), {}
         torch.manual_seed(77)
         outs, n_effs, split = [], [], 0
@@ -474,7 +482,7 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
                 x = torch.lerp(den, x, float(sig[i + 1] / sig[i]))
         torch.cuda.synchronize()
         res[graph] = ([o.cpu().numpy() for o in outs], x.cpu().numpy(), n_effs, model.calls, split,
-                      torch.cuda.get_rng_state(DEV).clone())
+                      torch.cuda.get_rng_state(DEV).clone(), one_call["n"])
     expect = []
     for i in range(len(sig) - 1):
         s = np.full((shape[0],), sig[i], dtype=np.float32)
@@ -482,6 +490,7 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
     assert res[False][2] == res[True][2] == expect * 3
     assert len(set(expect)) >= 5 and 0 in expect and n_think in expect   # the ramp exercises (nearly) every graph variant
     assert res[True][4] >= 2 * (len(sig) - 1)                            # the replays went through the split-phase path
+    assert res[True][6] >= 2 * (len(sig) - 1) - 6 and res[False][6] == 0    # ... in one trip through the FFI each (lp_node_call)
     assert res[True][3] < res[False][3]          # the Python backbone only ran while capturing
     for a, b in zip(res[False][0], res[True][0]):
         np.testing.assert_array_equal(a, b)

@@ -252,3 +252,33 @@ def test_per_tensor_caches_work_on_inference_tensors(nodes):
         assert k._latent_mask(dm) is m1 and torch.equal(m1, 1 - (dm > 0.5).float())
         assert k._latent_mask(dm.clone()) is not m1
     assert tensor_version(torch.zeros(2)) == 0
+
+
+def test_native_inner_step_rule_equals_the_python_rule(nodes, hip_lib):
+    """lp_effective_inner_steps (what lp_node_call applies between the device's answer and the graph launch) against
+    nodes.py:286-299 + min_step_frac_effective_steps (nodes.py:134-144) as Python evaluates them: the reference's own KAT
+    table, every half-way case of round() (ties to even), and a seeded sweep; float32 scalars as the mailbox delivers them."""
+    import random
+    import numpy as np
+    f = nodes.min_step_frac_effective_steps
+
+    def py(n, step_f, frac, total, early, msf):
+        if total - int(step_f) <= early:
+            return 0
+        return f(n, frac, msf)
+
+    c = hip_lib.lp_effective_inner_steps
+    for n, frac, msf, want in [(5, 0.1, 0.0, 5), (5, 0.2, 0.05, 5), (5, 0.05, 0.05, 5), (5, 0.04, 0.05, 4), (5, 0.025, 0.05, 2),
+                               (5, 0.005, 0.05, 0), (5, 0.0, 0.05, 0), (0, 0.01, 0.05, 0)]:
+        assert c(n, 0.0, frac, 100, 1, msf) == want == f(n, frac, msf)
+    for n in range(0, 13):                      # exact ties: n * frac / msf = k + 0.5
+        for k in range(0, 12):
+            frac = (k + 0.5) / max(n, 1) * 0.5
+            assert c(n, 3.0, frac, 30, 1, 0.5) == py(n, 3.0, frac, 30, 1, 0.5)
+    rnd = random.Random(3)
+    for _ in range(20000):
+        n, total, early = rnd.randint(0, 12), rnd.randint(1, 60), rnd.choice([0, 1, 2, 5])
+        step_f = float(rnd.randint(0, total))
+        frac = float(np.float32(rnd.random() * 1.2))
+        msf = rnd.choice([0.0, 0.05, 0.3, 0.5, 1.0, rnd.random()])
+        assert c(n, step_f, frac, total, early, msf) == py(n, step_f, frac, total, early, msf)
