@@ -290,7 +290,8 @@ typedef struct lp_final_desc {
     float*       out;          /* out*(1-m) + y*m (lanpaint.py:154)                       */
     uint64_t*    rng_bump_ptr; /* optional: *ptr += rng_bump after the launch (graph replay) */
     uint64_t     rng_bump;
-    const uint64_t* io_table;  /* optional device u64[2] (a finalize captured in a hipGraph; BOTH published addresses must
+    const uint64_t* io_table;  /* optional device u64[3] (a finalize captured in a hipGraph; word 2 = 0 voids the launch --
+                                  nothing written, rng_bump not applied -- and must be 1 otherwise; BOTH published addresses must
                                   be 16-byte aligned -- the launch is laid out for 16 B per lane before it can see
                                   them): x_dst and out are
                                   read from io_table[0] / io_table[1] on the device, as the replace launch of the
@@ -391,7 +392,8 @@ int lp_sigma_times_mailbox(const float* sigma, int32_t rows, const float* schedu
  * and launches the graph the caller captured for that count (`exec_by_count[n_eff]`: everything of the sigma call after
  * the replace launch).  Three FFI trips and the Python between them become one; the rule is evaluated in double on the
  * float32 scalars exactly as the Python expression does.  `launched` = 0 when no graph is known for the count (the
- * caller finishes the call itself; the replace launch is already enqueued).                                    */
+ * caller finishes the call itself; the replace launch is already enqueued).  `scalars_out` is float[4]: word 2 is the
+ * sequence number (`seq_out`), word 3 the count the device computed.                                              */
 typedef struct lp_node_call_desc {
     const float*        sigma;          /* device [rows]                                                          */
     int32_t             rows;
@@ -400,7 +402,7 @@ typedef struct lp_node_call_desc {
     int32_t             is_flow;
     int32_t             seq;            /* sequence word this call posts                                          */
     float*              times_out;      /* device [3][rows]                                                       */
-    float*              scalars_out;    /* PINNED HOST float[2]: { step index, mean(1 - abt) }                    */
+    float*              scalars_out;    /* PINNED HOST float[4]: { step index, mean(1 - abt), (seq), device n_eff } */
     int32_t*            seq_out;        /* PINNED HOST                                                            */
     const lp_step_desc* replace;        /* the call's replace launch (LP_PH_REPLACE | ...), NULL = none           */
     int32_t             n_steps;        /* PaintMethod.n_steps (LanPaint_NumSteps)                                */
@@ -410,8 +412,17 @@ typedef struct lp_node_call_desc {
     double              min_step_frac;  /* LanPaint_MinStepFrac                                                   */
     void* const*        exec_by_count;  /* hipGraphExec_t per inner-step count, NULL entries allowed              */
     int32_t             spin_limit;     /* polls before falling back to hipStreamSynchronize                      */
+    int32_t             guess;          /* >= 0: SPECULATE -- queue exec_by_count[guess] before the device has answered;
+                                           the sigma kernel evaluates the same rule, and when the true count differs it
+                                           zeroes *valid_word, which voids the queued run (its lp_finalize writes
+                                           nothing, lp_final_desc.io_table word 2); lp_node_call then queues the call
+                                           again for the true count.  < 0: wait for the answer first              */
+    uint64_t*           valid_word;     /* device word the captured lp_finalize checks (io_table + 2), or NULL: never
+                                           speculate                                                              */
     int32_t             n_eff;          /* out                                                                    */
     int32_t             launched;       /* out: 1 = exec_by_count[n_eff] was launched                             */
+    int32_t             speculated;     /* out: 1 = a run was queued for `guess`                                  */
+    int32_t             hit;            /* out: 1 = ... and the guess was right                                   */
     float               step_f, frac;   /* out: the two scalars as read from the mailbox                          */
 } lp_node_call_desc;
 int lp_node_call(lp_node_call_desc* call, void* stream);

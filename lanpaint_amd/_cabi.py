@@ -113,7 +113,8 @@ class LpNodeCallDesc(C.Structure):
                 ("seq_out", C.c_void_p), ("replace", C.POINTER(LpStepDesc)), ("n_steps", C.c_int32),
                 ("early_stop", C.c_int32), ("total_steps", C.c_int32), ("n_counts", C.c_int32),
                 ("min_step_frac", C.c_double), ("exec_by_count", C.POINTER(C.c_void_p)), ("spin_limit", C.c_int32),
-                ("n_eff", C.c_int32), ("launched", C.c_int32), ("step_f", C.c_float), ("frac", C.c_float)]
+                ("guess", C.c_int32), ("valid_word", C.c_void_p), ("n_eff", C.c_int32), ("launched", C.c_int32),
+                ("speculated", C.c_int32), ("hit", C.c_int32), ("step_f", C.c_float), ("frac", C.c_float)]
 
 
 class LpBlendDesc(C.Structure):

@@ -39,9 +39,20 @@ __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int v
 // One thread: B and the schedule are tiny.  __f*_rn keep every op separately rounded like the
 // reference's eager fp32 tensor ops (an FMA here could flip a round() in the n_eff rule).
 // ---------------------------------------------------------------------------------
+// The inner-step rule evaluated on the device too (round 3): with `rule.valid_out` the kernel compares the count the host
+// SPECULATED (`rule.guess`; it queued the whole sigma call for it before this kernel ran) with the true one and writes the
+// word the captured lp_finalize looks at: 0 voids that run -- nothing of the caller's is written, no generator state moves --
+// and the host, which reads the true count from the mailbox, queues the call again.
+struct SigmaRule {
+    int32_t n_steps, early_stop, total_steps, guess;       // guess < 0: not speculating (the word is set to 1)
+    double min_step_frac;
+    uint64_t* valid_out;                                   // device word, or nullptr: no rule on the device
+};
+
 __global__ void lp_sigma_times_kernel(const float* __restrict__ sigma, int rows, const float* __restrict__ schedule,
                                       int schedule_len, int is_flow, float* __restrict__ times,
-                                      float* __restrict__ scalars, int32_t* __restrict__ seq_out, int32_t seq) {
+                                      float* __restrict__ scalars, int32_t* __restrict__ seq_out, int32_t seq,
+                                      const SigmaRule rule) {
     // plain operators under `fp contract(off)`: every * + - / below is rounded on its own, like the
     // reference's eager tensor ops (HIP's __fmul_rn/__fadd_rn are inline wrappers whose bodies keep the
     // default contract(fast) flags and DO get fused into an FMA after inlining -- measured: 1 ulp off)
@@ -87,20 +98,36 @@ __global__ void lp_sigma_times_kernel(const float* __restrict__ sigma, int rows,
             best = i;
         }
     }
+    const float frac = sum_oma / static_cast<float>(rows);
     scalars[0] = static_cast<float>(best);
-    scalars[1] = sum_oma / static_cast<float>(rows);
+    scalars[1] = frac;
+    if (rule.valid_out) {
+        const int32_t n_eff = effective_inner_steps(rule.n_steps, static_cast<double>(static_cast<float>(best)),
+                                                    static_cast<double>(frac), rule.total_steps, rule.early_stop,
+                                                    rule.min_step_frac);
+        *rule.valid_out = (rule.guess < 0 || rule.guess == n_eff) ? 1ull : 0ull;
+        scalars[3] = static_cast<float>(n_eff);            // (word 2 of the mailbox is the sequence number)
+    }
     if (seq_out) {       // mailbox in pinned host memory: the sequence number lands after the two scalars
         __threadfence_system();
         __hip_atomic_store(seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
+int sigma_times_rule_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow,
+                              float* times, float* scalars, int32_t* seq_out, int32_t seq, int32_t n_steps, int32_t early_stop,
+                              int32_t total_steps, double min_step_frac, int32_t guess, uint64_t* valid_out, hipStream_t stream) {
+    if (!sigma || !schedule || !times || !scalars || rows <= 0 || schedule_len <= 0) return LP_E_INVALID;
+    const SigmaRule rule{n_steps, early_stop, total_steps, guess, min_step_frac, valid_out};
+    hipLaunchKernelGGL(lp_sigma_times_kernel, dim3(1), dim3(64), 0, stream, sigma, rows, schedule, schedule_len, is_flow,
+                       times, scalars, seq_out, seq, rule);
+    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+}
+
 int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow,
                          float* times, float* scalars, int32_t* seq_out, int32_t seq, hipStream_t stream) {
-    if (!sigma || !schedule || !times || !scalars || rows <= 0 || schedule_len <= 0) return LP_E_INVALID;
-    hipLaunchKernelGGL(lp_sigma_times_kernel, dim3(1), dim3(64), 0, stream, sigma, rows, schedule, schedule_len, is_flow,
-                       times, scalars, seq_out, seq);
-    return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
+    return sigma_times_rule_dispatch(sigma, rows, schedule, schedule_len, is_flow, times, scalars, seq_out, seq, 0, 0, 0, 0.0, -1,
+                                     nullptr, stream);
 }
 
 int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const float* abt, int abt_stride,
@@ -134,6 +161,9 @@ __global__ __launch_bounds__(256) void lp_finalize_kernel(const void* a_mask, co
     // launch published (scalar loads, issued first; only the stores at the end of the body wait for them)
     float* const x_dst = d.io_table ? reinterpret_cast<float*>(d.io_table[0]) : d.x_dst;
     float* const out = d.io_table ? reinterpret_cast<float*>(d.io_table[1]) : d.out;
+    // word 2 of the table: 0 voids this launch (a sigma call queued for a speculated inner-step count that turned out
+    // wrong, lp_node_call): nothing of the caller's is written and the replayed generator counter does not move
+    if (d.io_table && d.io_table[2] == 0ull) return;
     if (g < groups) {
         const int64_t i = g * VEC;
         float m[VEC], mo[VEC], yv[VEC], o[VEC];

@@ -17,6 +17,9 @@ int coeffs_dispatch(const lp_hyper* h, const float* ve, int ve_stride, const flo
 int finalize_dispatch(const lp_final_desc* d, hipStream_t stream);
 int sigma_times_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow, float* times,
                          float* scalars, int32_t* seq_out, int32_t seq, hipStream_t stream);
+int sigma_times_rule_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow,
+                              float* times, float* scalars, int32_t* seq_out, int32_t seq, int32_t n_steps, int32_t early_stop,
+                              int32_t total_steps, double min_step_frac, int32_t guess, uint64_t* valid_out, hipStream_t stream);
 int blend_dispatch(const lp_blend_desc* d, hipStream_t stream);
 int philox_dispatch(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, hipStream_t stream);
 int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, int width, hipStream_t stream);
@@ -162,39 +165,61 @@ int lp_graph_release(void* tail_graph, void* tail_exec) {
 
 int32_t lp_effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps, int32_t early_stop,
                                  double min_step_frac) {
-    // nodes.py:286-299 + :134-144, as Python evaluates it: int(step) compare, then doubles and round-half-even
-    if (total_steps - static_cast<int32_t>(step_f) <= early_stop) return 0;
-    const double f = frac;
-    if (min_step_frac <= 0.0 || f >= min_step_frac || n_steps <= 0) return n_steps;
-    const double r = std::nearbyint(static_cast<double>(n_steps) * f / min_step_frac);     // FE_TONEAREST: ties to even
-    return r > 0.0 ? static_cast<int32_t>(r) : 0;
+    return lp::effective_inner_steps(n_steps, step_f, frac, total_steps, early_stop, min_step_frac);
+}
+
+static int node_wait(const lp_node_call_desc* c, int32_t want, hipStream_t s) {
+    for (int32_t k = 0; k < c->spin_limit; ++k)
+        if (__atomic_load_n(c->seq_out, __ATOMIC_ACQUIRE) == want) return LP_OK;
+    // a long backlog in front of the kernel: sleep on the stream instead of spinning
+    if (hipStreamSynchronize(s) != hipSuccess) return LP_E_LAUNCH;
+    return __atomic_load_n(c->seq_out, __ATOMIC_ACQUIRE) == want ? LP_OK : LP_E_LAUNCH;
 }
 
 int lp_node_call(lp_node_call_desc* c, void* stream) {
     if (!c || !c->sigma || !c->schedule || !c->times_out || !c->scalars_out || !c->seq_out || c->rows <= 0) return LP_E_INVALID;
     hipStream_t s = as_stream(stream);
-    int rc = lp::sigma_times_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
-                                      c->scalars_out, c->seq_out, c->seq, s);
+    const auto exec_for = [&](int32_t n) -> hipGraphExec_t {
+        return (c->exec_by_count && n >= 0 && n < c->n_counts) ? static_cast<hipGraphExec_t>(c->exec_by_count[n]) : nullptr;
+    };
+    // Speculation: with a guess for the count and the device word the captured lp_finalize checks, the WHOLE call is queued
+    // before the device has said anything; the sigma kernel compares the guess with the true count and voids the run on a miss.
+    const bool speculate = c->guess >= 0 && c->valid_word && exec_for(c->guess) != nullptr && c->replace;
+    c->speculated = speculate ? 1 : 0;
+    c->hit = 0;
+    c->launched = 0;
+    int rc = lp::sigma_times_rule_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
+                                           c->scalars_out, c->seq_out, c->seq, c->n_steps, c->early_stop, c->total_steps,
+                                           c->min_step_frac, speculate ? c->guess : -1, c->valid_word, s);
     if (rc != LP_OK) return rc;
     if (c->replace) {                        // the part of the call that does not depend on the answer: queued before the wait
         rc = lp::step_dispatch(c->replace, s, nullptr);
         if (rc != LP_OK) return rc;
     }
-    const int32_t want = c->seq;
-    bool seen = false;
-    for (int32_t k = 0; k < c->spin_limit; ++k) {
-        if (__atomic_load_n(c->seq_out, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
-    }
-    if (!seen) {                             // a long backlog in front of the kernel: sleep on the stream instead of spinning
-        if (hipStreamSynchronize(s) != hipSuccess) return LP_E_LAUNCH;
-        if (__atomic_load_n(c->seq_out, __ATOMIC_ACQUIRE) != want) return LP_E_LAUNCH;
-    }
+    if (speculate && hipGraphLaunch(exec_for(c->guess), s) != hipSuccess) return LP_E_LAUNCH;
+    rc = node_wait(c, c->seq, s);
+    if (rc != LP_OK) return rc;
     c->step_f = c->scalars_out[0];
     c->frac = c->scalars_out[1];
-    c->n_eff = lp_effective_inner_steps(c->n_steps, static_cast<double>(c->step_f), static_cast<double>(c->frac), c->total_steps, c->early_stop, c->min_step_frac);
-    c->launched = 0;
-    if (c->exec_by_count && c->n_eff >= 0 && c->n_eff < c->n_counts && c->exec_by_count[c->n_eff]) {
-        if (hipGraphLaunch(static_cast<hipGraphExec_t>(c->exec_by_count[c->n_eff]), s) != hipSuccess) return LP_E_LAUNCH;
+    c->n_eff = lp::effective_inner_steps(c->n_steps, static_cast<double>(c->step_f), static_cast<double>(c->frac),
+                                         c->total_steps, c->early_stop, c->min_step_frac);
+    if (c->valid_word && static_cast<int32_t>(c->scalars_out[3]) != c->n_eff) return LP_E_UNSUPPORTED;   // host and device rule disagree
+    if (speculate) {
+        if (c->n_eff == c->guess) {          // the queued run is the call
+            c->hit = 1;
+            c->launched = 1;
+            return LP_OK;
+        }
+        // a miss: the queued run voided itself.  Queue the call again, unconditionally valid this time.
+        rc = lp::sigma_times_rule_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
+                                           c->scalars_out, c->seq_out, c->seq ^ 0x40000000, c->n_steps, c->early_stop,
+                                           c->total_steps, c->min_step_frac, -1, c->valid_word, s);
+        if (rc != LP_OK) return rc;
+        rc = lp::step_dispatch(c->replace, s, nullptr);
+        if (rc != LP_OK) return rc;
+    }
+    if (hipGraphExec_t e = exec_for(c->n_eff)) {
+        if (hipGraphLaunch(e, s) != hipSuccess) return LP_E_LAUNCH;
         c->launched = 1;
     }
     return LP_OK;

@@ -497,6 +497,18 @@ __device__ __forceinline__ void wave_sum_dpp(T (&v)[N]) {
     dpp_level<0x143, 0xc>(v);     // row_bcast 31 into rows 2 and 3: lane 63 = the wave's sum
 }
 
+// The inner-step rule of KSamplerX0Inpaint.__call__ (nodes.py:286-299 + min_step_frac_effective_steps, :134-144) as Python
+// evaluates it: int(step) compare, then doubles and round-half-even.  ONE source for the host (lp_node_call) and the device
+// (lp_sigma_times_kernel, which checks a speculated count): n * frac is exact in double (a 24-bit by a 31-bit integer
+// mantissa), the division is correctly rounded on both, rint ties to even on both -- the two cannot disagree.
+__host__ __device__ inline int32_t effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps,
+                                                         int32_t early_stop, double min_step_frac) {
+    if (total_steps - static_cast<int32_t>(step_f) <= early_stop) return 0;
+    if (min_step_frac <= 0.0 || frac >= min_step_frac || n_steps <= 0) return n_steps;
+    const double r = rint(static_cast<double>(n_steps) * frac / min_step_frac);
+    return r > 0.0 ? static_cast<int32_t>(r) : 0;
+}
+
 __host__ __device__ inline int x0_dtype(uint32_t flags) {
     return (flags & LP_FL_X0_BF16) ? DT_BF16 : (flags & LP_FL_X0_F16) ? DT_F16 : DT_F32;
 }

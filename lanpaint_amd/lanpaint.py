@@ -749,6 +749,7 @@ class LanPaint:
             off = gen.get_offset()
             k0.rng_state_val[0], k0.rng_state_val[1] = off, gen.initial_seed()
         nd.replace, nd.exec_by_count, nd.n_counts = table[2], table[0], len(table[1])
+        nd.valid_word = self._rng_state(x.device).data_ptr() + 32
         _cabi.check(self._lib.lp_node_call(ctypes.byref(nd), stream), "lp_node_call")
         n_eff = nd.n_eff
         if not nd.launched:
@@ -1018,10 +1019,11 @@ class LanPaint:
         bumped by every replay so the streams of different captures never overlap.  rng="torch": (generator
         offset, seed) published by the replace launch of each call.  [2], [3]: the I/O table of the call in flight
         (address of the sampler latent x, address of `out`), published by the replace launch for the captured
-        lp_finalize."""
+        lp_finalize.  [4]: the word that voids a captured lp_finalize when 0 (io_table word 2)."""
         state = self._rng_counters.get(dev)
         if state is None:
-            state = self._rng_counters[dev] = torch.zeros(4, dtype=torch.int64, device=dev)
+            state = self._rng_counters[dev] = torch.zeros(8, dtype=torch.int64, device=dev)
+            state[4] = 1          # [4]: "this sigma call is valid" -- 0 voids a captured lp_finalize (a speculated call, lp_node_call)
         return state
 
     def _capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,

@@ -20,6 +20,7 @@ Image/mask utility nodes, the AV encode/decode nodes and the video-mask editor a
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from contextlib import contextmanager
 
@@ -267,10 +268,46 @@ class KSamplerX0Inpaint:
         self._mailbox = None             # pinned host float32[4]: lp_sigma_times writes {step index, mean(1-abt), seq}
         self._seq = 0
         self._node_desc = None           # LpNodeCallDesc of the one-call steady state (lp_node_call)
+        self._last_step = None           # schedule position of the previous call (from the device), for the next guess
+        self._spec_misses = 0            # 2 = speculation is off for the run (two wrong guesses among the last four)
+        self._spec_hist = []             # outcomes of the last four guesses
+        self._n_eff_table = None         # (key, inner-step count per schedule position) from a host mirror of the schedule
         self._sched = None               # (schedule tensor object, dense copy, data_ptr, numel, len - 1): looked at once per run
         self._times = None               # (rows, device, [two sets of (VE sigma, abt, flow t, buffer)]): the three time
                                          # tensors of a call are views of one buffer, made once (a view costs the host
                                          # ~1.5 us) and used by alternate calls
+
+    def _guess_inner_steps(self, nd, rows, flow):
+        """The count the NEXT sigma is expected to get, or -1: samplers walk the schedule, so after the call at schedule
+        position p the next one is usually at p + 1.  The count for each position comes from a host mirror of the schedule
+        (one device->host copy per run) pushed through the same fp32 arithmetic as lp_sigma_times and the same rule.  A
+        wrong guess is only slower, never wrong: the device voids the speculated run (lp_node_call); two misses among four
+        guesses (a sampler that evaluates the model several times per step) turn guessing off for the run."""
+        if self._last_step is None or self._spec_misses >= 2 or os.environ.get("LANPAINT_AMD_SPECULATE", "1") == "0":
+            return -1
+        tab = self._n_eff_table
+        key = (rows, flow, nd.n_steps, nd.early_stop, nd.min_step_frac)
+        if tab is None or tab[0] != key:
+            import numpy as np
+            sched = self._sched[1].detach().cpu().numpy().astype(np.float32)            # the one host copy of the run
+            one = np.float32(1.0)
+            counts = []
+            for j, s in enumerate(sched):
+                if flow:
+                    a = one - s
+                    abt = (a * a) / (a * a + s * s) if (a * a + s * s) != 0 else np.float32(np.nan)
+                else:
+                    abt = one / (one + s * s)
+                acc = np.float32(0.0)
+                for _ in range(rows):                       # the kernel's sequential fp32 mean over (equal) rows
+                    acc = np.float32(acc + np.float32(one - abt))
+                frac = float(np.float32(acc / np.float32(rows)))
+                counts.append(-1 if frac != frac else
+                              _cabi.load().lp_effective_inner_steps(nd.n_steps, float(j), frac, nd.total_steps, nd.early_stop,
+                                                                    nd.min_step_frac))
+            self._n_eff_table = tab = (key, counts)
+        j = self._last_step + 1
+        return tab[1][j] if 0 <= j < len(tab[1]) else -1
 
     def _mailbox_views(self):
         """The pinned host words the device writes the two scalars of the inner-step rule into (fine-grained host
@@ -350,10 +387,16 @@ class KSamplerX0Inpaint:
                 nd.scalars_out, nd.seq_out = mb.data_ptr(), mb.data_ptr() + 8
                 nd.n_steps, nd.early_stop, nd.total_steps = int(pm.n_steps), int(self.LanPaint_early_stop), sc[4]
                 nd.min_step_frac = float(getattr(self, "LanPaint_min_step_frac", 1.0))
+                nd.guess = self._guess_inner_steps(nd, rows, bool(IS_FLUX or IS_FLOW))
                 res = pm.node_call(x, self.latent_image, self.noise, sigma, self._latent_mask(denoise_mask),
                                    (VE_Sigma, abt, Flow_t), model_options, seed, nd)
                 if res is not None:
                     out = res[0]
+                    self._last_step = int(nd.step_f)
+                    if nd.speculated:                 # two misses among the last four guesses turn guessing off for the run
+                        self._spec_hist = (self._spec_hist + [bool(nd.hit)])[-4:]
+                        if self._spec_hist.count(False) >= 2:
+                            self._spec_misses = 2
                     step_i = model_options.get("i", kwargs.get("i", 0))          # preview hook, nodes.py:304-313
                     if step_i % 2 == 0:
                         cb = model_options.get("callback", None)

@@ -464,6 +464,9 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
         def counted(*a, **kw):                       # the one-FFI-trip steady state (lp_node_call) must be what replays take
             r = node_call(*a, **kw)
             one_call["n"] += r is not None
+            if r is not None:
+                one_call["spec"] = one_call.get("spec", 0) + int(a[-1].speculated)
+                one_call["hit"] = one_call.get("hit", 0) + int(a[-1].hit)
             return r
         k.PaintMethod.node_call = counted
         dm, mo = tt(denoise_mask), {}
@@ -482,7 +485,7 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
                 x = torch.lerp(den, x, float(sig[i + 1] / sig[i]))
         torch.cuda.synchronize()
         res[graph] = ([o.cpu().numpy() for o in outs], x.cpu().numpy(), n_effs, model.calls, split,
-                      torch.cuda.get_rng_state(DEV).clone(), one_call["n"])
+                      torch.cuda.get_rng_state(DEV).clone(), one_call["n"], one_call.get("spec", 0), one_call.get("hit", 0))
     expect = []
     for i in range(len(sig) - 1):
         s = np.full((shape[0],), sig[i], dtype=np.float32)
@@ -491,6 +494,10 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
     assert len(set(expect)) >= 5 and 0 in expect and n_think in expect   # the ramp exercises (nearly) every graph variant
     assert res[True][4] >= 2 * (len(sig) - 1)                            # the replays went through the split-phase path
     assert res[True][6] >= 2 * (len(sig) - 1) - 6 and res[False][6] == 0    # ... in one trip through the FFI each (lp_node_call)
+    # ... most of them queued for a SPECULATED count before the device answered (the schedule is walked in order: hits), and
+    # the wrap-around from the last sigma of a pass to the first of the next is a miss the device voided -- with no trace in
+    # the results (bitwise equality below) or in the generator state
+    assert res[True][7] >= len(sig) and res[True][8] >= res[True][7] - 3 and res[True][8] < res[True][7]
     assert res[True][3] < res[False][3]          # the Python backbone only ran while capturing
     for a, b in zip(res[False][0], res[True][0]):
         np.testing.assert_array_equal(a, b)
@@ -628,3 +635,70 @@ def test_nan_in_the_head_an_element_does_not_read_stays_out_of_it(bits):
     np.testing.assert_array_equal(xp, xc)
     # `out` is the final head-0 prediction re-projected: known elements take y, inpaint elements the clean part of head 0
     np.testing.assert_array_equal(op, oc)
+
+
+@pytest.mark.parametrize("rng", ["torch", "philox"])
+def test_speculated_inner_step_counts_that_miss_leave_no_trace(rng):
+    """lp_node_call queues a sigma call for a GUESSED inner-step count; the device checks the guess and voids the run on a
+    miss, then the call is queued again.  A Heun-like order (every sigma evaluated twice) makes half the guesses wrong until
+    guessing turns itself off: the results must equal a run that never guesses (LANPAINT_AMD_SPECULATE=0) bit for bit -- x,
+    every denoised, the torch generator (rng="torch") and the replayed Philox counter (rng="philox": same noise in both runs)."""
+    import os
+    import torch
+    from lanpaint_amd import LanPaint
+    from lanpaint_amd import nodes
+    shape, n_think = (1, 4, 16, 16), 5
+    sig = gc.karras_sigmas(10, 0.05, 12.0)
+    rs = np.random.default_rng(4)
+    y = rs.standard_normal(shape, dtype=np.float32)
+    noise = rs.standard_normal(shape, dtype=np.float32)
+    denoise_mask = (rs.random(shape) > 0.4).astype(np.float32)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    order = [0, 1, 1, 2, 2, 3, 3, 4, 5, 6, 7, 8, 9, 9, 0, 1, 2, 3, 4, 5, 6, 7, 8]       # doubled, then in order, then a wrap
+
+    class M(_DummyModel):
+        def __call__(self, x, sigma, model_options=None, seed=None):
+            self.calls += 1
+            return 0.9 * x, 0.8 * x
+
+    res = {}
+    for spec in ("0", "1"):
+        os.environ["LANPAINT_AMD_SPECULATE"] = spec
+        try:
+            model = M(_DummySampling())
+            model.model_type = "EPS"
+            k = nodes.KSamplerX0Inpaint(model, tt(sig))
+            k.latent_image, k.noise = tt(y), tt(noise)
+            k.PaintMethod = LanPaint(model, n_think, 15.0, 5.0, 1.0, 0.2, MinStepFrac=1.0, rng=rng, philox_seed=11, graph=True)
+            k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 1.0
+            stats = {"spec": 0, "hit": 0}
+            node_call = k.PaintMethod.node_call
+
+            def counted(*a, **kw):
+                r = node_call(*a, **kw)
+                if r is not None:
+                    stats["spec"] += int(a[-1].speculated)
+                    stats["hit"] += int(a[-1].hit)
+                return r
+            k.PaintMethod.node_call = counted
+            dm, mo = tt(denoise_mask), {}
+            torch.manual_seed(5)
+            outs = []
+            for rep in range(2):                 # pass 0 captures every count, pass 1 replays (and guesses)
+                x = tt(y + noise * sig[0])
+                for j in order:
+                    s = torch.full((1,), float(sig[j]), dtype=torch.float32, device=DEV)
+                    den = k(x, s, dm, model_options=mo, seed=0)
+                    outs.append(den.clone())
+                    x = torch.lerp(den, x, 0.7)
+            torch.cuda.synchronize()
+            res[spec] = ([o.cpu().numpy() for o in outs], x.cpu().numpy(), torch.cuda.get_rng_state(DEV).clone(),
+                         k.PaintMethod.iterations_run, dict(stats))
+        finally:
+            os.environ.pop("LANPAINT_AMD_SPECULATE", None)
+    assert res["0"][4]["spec"] == 0
+    assert res["1"][4]["spec"] >= 4 and res["1"][4]["hit"] < res["1"][4]["spec"]        # it guessed, and some guesses were wrong
+    assert res["0"][3] == res["1"][3]
+    for a, b in zip(res["0"][0] + [res["0"][1]], res["1"][0] + [res["1"][1]]):
+        np.testing.assert_array_equal(a, b)
+    assert torch.equal(res["0"][2], res["1"][2])
