@@ -665,7 +665,8 @@ def test_speculated_inner_step_counts_that_miss_leave_no_trace(rng):
     for spec in ("0", "1"):
         os.environ["LANPAINT_AMD_SPECULATE"] = spec
         try:
-            model = M(_DummySampling())
+            from tests.stubs import VESampling
+            model = M(VESampling())               # (declares its noise_scaling form: the replace step is fusable, the call replayable)
             model.model_type = "EPS"
             k = nodes.KSamplerX0Inpaint(model, tt(sig))
             k.latent_image, k.noise = tt(y), tt(noise)
