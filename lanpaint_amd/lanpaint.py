@@ -781,8 +781,7 @@ class LanPaint:
             caps.append(cap if (cap is not None and cap.tail is not None) else None)
         arr = (ctypes.c_void_p * len(caps))(*[(c.tail.graph_exec if c is not None else None) for c in caps])
         # the full captures (replace launch = node 0) of the same counts: a speculated call is one graph launch
-        one_launch = os.environ.get("LANPAINT_AMD_SPECULATE_FULL", "1") != "0"
-        full = [c if (one_launch and c is not None and c.binding is not None and c.raw_exec is not None) else None for c in caps]
+        full = [c if (c is not None and c.binding is not None and c.raw_exec is not None) else None for c in caps]
         vp = ctypes.c_void_p * len(caps)
         full_exec = vp(*[(c.raw_exec if c is not None else None) for c in full])
         binds = vp(*[(ctypes.addressof(c.binding) if c is not None else None) for c in full])
