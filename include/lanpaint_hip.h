@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 13
+#define LP_ABI_VERSION 12
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -419,13 +419,6 @@ typedef struct lp_node_call_desc {
                                            again for the true count.  < 0: wait for the answer first              */
     uint64_t*           valid_word;     /* device word the captured lp_finalize checks (io_table + 2), or NULL: never
                                            speculate                                                              */
-    /* Optional, per count like exec_by_count: the FULL capture of the call (replace launch = node 0) with its binding and
-     * its own replace descriptor.  A speculated call then is ONE graph launch -- this call's pointers are copied from
-     * `replace` into that descriptor and written into node 0 (hipGraphExecKernelNodeSetParams) -- instead of an eager
-     * replace launch followed by the tail graph.  NULL arrays / entries: the eager launch + tail form.            */
-    void* const*        full_exec_by_count;
-    const struct lp_graph_binding* const* binding_by_count;
-    const lp_step_desc* const* replace_by_count;
     int32_t             n_eff;          /* out                                                                    */
     int32_t             launched;       /* out: 1 = exec_by_count[n_eff] was launched                             */
     int32_t             speculated;     /* out: 1 = a run was queued for `guess`                                  */

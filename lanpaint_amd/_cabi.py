@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 13
+ABI_VERSION = 12
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -113,9 +113,7 @@ class LpNodeCallDesc(C.Structure):
                 ("seq_out", C.c_void_p), ("replace", C.POINTER(LpStepDesc)), ("n_steps", C.c_int32),
                 ("early_stop", C.c_int32), ("total_steps", C.c_int32), ("n_counts", C.c_int32),
                 ("min_step_frac", C.c_double), ("exec_by_count", C.POINTER(C.c_void_p)), ("spin_limit", C.c_int32),
-                ("guess", C.c_int32), ("valid_word", C.c_void_p), ("full_exec_by_count", C.POINTER(C.c_void_p)),
-                ("binding_by_count", C.POINTER(C.c_void_p)), ("replace_by_count", C.POINTER(C.c_void_p)),
-                ("n_eff", C.c_int32), ("launched", C.c_int32),
+                ("guess", C.c_int32), ("valid_word", C.c_void_p), ("n_eff", C.c_int32), ("launched", C.c_int32),
                 ("speculated", C.c_int32), ("hit", C.c_int32), ("step_f", C.c_float), ("frac", C.c_float)]
 
 

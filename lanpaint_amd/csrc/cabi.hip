@@ -192,29 +192,11 @@ int lp_node_call(lp_node_call_desc* c, void* stream) {
                                            c->scalars_out, c->seq_out, c->seq, c->n_steps, c->early_stop, c->total_steps,
                                            c->min_step_frac, speculate ? c->guess : -1, c->valid_word, s);
     if (rc != LP_OK) return rc;
-    // a speculated call as ONE graph launch when the full capture of the guessed count is at hand: its replace node takes
-    // this call's pointers (the descriptor of that capture, patched from `replace`)
-    const int32_t g = c->guess;
-    const bool one_launch = speculate && c->full_exec_by_count && c->binding_by_count && c->replace_by_count &&
-                            c->full_exec_by_count[g] && c->binding_by_count[g] && c->replace_by_count[g];
-    if (one_launch) {
-        lp_step_desc d = *c->replace_by_count[g];
-        const lp_step_desc& r = *c->replace;
-        d.x = r.x; d.noise = r.noise; d.t_ve = r.t_ve; d.t_abt = r.t_abt; d.t_rsig = r.t_rsig; d.t_model = r.t_model;
-        d.io_table_val[0] = r.io_table_val[0]; d.io_table_val[1] = r.io_table_val[1];
-        d.rng_state_val[0] = r.rng_state_val[0]; d.rng_state_val[1] = r.rng_state_val[1];
-        d.es_seq_base = r.es_seq_base;
-        hipGraphExec_t full = static_cast<hipGraphExec_t>(c->full_exec_by_count[g]);
-        rc = lp::replace_node_update(&d, full, c->binding_by_count[g]);
+    if (c->replace) {                        // the part of the call that does not depend on the answer: queued before the wait
+        rc = lp::step_dispatch(c->replace, s, nullptr);
         if (rc != LP_OK) return rc;
-        if (hipGraphLaunch(full, s) != hipSuccess) return LP_E_LAUNCH;
-    } else {
-        if (c->replace) {                    // the part of the call that does not depend on the answer: queued before the wait
-            rc = lp::step_dispatch(c->replace, s, nullptr);
-            if (rc != LP_OK) return rc;
-        }
-        if (speculate && hipGraphLaunch(exec_for(c->guess), s) != hipSuccess) return LP_E_LAUNCH;
     }
+    if (speculate && hipGraphLaunch(exec_for(c->guess), s) != hipSuccess) return LP_E_LAUNCH;
     rc = node_wait(c, c->seq, s);
     if (rc != LP_OK) return rc;
     c->step_f = c->scalars_out[0];

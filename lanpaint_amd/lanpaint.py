@@ -749,7 +749,6 @@ class LanPaint:
             off = gen.get_offset()
             k0.rng_state_val[0], k0.rng_state_val[1] = off, gen.initial_seed()
         nd.replace, nd.exec_by_count, nd.n_counts = table[2], table[0], len(table[1])
-        nd.full_exec_by_count, nd.binding_by_count, nd.replace_by_count = table[5], table[6], table[7]
         nd.valid_word = self._rng_state(x.device).data_ptr() + 32
         _cabi.check(self._lib.lp_node_call(ctypes.byref(nd), stream), "lp_node_call")
         n_eff = nd.n_eff
@@ -780,13 +779,7 @@ class LanPaint:
                     cap0.siblings[n] = cap
             caps.append(cap if (cap is not None and cap.tail is not None) else None)
         arr = (ctypes.c_void_p * len(caps))(*[(c.tail.graph_exec if c is not None else None) for c in caps])
-        # the full captures (replace launch = node 0) of the same counts: a speculated call is one graph launch
-        full = [c if (c is not None and c.binding is not None and c.raw_exec is not None) else None for c in caps]
-        vp = ctypes.c_void_p * len(caps)
-        full_exec = vp(*[(c.raw_exec if c is not None else None) for c in full])
-        binds = vp(*[(ctypes.addressof(c.binding) if c is not None else None) for c in full])
-        k0s = vp(*[(ctypes.addressof(c.k0_desc) if c is not None else None) for c in full])
-        cap0.node_table = (arr, caps, ctypes.pointer(cap0.k0_desc), len(self._graphs), model_options, full_exec, binds, k0s)
+        cap0.node_table = (arr, caps, ctypes.pointer(cap0.k0_desc), len(self._graphs), model_options)
         return cap0.node_table
 
     # ------------------------------------------------------------------ hipGraph replay of one sigma call
