@@ -842,7 +842,7 @@ def extra_lines(args, dev):
     for _ in range(2):
         node_pass()
     torch.cuda.synchronize()
-    it0, t0, reps = k.PaintMethod.iterations_run, time.perf_counter(), 5
+    it0, t0, reps = k.PaintMethod.iterations_run, time.perf_counter(), max(20, args.steps // 8)   # (5 passes = 6 ms read +-10 %)
     for _ in range(reps):
         node_pass()
     torch.cuda.synchronize()
@@ -852,8 +852,8 @@ def extra_lines(args, dev):
         "value": iters / dt, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
         "iterations_per_step": iters // reps,
         "note": "C2 through KSamplerX0Inpaint, MinStepFrac=1.0, EarlyStop=1 (n_eff = round(5(1-abt)), last sigma 0); "
-                "the n_eff rule needs sigma's position from the device once per sigma: read from a pinned-host mailbox, "
-                "with the replace step of the call enqueued before the host waits (begin_call / finish_call)"}
+                "the n_eff rule needs sigma's position from the device once per sigma: one call into the library per sigma "
+                "(lp_node_call) queues the call for a speculated count, the device checks the guess and voids a miss"}
     # ---- dummy UNet backbone on the SD1.5 shape
     try:
         from tests.dummy_unet import DummyUNetBackbone
