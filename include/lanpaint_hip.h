@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 12
+#define LP_ABI_VERSION 13
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -93,6 +93,12 @@ typedef struct lp_hyper {
                                         (lp_coeffs folded in: one launch less per sigma call) from the raw per-row
                                         times `t_*`; its own replace / emit use the row's scale and replace sigma
                                         computed from the same inputs.  Not with LP_FL_PER_ELEMENT.             */
+#define LP_PH_SIGMA        (1u << 6) /* with LP_PH_REPLACE | LP_PH_COEFFS (bit-packed mask): the launch ALSO does what
+                                        lp_sigma_times does -- sigma -> (VE sigma, abt, flow t) per row, the two scalars
+                                        of the inner-step rule, the rule itself against a speculated count, the mailbox
+                                        (lp_step_desc.sg_*) -- and takes its per-row times from sigma instead of t_ve /
+                                        t_abt / t_rsig / t_model.  One launch less on a speculated sigma call, where the
+                                        later arrival of the answer costs nothing (lp_node_call).                       */
 
 /* ---- flags ---------------------------------------------------------------- */
 #define LP_FL_FLOW          (1u << 0)  /* flow/flux VP scaling, else VE                        */
@@ -272,6 +278,15 @@ typedef struct lp_step_desc {
      * first and of the last block store LP_CLK_STAMPS shader-clock stamps each (s_memtime ticks since its own kernel
      * entry) at clk_out[0..] and clk_out[16..], then the 100 MHz s_memrealtime span of the kernel at [15] / [31].
      * A release build ignores the field.                                                                      */
+    /* LP_PH_SIGMA (see there): the arguments of lp_sigma_times_mailbox and of the inner-step rule                */
+    const float* sg_sigma;       /* device [rows]                                                              */
+    const float* sg_schedule;    /* device [sg_schedule_len]                                                   */
+    float*       sg_times_out;   /* device [3][rows]                                                           */
+    float*       sg_scalars_out; /* pinned host float[4]                                                       */
+    int32_t*     sg_seq_out;     /* pinned host                                                                */
+    uint64_t*    sg_valid_out;   /* device word lp_finalize checks                                             */
+    double       sg_min_step_frac;
+    int32_t      sg_schedule_len, sg_seq, sg_n_steps, sg_early_stop, sg_total_steps, sg_guess;
     double*      clk_out;
 } lp_step_desc;
 #define LP_CLK_STAMPS 8  /* 0 entry, 1 operand loads issued, 2 noise generated, 3 operands arrived, 4 stop verdict
@@ -419,6 +434,8 @@ typedef struct lp_node_call_desc {
                                            again for the true count.  < 0: wait for the answer first              */
     uint64_t*           valid_word;     /* device word the captured lp_finalize checks (io_table + 2), or NULL: never
                                            speculate                                                              */
+    int32_t             fold_sigma;     /* 1: a speculated call carries the sigma algebra inside its replace launch
+                                           (LP_PH_SIGMA) instead of a kernel of its own, when the descriptor allows */
     int32_t             n_eff;          /* out                                                                    */
     int32_t             launched;       /* out: 1 = exec_by_count[n_eff] was launched                             */
     int32_t             speculated;     /* out: 1 = a run was queued for `guess`                                  */

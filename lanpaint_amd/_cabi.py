@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -24,7 +24,7 @@ LP_C_REGION0, LP_C_REGION1, LP_C_TMODEL = 12, 22, 32
 (LP_R_E_FULL, LP_R_K_FULL, LP_R_STD_FULL, LP_R_E_HALF, LP_R_K_HALF, LP_R_STD_HALF, LP_R_DT, LP_R_A, LP_R_CX0,
  LP_R_CXT) = range(10)
 
-LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT, LP_PH_COEFFS = 1, 2, 4, 8, 16, 32
+LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT, LP_PH_COEFFS, LP_PH_SIGMA = 1, 2, 4, 8, 16, 32, 64
 LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
 LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED, LP_FL_MASK_BITS, LP_FL_NO_REGION_SKIP = 256, 512, 1024, 2048, 4096
@@ -62,7 +62,11 @@ class LpStepDesc(C.Structure):
         ("io_table_out", C.c_void_p), ("io_table_val", C.c_uint64 * 2),
         ("es", C.c_void_p), ("es_x0s", C.c_void_p * 3), ("es_ring", C.c_void_p), ("es_partials", C.c_void_p), ("es_host", C.c_void_p),
         ("es_threshold", C.c_double), ("es_seq_base", C.c_int64), ("es_patience_eff", C.c_int32), ("es_index", C.c_int32),
-        ("es_n_steps", C.c_int32), ("es_reset", C.c_int32), ("clk_out", C.c_void_p),
+        ("es_n_steps", C.c_int32), ("es_reset", C.c_int32),
+        ("sg_sigma", C.c_void_p), ("sg_schedule", C.c_void_p), ("sg_times_out", C.c_void_p), ("sg_scalars_out", C.c_void_p),
+        ("sg_seq_out", C.c_void_p), ("sg_valid_out", C.c_void_p), ("sg_min_step_frac", C.c_double),
+        ("sg_schedule_len", C.c_int32), ("sg_seq", C.c_int32), ("sg_n_steps", C.c_int32), ("sg_early_stop", C.c_int32),
+        ("sg_total_steps", C.c_int32), ("sg_guess", C.c_int32), ("clk_out", C.c_void_p),
     ]
 
 
@@ -113,7 +117,7 @@ class LpNodeCallDesc(C.Structure):
                 ("seq_out", C.c_void_p), ("replace", C.POINTER(LpStepDesc)), ("n_steps", C.c_int32),
                 ("early_stop", C.c_int32), ("total_steps", C.c_int32), ("n_counts", C.c_int32),
                 ("min_step_frac", C.c_double), ("exec_by_count", C.POINTER(C.c_void_p)), ("spin_limit", C.c_int32),
-                ("guess", C.c_int32), ("valid_word", C.c_void_p), ("n_eff", C.c_int32), ("launched", C.c_int32),
+                ("guess", C.c_int32), ("valid_word", C.c_void_p), ("fold_sigma", C.c_int32), ("n_eff", C.c_int32), ("launched", C.c_int32),
                 ("speculated", C.c_int32), ("hit", C.c_int32), ("step_f", C.c_float), ("frac", C.c_float)]
 
 

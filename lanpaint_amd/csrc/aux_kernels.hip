@@ -42,76 +42,14 @@ __global__ void lp_coeffs_kernel(lp_hyper h, const float* __restrict__ ve, int v
 // The inner-step rule evaluated on the device too (round 3): with `rule.valid_out` the kernel compares the count the host
 // SPECULATED (`rule.guess`; it queued the whole sigma call for it before this kernel ran) with the true one and writes the
 // word the captured lp_finalize looks at: 0 voids that run -- nothing of the caller's is written, no generator state moves --
-// and the host, which reads the true count from the mailbox, queues the call again.
-struct SigmaRule {
-    int32_t n_steps, early_stop, total_steps, guess;       // guess < 0: not speculating (the word is set to 1)
-    double min_step_frac;
-    uint64_t* valid_out;                                   // device word, or nullptr: no rule on the device
-};
-
+// and the host, which reads the true count from the mailbox, queues the call again.  (Body shared with the LP_PH_SIGMA form
+// of the replace launch: lp_common.h.)
 __global__ void lp_sigma_times_kernel(const float* __restrict__ sigma, int rows, const float* __restrict__ schedule,
                                       int schedule_len, int is_flow, float* __restrict__ times,
                                       float* __restrict__ scalars, int32_t* __restrict__ seq_out, int32_t seq,
                                       const SigmaRule rule) {
-    // plain operators under `fp contract(off)`: every * + - / below is rounded on its own, like the
-    // reference's eager tensor ops (HIP's __fmul_rn/__fadd_rn are inline wrappers whose bodies keep the
-    // default contract(fast) flags and DO get fused into an FMA after inlining -- measured: 1 ulp off)
-#pragma clang fp contract(off)
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    float sum_sigma = 0.0f, sum_oma = 0.0f;
-    for (int r = 0; r < rows; ++r) {
-        const float s = sigma[r];
-        float ve, abt, ft;
-        if (is_flow) {                                               // nodes.py:243-245
-            const float a = 1.0f - s;
-            const float a2 = a * a;
-            const float s2 = s * s;
-            const float den = a2 + s2;
-            abt = a2 / den;
-            ve = s / a;
-            ft = s;
-        } else {                                                     // nodes.py:250-252
-            ve = s;
-            const float s2 = s * s;
-            const float den = 1.0f + s2;
-            abt = 1.0f / den;
-            const float b = 1.0f - abt;
-            const float sb = sqrtf(b), sa = sqrtf(abt);
-            const float sden = sb + sa;
-            ft = sb / sden;
-        }
-        times[r] = ve;
-        times[rows + r] = abt;
-        times[2 * rows + r] = ft;
-        sum_sigma = sum_sigma + s;
-        const float oma = 1.0f - abt;
-        sum_oma = sum_oma + oma;
-    }
-    const float mean_sigma = sum_sigma / static_cast<float>(rows);
-    int best = 0;
-    float best_d = INFINITY;
-    for (int i = 0; i < schedule_len; ++i) {                         // first minimum, like torch.argmin
-        const float diff = schedule[i] - mean_sigma;
-        const float dd = fabsf(diff);
-        if (dd < best_d) {
-            best_d = dd;
-            best = i;
-        }
-    }
-    const float frac = sum_oma / static_cast<float>(rows);
-    scalars[0] = static_cast<float>(best);
-    scalars[1] = frac;
-    if (rule.valid_out) {
-        const int32_t n_eff = effective_inner_steps(rule.n_steps, static_cast<double>(static_cast<float>(best)),
-                                                    static_cast<double>(frac), rule.total_steps, rule.early_stop,
-                                                    rule.min_step_frac);
-        *rule.valid_out = (rule.guess < 0 || rule.guess == n_eff) ? 1ull : 0ull;
-        scalars[3] = static_cast<float>(n_eff);            // (word 2 of the mailbox is the sequence number)
-    }
-    if (seq_out) {       // mailbox in pinned host memory: the sequence number lands after the two scalars
-        __threadfence_system();
-        __hip_atomic_store(seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    sigma_rows_and_rule(sigma, rows, schedule, schedule_len, is_flow != 0, times, scalars, seq_out, seq, rule);
 }
 
 int sigma_times_rule_dispatch(const float* sigma, int rows, const float* schedule, int schedule_len, int is_flow,

@@ -188,13 +188,32 @@ int lp_node_call(lp_node_call_desc* c, void* stream) {
     c->speculated = speculate ? 1 : 0;
     c->hit = 0;
     c->launched = 0;
-    int rc = lp::sigma_times_rule_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
+    int rc = LP_OK;
+    // On a speculated call the answer is only a confirmation, so its arriving a little later costs nothing: the sigma
+    // algebra rides in the replace launch (LP_PH_SIGMA) instead of a launch of its own.  Otherwise the small kernel goes
+    // first -- its answer is what the host is waiting for.
+    const bool fold_sigma = speculate && c->replace->phases == (LP_PH_REPLACE | LP_PH_EMIT | LP_PH_COEFFS) &&
+                            (c->replace->flags & LP_FL_MASK_BITS) && !c->replace->corr_el && !c->replace->es_reset &&
+                            c->replace->replace_kind != LP_REPLACE_KNOWN && c->is_flow == ((c->replace->flags & LP_FL_FLOW) ? 1 : 0) &&
+                            c->rows == c->replace->rows && c->fold_sigma;
+    if (fold_sigma) {
+        lp_step_desc d = *c->replace;
+        d.phases |= LP_PH_SIGMA;
+        d.sg_sigma = c->sigma; d.sg_schedule = c->schedule; d.sg_schedule_len = c->schedule_len; d.sg_times_out = c->times_out;
+        d.sg_scalars_out = c->scalars_out; d.sg_seq_out = c->seq_out; d.sg_seq = c->seq; d.sg_valid_out = c->valid_word;
+        d.sg_n_steps = c->n_steps; d.sg_early_stop = c->early_stop; d.sg_total_steps = c->total_steps; d.sg_guess = c->guess;
+        d.sg_min_step_frac = c->min_step_frac;
+        rc = lp::step_dispatch(&d, s, nullptr);
+        if (rc != LP_OK) return rc;
+    } else {
+        rc = lp::sigma_times_rule_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
                                            c->scalars_out, c->seq_out, c->seq, c->n_steps, c->early_stop, c->total_steps,
                                            c->min_step_frac, speculate ? c->guess : -1, c->valid_word, s);
-    if (rc != LP_OK) return rc;
-    if (c->replace) {                        // the part of the call that does not depend on the answer: queued before the wait
-        rc = lp::step_dispatch(c->replace, s, nullptr);
         if (rc != LP_OK) return rc;
+        if (c->replace) {                    // the part of the call that does not depend on the answer: queued before the wait
+            rc = lp::step_dispatch(c->replace, s, nullptr);
+            if (rc != LP_OK) return rc;
+        }
     }
     if (speculate && hipGraphLaunch(exec_for(c->guess), s) != hipSuccess) return LP_E_LAUNCH;
     rc = node_wait(c, c->seq, s);

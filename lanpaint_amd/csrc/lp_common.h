@@ -497,6 +497,88 @@ __device__ __forceinline__ void wave_sum_dpp(T (&v)[N]) {
     dpp_level<0x143, 0xc>(v);     // row_bcast 31 into rows 2 and 3: lane 63 = the wave's sum
 }
 
+// sigma -> (VE sigma, abt, flow t), nodes.py:243-245 / :250-252, every operation rounded on its own like the reference's
+// eager fp32 tensor ops (an FMA here could flip a round() in the n_eff rule).  ONE source for lp_sigma_times_kernel and
+// the LP_PH_SIGMA form of the replace launch.
+__device__ __forceinline__ void sigma_to_times(float s, bool is_flow, float& ve, float& abt, float& ft) {
+#pragma clang fp contract(off)
+    if (is_flow) {
+        const float a = 1.0f - s;
+        const float a2 = a * a;
+        const float s2 = s * s;
+        const float den = a2 + s2;
+        abt = a2 / den;
+        ve = s / a;
+        ft = s;
+    } else {
+        ve = s;
+        const float s2 = s * s;
+        const float den = 1.0f + s2;
+        abt = 1.0f / den;
+        const float b = 1.0f - abt;
+        const float sb = sqrtf(b), sa = sqrtf(abt);
+        const float sden = sb + sa;
+        ft = sb / sden;
+    }
+}
+
+// What thread 0 of lp_sigma_times_kernel (or of the first block of an LP_PH_SIGMA replace launch) does after the rows:
+// the two scalars of the inner-step rule, the rule against a speculated count, the mailbox.
+struct SigmaRule {
+    int32_t n_steps, early_stop, total_steps, guess;       // guess < 0: not speculating (the word is set to 1)
+    double min_step_frac;
+    uint64_t* valid_out;                                   // device word, or nullptr: no rule on the device
+};
+
+__host__ __device__ inline int32_t effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps,
+                                                         int32_t early_stop, double min_step_frac);
+
+__device__ __forceinline__ void sigma_rows_and_rule(const float* __restrict__ sigma, int rows, const float* __restrict__ schedule,
+                                                    int schedule_len, bool is_flow, float* __restrict__ times,
+                                                    float* __restrict__ scalars, int32_t* __restrict__ seq_out, int32_t seq,
+                                                    const SigmaRule& rule) {
+#pragma clang fp contract(off)
+    float sum_sigma = 0.0f, sum_oma = 0.0f;
+    for (int r = 0; r < rows; ++r) {
+        const float s = sigma[r];
+        float ve, abt, ft;
+        sigma_to_times(s, is_flow, ve, abt, ft);
+        if (times) {
+            times[r] = ve;
+            times[rows + r] = abt;
+            times[2 * rows + r] = ft;
+        }
+        sum_sigma = sum_sigma + s;
+        const float oma = 1.0f - abt;
+        sum_oma = sum_oma + oma;
+    }
+    const float mean_sigma = sum_sigma / static_cast<float>(rows);
+    int best = 0;
+    float best_d = INFINITY;
+    for (int i = 0; i < schedule_len; ++i) {                         // first minimum, like torch.argmin
+        const float diff = schedule[i] - mean_sigma;
+        const float dd = fabsf(diff);
+        if (dd < best_d) {
+            best_d = dd;
+            best = i;
+        }
+    }
+    const float frac = sum_oma / static_cast<float>(rows);
+    scalars[0] = static_cast<float>(best);
+    scalars[1] = frac;
+    if (rule.valid_out) {
+        const int32_t n_eff = effective_inner_steps(rule.n_steps, static_cast<double>(static_cast<float>(best)),
+                                                    static_cast<double>(frac), rule.total_steps, rule.early_stop,
+                                                    rule.min_step_frac);
+        *rule.valid_out = (rule.guess < 0 || rule.guess == n_eff) ? 1ull : 0ull;
+        scalars[3] = static_cast<float>(n_eff);            // (word 2 of the mailbox is the sequence number)
+    }
+    if (seq_out) {       // mailbox in pinned host memory: the sequence number lands after the scalars
+        __threadfence_system();
+        __hip_atomic_store(seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // The inner-step rule of KSamplerX0Inpaint.__call__ (nodes.py:286-299 + min_step_frac_effective_steps, :134-144) as Python
 // evaluates it: int(step) compare, then doubles and round-half-even.  ONE source for the host (lp_node_call) and the device
 // (lp_sigma_times_kernel, which checks a speculated count): n * frac is exact in double (a 24-bit by a 31-bit integer

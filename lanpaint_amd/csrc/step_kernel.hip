@@ -475,16 +475,33 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         // lp_coeffs folded into the replace launch: every block derives the two row scalars its own work needs
         // (same expressions as the table's), lanes 0..3 of the row's first block build the table for the
         // launches that follow
-        const float abt_f = d.t_abt[static_cast<int64_t>(row) * d.t_abt_stride];
-        const float ve_f = d.t_ve ? d.t_ve[static_cast<int64_t>(row) * d.t_ve_stride] : 0.0f;
-        const float rs_f = d.t_rsig ? d.t_rsig[static_cast<int64_t>(row) * d.t_rsig_stride] : 0.0f;
+        float abt_f, ve_f, rs_f, tm_sig = 0.0f;
+        constexpr bool fold_sigma = (PH & LP_PH_SIGMA) != 0;
+        if constexpr (fold_sigma) {
+            // LP_PH_SIGMA: the times of this row straight from sigma (what lp_sigma_times would have written to t_ve / t_abt /
+            // t_model; the replace sigma IS sigma); thread 0 of the first block also does that kernel's single-thread part --
+            // the rule's two scalars, the rule against the speculated count, the mailbox
+            float ft;
+            rs_f = d.sg_sigma[row];
+            sigma_to_times(rs_f, flow, ve_f, abt_f, ft);
+            tm_sig = flow ? ft : ve_f;
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+                const SigmaRule rule{d.sg_n_steps, d.sg_early_stop, d.sg_total_steps, d.sg_guess, d.sg_min_step_frac, d.sg_valid_out};
+                sigma_rows_and_rule(d.sg_sigma, d.rows, d.sg_schedule, d.sg_schedule_len, flow, d.sg_times_out, d.sg_scalars_out,
+                                    d.sg_seq_out, d.sg_seq, rule);
+            }
+        } else {
+            abt_f = d.t_abt[static_cast<int64_t>(row) * d.t_abt_stride];
+            ve_f = d.t_ve ? d.t_ve[static_cast<int64_t>(row) * d.t_ve_stride] : 0.0f;
+            rs_f = d.t_rsig ? d.t_rsig[static_cast<int64_t>(row) * d.t_rsig_stride] : 0.0f;
+        }
         rc.scale = row_scale(flow, abt_f, ve_f);
         rc.rsigma = rs_f;
         if (blockIdx.x == 0 && threadIdx.x < 4) {
             lp_hyper h;
             h.lambda = d.lambda; h.beta = d.beta; h.step_size = d.step_size; h.min_step_frac = d.min_step_frac;
             h.is_flow = flow ? 1 : 0; h.one_plus_lambda = d.one_plus_lambda;
-            const float tm_f = d.t_model ? d.t_model[static_cast<int64_t>(row) * d.t_model_stride] : 0.0f;
+            const float tm_f = fold_sigma ? tm_sig : (d.t_model ? d.t_model[static_cast<int64_t>(row) * d.t_model_stride] : 0.0f);
             const float step = d.step_size * fmaxf(1.0f - abt_f, d.min_step_frac);                 // lanpaint.py:81
             coeffs_lane(h, abt_f, ve_f, rs_f, tm_f, step, (threadIdx.x >> 1) & 1, threadIdx.x & 1,
                         d.coef_out + static_cast<int64_t>(row) * LP_COEF_STRIDE);
@@ -1211,6 +1228,8 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     if (d.phases == (R | E | LP_PH_COEFFS))                                          // replace step + the coefficient table
         return hard ? launch<VEC, MODE_HARD, R | E | LP_PH_COEFFS>(d, stream, timer)
                     : launch<VEC, MODE_ROW, R | E | LP_PH_COEFFS>(d, stream, timer);
+    if (d.phases == (R | E | LP_PH_COEFFS | LP_PH_SIGMA))                            // ... + the sigma algebra of the call (bit mask only)
+        return launch<VEC, MODE_HARD, R | E | LP_PH_COEFFS | LP_PH_SIGMA>(d, stream, timer);
     const bool rng_torch = d.rng_kind == LP_RNG_TORCH;
     // ATen's element-to-thread layout pays off when a Philox block really serves several elements of this tensor
     // (batch rows: as long as a row covers at least half a round most lanes still use two or more values of their block)
@@ -1249,13 +1268,23 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     if ((d.flags & LP_FL_MASK_BITS) && ((d.flags & (LP_FL_MASK_U8 | LP_FL_MASK_DENOISE)) || !aligned(d.mask, 4)))
         return LP_E_INVALID;
     const uint32_t ph = d.phases;
-    if (ph == 0 || (ph & ~0x3fu)) return LP_E_INVALID;
+    if (ph == 0 || (ph & ~0x7fu)) return LP_E_INVALID;
+    if (ph & LP_PH_SIGMA) {        // only on the fused replace launch of a row-table call with a bit-packed mask
+        if (ph != (LP_PH_REPLACE | LP_PH_EMIT | LP_PH_COEFFS | LP_PH_SIGMA) || !(d.flags & LP_FL_MASK_BITS) || d.corr_el ||
+            d.replace_kind == LP_REPLACE_KNOWN)
+            return LP_E_INVALID;
+        if (!d.sg_sigma || !d.sg_schedule || d.sg_schedule_len <= 0 || !d.sg_scalars_out) return LP_E_INVALID;
+        if (d.es_reset) return LP_E_UNSUPPORTED;      // (the early-stop reset reads abt from t_abt, which this launch only writes)
+    }
     if (d.rng_kind != LP_RNG_PHILOX && d.rng_kind != LP_RNG_TORCH) return LP_E_INVALID;
     if (d.rng_kind == LP_RNG_TORCH && (d.rng_bg == 0 || (d.rng_inc & 3u) || d.rng_inc == 0)) return LP_E_INVALID;
     if (ph & LP_PH_COEFFS) {       // only as the fused replace launch of a row-table call
-        if (ph != (LP_PH_REPLACE | LP_PH_EMIT | LP_PH_COEFFS) || (d.flags & LP_FL_PER_ELEMENT)) return LP_E_INVALID;
-        if (!d.t_abt || !d.coef_out || (!(d.flags & LP_FL_FLOW) && !d.t_ve)) return LP_E_INVALID;
-        if (d.replace_kind != LP_REPLACE_KNOWN && !d.t_rsig) return LP_E_INVALID;
+        if ((ph & ~LP_PH_SIGMA) != (LP_PH_REPLACE | LP_PH_EMIT | LP_PH_COEFFS) || (d.flags & LP_FL_PER_ELEMENT)) return LP_E_INVALID;
+        if (!d.coef_out) return LP_E_INVALID;
+        if (!(ph & LP_PH_SIGMA)) {
+            if (!d.t_abt || (!(d.flags & LP_FL_FLOW) && !d.t_ve)) return LP_E_INVALID;
+            if (d.replace_kind != LP_REPLACE_KNOWN && !d.t_rsig) return LP_E_INVALID;
+        }
     }
     if ((ph & LP_PH_POST_FIRST) && (ph & LP_PH_POST_STEADY)) return LP_E_INVALID;
     if ((ph & LP_PH_REPLACE) && (ph & (kPost | LP_PH_PRE_HALF))) return LP_E_INVALID;

@@ -382,6 +382,7 @@ class KSamplerX0Inpaint:
                 if nd is None:
                     nd = self._node_desc = _cabi.LpNodeCallDesc()
                     nd.spin_limit = 200000
+                    nd.fold_sigma = int(os.environ.get("LANPAINT_AMD_FOLD_SIGMA", "1") != "0")
                 nd.sigma, nd.rows, nd.schedule, nd.schedule_len = sig_c.data_ptr(), rows, sc[2], sc[3]
                 nd.is_flow, nd.seq, nd.times_out = int(bool(IS_FLUX or IS_FLOW)), fused_seq, buf.data_ptr()
                 nd.scalars_out, nd.seq_out = mb.data_ptr(), mb.data_ptr() + 8

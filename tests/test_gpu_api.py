@@ -637,9 +637,11 @@ def test_nan_in_the_head_an_element_does_not_read_stays_out_of_it(bits):
     np.testing.assert_array_equal(op, oc)
 
 
-@pytest.mark.parametrize("rng", ["torch", "philox"])
-def test_speculated_inner_step_counts_that_miss_leave_no_trace(rng):
-    """lp_node_call queues a sigma call for a GUESSED inner-step count; the device checks the guess and voids the run on a
+@pytest.mark.parametrize("rng,shape", [("torch", (1, 4, 16, 16)), ("philox", (1, 4, 16, 16)), ("torch", (1, 4, 368, 368))],
+                         ids=["torch", "philox", "torch_16B_lanes"])
+def test_speculated_inner_step_counts_that_miss_leave_no_trace(rng, shape):
+    """lp_node_call queues a sigma call for a GUESSED inner-step count -- the sigma algebra riding in the replace launch
+    (LP_PH_SIGMA; one element and four per lane) -- the device checks the guess and voids the run on a
     miss, then the call is queued again.  A Heun-like order (every sigma evaluated twice) makes half the guesses wrong until
     guessing turns itself off: the results must equal a run that never guesses (LANPAINT_AMD_SPECULATE=0) bit for bit -- x,
     every denoised, the torch generator (rng="torch") and the replayed Philox counter (rng="philox": same noise in both runs)."""
@@ -647,7 +649,7 @@ def test_speculated_inner_step_counts_that_miss_leave_no_trace(rng):
     import torch
     from lanpaint_amd import LanPaint
     from lanpaint_amd import nodes
-    shape, n_think = (1, 4, 16, 16), 5
+    n_think = 5
     sig = gc.karras_sigmas(10, 0.05, 12.0)
     rs = np.random.default_rng(4)
     y = rs.standard_normal(shape, dtype=np.float32)
