@@ -748,8 +748,10 @@ class LanPaint:
             gen = self._generator(x.device)
             off = gen.get_offset()
             k0.rng_state_val[0], k0.rng_state_val[1] = off, gen.initial_seed()
-        nd.replace, nd.exec_by_count, nd.n_counts = table[2], table[0], len(table[1])
-        nd.valid_word = self._rng_state(x.device).data_ptr() + 32
+        if getattr(nd, "_lp_table", None) is not table:     # (the table changes when a new count has been captured)
+            nd._lp_table = table
+            nd.replace, nd.exec_by_count, nd.n_counts = table[2], table[0], len(table[1])
+            nd.valid_word = self._rng_state(x.device).data_ptr() + 32
         _cabi.check(self._lib.lp_node_call(ctypes.byref(nd), stream), "lp_node_call")
         n_eff = nd.n_eff
         if not nd.launched:

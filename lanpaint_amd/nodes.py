@@ -268,6 +268,8 @@ class KSamplerX0Inpaint:
         self._mailbox = None             # pinned host float32[4]: lp_sigma_times writes {step index, mean(1-abt), seq}
         self._seq = 0
         self._node_desc = None           # LpNodeCallDesc of the one-call steady state (lp_node_call)
+        self._node_static = None         # the per-run constants last written into it
+        self._speculate = os.environ.get("LANPAINT_AMD_SPECULATE", "1") != "0"
         self._last_step = None           # schedule position of the previous call (from the device), for the next guess
         self._spec_misses = 0            # 2 = speculation is off for the run (two wrong guesses among the last four)
         self._spec_hist = []             # outcomes of the last four guesses
@@ -283,7 +285,7 @@ class KSamplerX0Inpaint:
         (one device->host copy per run) pushed through the same fp32 arithmetic as lp_sigma_times and the same rule.  A
         wrong guess is only slower, never wrong: the device voids the speculated run (lp_node_call); two misses among four
         guesses (a sampler that evaluates the model several times per step) turn guessing off for the run."""
-        if self._last_step is None or self._spec_misses >= 2 or os.environ.get("LANPAINT_AMD_SPECULATE", "1") == "0":
+        if self._last_step is None or self._spec_misses >= 2 or not self._speculate:
             return -1
         tab = self._n_eff_table
         key = (rows, flow, nd.n_steps, nd.early_stop, nd.min_step_frac)
@@ -383,12 +385,17 @@ class KSamplerX0Inpaint:
                     nd = self._node_desc = _cabi.LpNodeCallDesc()
                     nd.spin_limit = 200000
                     nd.fold_sigma = int(os.environ.get("LANPAINT_AMD_FOLD_SIGMA", "1") != "0")
-                nd.sigma, nd.rows, nd.schedule, nd.schedule_len = sig_c.data_ptr(), rows, sc[2], sc[3]
-                nd.is_flow, nd.seq, nd.times_out = int(bool(IS_FLUX or IS_FLOW)), fused_seq, buf.data_ptr()
-                nd.scalars_out, nd.seq_out = mb.data_ptr(), mb.data_ptr() + 8
-                nd.n_steps, nd.early_stop, nd.total_steps = int(pm.n_steps), int(self.LanPaint_early_stop), sc[4]
-                nd.min_step_frac = float(getattr(self, "LanPaint_min_step_frac", 1.0))
-                nd.guess = self._guess_inner_steps(nd, rows, bool(IS_FLUX or IS_FLOW))
+                # (what does not change from call to call within a run is written once)
+                static = (rows, sc[2], sc[3], bool(IS_FLUX or IS_FLOW), pm.n_steps, self.LanPaint_early_stop, sc[4],
+                          getattr(self, "LanPaint_min_step_frac", 1.0), mb)
+                if self._node_static != static:
+                    self._node_static = static
+                    nd.rows, nd.schedule, nd.schedule_len, nd.is_flow = rows, sc[2], sc[3], int(static[3])
+                    nd.scalars_out, nd.seq_out = mb.data_ptr(), mb.data_ptr() + 8
+                    nd.n_steps, nd.early_stop, nd.total_steps = int(pm.n_steps), int(self.LanPaint_early_stop), sc[4]
+                    nd.min_step_frac = float(static[7])
+                nd.sigma, nd.seq, nd.times_out = sig_c.data_ptr(), fused_seq, buf.data_ptr()
+                nd.guess = self._guess_inner_steps(nd, rows, static[3])
                 res = pm.node_call(x, self.latent_image, self.noise, sigma, self._latent_mask(denoise_mask),
                                    (VE_Sigma, abt, Flow_t), model_options, seed, nd)
                 if res is not None:

@@ -643,7 +643,7 @@ def test_speculated_inner_step_counts_that_miss_leave_no_trace(rng, shape):
     """lp_node_call queues a sigma call for a GUESSED inner-step count -- the sigma algebra riding in the replace launch
     (LP_PH_SIGMA; one element and four per lane) -- the device checks the guess and voids the run on a
     miss, then the call is queued again.  A Heun-like order (every sigma evaluated twice) makes half the guesses wrong until
-    guessing turns itself off: the results must equal a run that never guesses (LANPAINT_AMD_SPECULATE=0) bit for bit -- x,
+    guessing turns itself off: the results must equal a run that never guesses (LANPAINT_AMD_SPECULATE=0, read when the callable is built) bit for bit -- x,
     every denoised, the torch generator (rng="torch") and the replayed Philox counter (rng="philox": same noise in both runs)."""
     import os
     import torch
