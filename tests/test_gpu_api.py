@@ -422,7 +422,7 @@ def test_ksampler_x0_inpaint_matches_the_reference_sampler_callable(name):
 
 
 @pytest.mark.parametrize("flow,inference", [(False, False), (True, False), (False, True)])
-def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference):
+def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference, monkeypatch):
     """(`inference`: the whole run inside torch.inference_mode(), as ComfyUI executes its nodes -- inference tensors
     do not track `_version`, which the per-tensor caches of the engine and the sampler callable used to read.)
     The replayed node path (replace step enqueued before the host knows n_eff, mailbox read, graph picked
@@ -447,6 +447,7 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
             return 0.9 * x, 0.8 * x
 
     import contextlib
+    monkeypatch.delenv("LANPAINT_AMD_SPECULATE", raising=False)      # (this test is about the default: guessing on)
     res = {}
     for graph in (False, True):
       with (torch.inference_mode() if inference else contextlib.nullcontext()):
