@@ -186,6 +186,7 @@ def run_gpu(args):
         # RCCL refuses two ranks on one device ("Duplicate GPU detected"): a box with fewer GPUs than ranks can only
         # rehearse the N > 1 path over gloo.  The line says so (dist.backend / dist.backend_requested).
         backend = "gloo"
+    numa = lpd.bind_to_device_numa(dev_index) if (world > 1 and not args.no_numa_bind) else None
     lpd.init(backend, dev)                              # "nccl" IS RCCL on ROCm; no-op at world size 1
 
     # Per-dispatch event timing of the dominant kernel, taken FIRST in the process: the same burst repeated after
@@ -264,7 +265,7 @@ def run_gpu(args):
     # collective backend really carried `world` ranks and that each of them ran the full K steps)
     dist_info = lpd.gather_rank_reports({
         "rank": rank, "device": f"cuda:{dev_index}", "device_name": torch.cuda.get_device_name(dev),
-        "pci_bus_id": _pci_bus_id(dev_index), "pid": os.getpid(), "steps": args.steps, "iterations": int(iters_local),
+        "pci_bus_id": _pci_bus_id(dev_index), "numa": numa, "pid": os.getpid(), "steps": args.steps, "iterations": int(iters_local),
         "elapsed_s": elapsed, "it_s": iters_local / elapsed, "final_checksum": float(x_last.double().sum().item())})
     if dist_info is not None and rank == 0:
         dist_info.update({"backend_requested": args.dist_backend, "broadcast_bytes": bcast.get("bytes"),
@@ -1041,6 +1042,8 @@ def main():
                     help="nccl = RCCL (default).  With fewer GPUs than ranks RCCL cannot run (duplicate device) and the "
                          "ranks fall back to gloo by themselves; the line's dist.backend says which one carried the run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-numa-bind", action="store_true",
+                    help="N > 1: do not pin each rank to the CPU cores of its GPU's NUMA node")
     ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")
     ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")
     args = ap.parse_args()

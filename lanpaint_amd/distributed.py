@@ -43,6 +43,29 @@ def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -
     return dist.get_rank(), dist.get_world_size()
 
 
+def bind_to_device_numa(device_index: int) -> Optional[dict]:
+    """Keep this process on the CPU cores of the NUMA node its GPU hangs off (one process per GPU on a two-socket node:
+    a launch-bound loop notices doorbell writes and pinned-mailbox polls crossing the socket link).  Best effort --
+    sysfs layout, permissions or a container may not allow it; returns what was done ({"numa_node", "cpus"}) or None."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return {"numa_node": node, "cpus": len(allowed)}
+    except Exception:
+        return None
+
+
 def replica_seed(seed: int, rank: int) -> int:
     """Per-rank RNG seed (xi stream and initial noise): seed + rank."""
     return (int(seed) + int(rank)) & 0xFFFFFFFFFFFFFFFF
