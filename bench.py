@@ -186,7 +186,7 @@ def run_gpu(args):
         # RCCL refuses two ranks on one device ("Duplicate GPU detected"): a box with fewer GPUs than ranks can only
         # rehearse the N > 1 path over gloo.  The line says so (dist.backend / dist.backend_requested).
         backend = "gloo"
-    numa = lpd.bind_to_device_numa(dev_index) if (world > 1 and not args.no_numa_bind) else None
+    numa = lpd.bind_to_device_numa(dev_index) if not args.no_numa_bind else None
     lpd.init(backend, dev)                              # "nccl" IS RCCL on ROCm; no-op at world size 1
 
     # Per-dispatch event timing of the dominant kernel, taken FIRST in the process: the same burst repeated after
@@ -338,6 +338,7 @@ def run_gpu(args):
                    "latent_elements_per_gpu": n_el, "lambda": HYPER["Lambda"], "beta": HYPER["Beta"],
                    "step_size": HYPER["StepSize"]},
         "latent_rows_x_iterations_per_s": iters_total * b / tmax,
+        "host_binding": numa,
         "repeats": ({"values": repeat_values, "median": float(np.median(repeat_values)), "min": min(repeat_values),
                      "max": max(repeat_values), "note": f"further timed blocks of {args.steps} steps each, same bracketing"}
                     if repeat_values else None),
@@ -1043,7 +1044,7 @@ def main():
                          "ranks fall back to gloo by themselves; the line's dist.backend says which one carried the run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-numa-bind", action="store_true",
-                    help="N > 1: do not pin each rank to the CPU cores of its GPU's NUMA node")
+                    help="do not pin the process (each rank) to the CPU cores of its GPU's NUMA node")
     ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")
     ap.add_argument("--no-large-shape", action="store_true", help="skip the supplementary c5_wan-shape roofline")
     args = ap.parse_args()
