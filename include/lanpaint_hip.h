@@ -123,7 +123,7 @@ typedef struct lp_hyper {
 #define LP_FL_NO_REGION_SKIP (1u << 12) /* stream x0, x0_big and y for every element even where the bit-packed mask makes
                                           one of them unused for a whole wave (measurement / A-B switch)       */
 #define LP_FL_ES            (1u << 13) /* the POST phase of this launch also evaluates the inner early-stop rule ON THE DEVICE
-                                          (earlystop.py:238-336): per-block partial sums of the weighted MSEs (x0s against the
+                                          (earlystop.py:238-336): every block forms the sums of the weighted MSEs (x0s against the
                                           previous x0s and against the drift anchor; iteration 0: x_t after against x_t before)
                                           and adds them into the accumulator set of the iteration (es_partials);
                                           lp_step then enqueues a one-wave kernel that totals the set in a fixed order, applies

@@ -409,18 +409,18 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     bool es_gated = false, es_idle = false;
     int es_prev = -1, es_anchor = -1, es_write = 0;
     bool es_keeper = false;
-    // folded decision: what its prologue loads (state fields, the previous launch's per-block sums)
+    // folded decision: what its prologue loads (state fields, the first wave's slot of the previous iteration's accumulator set)
     lp_es_state es_lite;
     uint2 es_words[8];
     double es_fv[kEsSums] = {0., 0., 0., 0., 0., 0.};
     if constexpr (ES) {
         es_gated = (fl & LP_FL_ES_GATED) != 0;
         if constexpr (es_fold) {
-            // Folded decision (latency-bound sizes): launch i first applies the stop rule of iteration i - 1 -- every
-            // block reduces the previous launch's per-block sums itself (same fixed order -> same bits in every
-            // block) and steps the state in registers; block 0 stores it.  The state ping-pongs between two slots
-            // and the sums between two buffers, so nobody reads what a neighbour block of the same launch writes.
-            // This replaces a one-block kernel between every two launches: ~5 us per iteration at SDXL size.
+            // Folded decision: launch i first applies the stop rule of iteration i - 1 -- every block totals the
+            // previous iteration's accumulator set itself (64 slots, same fixed order -> same bits in every block) and
+            // steps the state in registers; block 0 stores it.  The state ping-pongs between two slots and the sums
+            // rotate through three sets, so nobody reads what a neighbour block of the same launch writes.
+            // This replaces a decision kernel between every two launches: ~5 us per iteration at SDXL size.
             // Everything the verdict needs is only LOADED here; it is formed after the operand loads of the step have
             // been issued as well (below, behind the Philox rounds), so the launch pays one memory round trip where a
             // verdict-first order pays three (state -> sums -> the x0s buffers the verdict selects).

@@ -160,7 +160,7 @@ class _Workspace:
 
 class _DeviceStop:
     """Buffers of the inner early stop evaluated on the device (LP_FL_ES): the lp_es_state, three rotating x0s
-    buffers, the per-block partial sums and the pinned-host mailbox the deciding block posts its trace records to."""
+    buffers, the accumulator sets the blocks add their sums into and the pinned-host mailbox the trace records go to."""
 
     def __init__(self, like: torch.Tensor, n_steps: int):
         dev = like.device
