@@ -189,11 +189,6 @@ __device__ __forceinline__ void load_f32(const float* __restrict__ p, int64_t i,
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + i));
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
-    } else if constexpr (V == 8) {       // eight elements per lane (half-width heads at streaming sizes): two 16-byte accesses
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + i));
-        const f4 u = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + i + 4));
-        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; o[4] = u.x; o[5] = u.y; o[6] = u.z; o[7] = u.w;
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k) o[k] = p[i + k];
@@ -208,11 +203,6 @@ __device__ __forceinline__ void store_f32(float* __restrict__ p, int64_t i, cons
         typedef float f4 __attribute__((ext_vector_type(4)));
         f4 t = {v[0], v[1], v[2], v[3]};
         __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p + i));
-    } else if constexpr (V == 8) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        f4 t = {v[0], v[1], v[2], v[3]}, u = {v[4], v[5], v[6], v[7]};
-        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p + i));
-        __builtin_nontemporal_store(u, reinterpret_cast<f4*>(p + i + 4));
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k) p[i + k] = v[k];
@@ -228,7 +218,6 @@ struct Raw {
     uint32_t w[V];
 };
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
 template <int V>
 __device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, int64_t i, Raw<V>& r) {
@@ -242,9 +231,6 @@ __device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, int
         if constexpr (V == 4) {      // streaming data like the fp32 path: non-temporal (round 3; bf16 heads past L3)
             const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2*>(q));
             r.w[0] = t.x; r.w[1] = t.y;
-        } else if constexpr (V == 8) {   // 16 bytes per lane on the half-width streams too
-            const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4*>(q));
-            r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w;
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) r.w[k] = q[k];
@@ -280,9 +266,6 @@ __device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V]) 
         uint16_t h[V];
         if constexpr (V == 4) {
             h[0] = r.w[0] & 0xffffu; h[1] = r.w[0] >> 16; h[2] = r.w[1] & 0xffffu; h[3] = r.w[1] >> 16;
-        } else if constexpr (V == 8) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { h[2 * k] = r.w[k] & 0xffffu; h[2 * k + 1] = r.w[k] >> 16; }
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) h[k] = static_cast<uint16_t>(r.w[k]);
@@ -336,11 +319,6 @@ __device__ __forceinline__ void store_any(void* __restrict__ p, int dt, int64_t 
             u2 t;
             t.x = h[0] | (uint32_t(h[1]) << 16); t.y = h[2] | (uint32_t(h[3]) << 16);
             __builtin_nontemporal_store(t, reinterpret_cast<u2*>(q));
-        } else if constexpr (V == 8) {
-            u4 t;
-            t.x = h[0] | (uint32_t(h[1]) << 16); t.y = h[2] | (uint32_t(h[3]) << 16);
-            t.z = h[4] | (uint32_t(h[5]) << 16); t.w = h[6] | (uint32_t(h[7]) << 16);
-            __builtin_nontemporal_store(t, reinterpret_cast<u4*>(q));
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) q[k] = h[k];

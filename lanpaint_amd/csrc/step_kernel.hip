@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         // In a mixed wave (mask edges, fine-grained masks) each LANE still leaves out the stream none of its four elements
         // reads: the loads run under the lanes' predicate, and a 128-byte line no active lane touches is not fetched
         // (eight lanes = 32 consecutive elements of one region; 50 % box on 1.2 GB: -7 %, disc -4 %).
-        constexpr bool RA = HARD && (VEC == 4 || VEC == 8) && !ST && (PH & kPost) != 0;
+        constexpr bool RA = HARD && VEC == 4 && !ST && (PH & kPost) != 0;
         bool need_x0 = true, need_known = true;
         bool lane_x0 = true, lane_known = true;
         if constexpr (PER_EL) {
@@ -583,12 +583,11 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         if ((ph & LP_PH_POST_STEADY) || ((ph & LP_PH_PRE_HALF) && !post)) load_f32<VEC>(d.C, i, cv);
         if constexpr (RA) {
             if (!given && d.x0_big != d.x0 && !(fl & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP))) {   // (HARD: no corr_el)
-                constexpr uint32_t kAll = (1u << VEC) - 1u;
-                const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & kAll;   // this lane's VEC mask bits
+                const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;   // this lane's 4 mask bits
                 need_known = __ballot(nib != 0u) != 0ull;
-                need_x0 = __ballot(nib != kAll) != 0ull;
+                need_x0 = __ballot(nib != 0xFu) != 0ull;
                 lane_known = nib != 0u;
-                lane_x0 = nib != kAll;
+                lane_x0 = nib != 0xFu;
             }
         }
         // ST: the same decision per SLOT -- the 64 elements one wave holds in slot k are consecutive.  A slot nobody in
@@ -1334,26 +1333,8 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
     const Tune& t = tune();
     const int64_t small = t.small_elems ? t.small_elems : (512 * 1024);
     bool vec4 = can_vec4 && d.n_el > small;
-    if (t.vec == 4 || t.vec == 8) vec4 = can_vec4;
+    if (t.vec == 4) vec4 = can_vec4;
     if (t.vec == 1) vec4 = false;
-    // Eight elements per lane where the backbone's heads arrive in half precision on a streaming-size latent: the two
-    // half-width streams (and a half-width x_in) then move 16 bytes per lane like the fp32 ones instead of 8
-    // (x_wan_b16, bf16 heads: see profiles/r03_microbench_es.log).  Hot phases of the plain loop with the bit-packed mask
-    // and the Philox2x32 stream only (the torch stream has its own four-element lane layout).
-    {
-        constexpr uint32_t F = LP_PH_POST_FIRST, S = LP_PH_POST_STEADY, P = LP_PH_PRE_HALF, E = LP_PH_EMIT;
-        const bool vec8 = vec4 && t.vec != 4 && x0_half && (d.el_per_row % 8 == 0) && (d.flags & LP_FL_MASK_BITS) && !d.corr_el &&
-                          !(d.flags & (LP_FL_ES | LP_FL_PER_ELEMENT | LP_FL_X0S_GIVEN | LP_FL_WRITE_X0S)) &&
-                          d.rng_kind == LP_RNG_PHILOX && !d.xi_post && !d.xi_pre && aligned(d.x0, 16) && aligned(d.x0_big, 16) &&
-                          aligned(d.x_in, 16) && (d.n_el > 2 * small || t.vec == 8);
-        if (vec8) {
-            hipError_t e8 = hipErrorUnknown;
-            if (d.phases == (S | P | E)) e8 = launch<8, MODE_HARD, S | P | E, 2, 0>(d, stream, timer);
-            else if (d.phases == (F | P | E)) e8 = launch<8, MODE_HARD, F | P | E, 2, 0>(d, stream, timer);
-            else if (d.phases == (S | E)) e8 = launch<8, MODE_HARD, S | E, 2, 0>(d, stream, timer);
-            if (e8 != hipErrorUnknown) return e8 == hipSuccess ? LP_OK : LP_E_LAUNCH;
-        }
-    }
     const hipError_t err = vec4 ? launch_phase<4>(d, stream, timer) : launch_phase<1>(d, stream, timer);
     return err == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }

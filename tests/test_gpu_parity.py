@@ -1052,41 +1052,3 @@ def test_armed_early_stop_that_can_never_fire_runs_the_plain_loop():
                     len(mo["lanpaint_semantic_trace"])))
     assert res[0][2:] == res[1][2:] == (n, n + 1, res[0][4], 0)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-
-
-def test_eight_elements_per_lane_with_half_width_heads_equals_the_four_element_kernels():
-    """Past 1 Mi elements, bf16 backbone heads + bit-packed mask + the Philox2x32 stream run at EIGHT elements per lane (the
-    half-width streams then move 16 bytes per lane like the fp32 ones).  The same call with the fp32 mask takes the
-    four-element kernels; every mask format computes the same bits (one Philox block per element, keyed on the element), so
-    x and out must be bitwise equal -- over a first, a steady and a last iteration."""
-    import torch
-    import lanpaint_amd
-    from lanpaint_amd import LanPaint
-    shape = (1, 4, 560, 560)                         # 1 254 400 elements, rows a multiple of 8
-    torch.manual_seed(2)
-    y = torch.randn(shape, device="cuda")
-    noise = torch.randn(shape, device="cuda")
-    mask = torch.zeros(shape, device="cuda")
-    mask[..., :, :200] = 1.0
-    mask[..., 100:300, 300:500] = 1.0
-    sig = torch.tensor([1.7], device="cuda")
-    abt = 1 / (1 + sig ** 2)
-    times = (sig.clone(), abt, torch.sqrt(1 - abt) / (torch.sqrt(1 - abt) + torch.sqrt(abt)))
-
-    class Net:
-        def __init__(self):
-            self.inner_model = self
-            self.model_sampling = MODELS["linear_tuple"](flow=False).inner_model.model_sampling
-
-        def __call__(self, x, t, model_options=None, seed=None):
-            return (0.9 * x + 0.05).to(torch.bfloat16), (0.7 * x - 0.02).to(torch.bfloat16)
-
-    res = []
-    for packed in (True, False):
-        m = lanpaint_amd.pack_mask(mask.clone()) if packed else mask.clone()
-        eng = LanPaint(Net(), 3, 15.0, 5.0, 1.0, 0.2, rng="philox", philox_seed=9, graph=False, model_dtype=torch.bfloat16)
-        x = (y + noise * 1.7).clone()
-        out = eng(x, y, noise, sig, m, times, {}, 0)
-        res.append((x, out))
-    assert torch.isfinite(res[0][0]).all()
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
