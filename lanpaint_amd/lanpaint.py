@@ -491,7 +491,7 @@ class LanPaint:
 
     # ------------------------------------------------------------------ plumbing
     def _overridden(self, name):
-        return name in self.__dict__ or getattr(type(self), name) is not getattr(LanPaint, name)
+        return name in self.__dict__ or getattr(type(self), name) is not _OWN_METHODS[_OWN_NAMES.index(name)]
 
     def _stream(self, device):
         return raw_stream(device)
@@ -828,8 +828,11 @@ class LanPaint:
         return (self.chara_lamb, self.chara_beta, self.step_size, self.min_step_frac)
 
     def _override_state(self):
-        return (self._overridden("langevin_dynamics"), self._overridden("score_model"),
-                self._overridden("prepare_step_size"), self.IS_FLUX, self.IS_FLOW, self.model_dtype)
+        """Which of the three overridable methods are not this module's own (on the instance or on its class -- compared with
+        the functions as DEFINED here, so patching the base class itself counts too), plus the model-type switches."""
+        d, t, o = self.__dict__, type(self), _OWN_METHODS
+        return ("langevin_dynamics" in d or t.langevin_dynamics is not o[0], "score_model" in d or t.score_model is not o[1],
+                "prepare_step_size" in d or t.prepare_step_size is not o[2], self.IS_FLUX, self.IS_FLOW, self.model_dtype)
 
     def _graph_eligible(self, x, model_options, sigma, current_times):
         if not self.graph or self._graph_blocked or callable(self.rng) or self._noise_regenerated:
@@ -1701,3 +1704,8 @@ class LanPaint:
 
     def _launch_step_desc(self, d, stream):
         _cabi.check(self._lib.lp_step(ctypes.byref(d), stream), "lp_step")
+
+
+# the overridable methods as defined in this module (LanPaint._override_state / _overridden compare against these)
+_OWN_NAMES = ("langevin_dynamics", "score_model", "prepare_step_size")
+_OWN_METHODS = tuple(LanPaint.__dict__[n] for n in _OWN_NAMES)
