@@ -99,3 +99,19 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert 1024 < bench._free_port() < 65536
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "spawn_ranks(args.gpus" in src and "launch with torch.distributed.run" not in src
+
+
+@pytest.mark.timeout(300)
+def test_self_started_ranks_fail_fast_and_loudly_without_a_gpu():
+    """The launcher-less N > 1 entry point on a box with no GPU: every rank dies on its first device call; the parent must
+    come back promptly with a non-zero exit code (no hang waiting for a rendezvous that will never complete, no stray
+    children) and print no JSON line."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "stopping the other ranks" in p.stderr or "Error" in p.stderr or "error" in p.stderr

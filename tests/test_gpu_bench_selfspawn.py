@@ -60,3 +60,25 @@ def test_bench_two_ranks_without_a_launcher_rccl():
         return
     d = _check(_run("nccl"), "nccl")
     assert d["rccl_version"] and d["distinct_devices"] == 2
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The launcher form the driver documents (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`)
+    keeps working next to the self-started one: same line, `dist.launcher` says who started the ranks."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3",
+           "--warmup", "1", "--repeats", "0", "--prewarm-seconds", "0.05", "--no-cpu-baseline", "--no-large-shape"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    d = line["dist"]
+    assert line["n_gpus"] == 2 and d["world_size"] == d["ranks_reporting"] == 2 and d["launcher"] == "external"
+    assert all(r["iterations"] == 3 * line["config"]["iterations_per_step"] for r in d["per_rank"])
