@@ -552,8 +552,26 @@ def standalone_step(_cabi, workload, dev, phase=None, model_dtype=None):
         half = model_dtype == torch.bfloat16
         d.flags |= (_cabi.LP_FL_X0_BF16 | _cabi.LP_FL_XIN_BF16) if half else (_cabi.LP_FL_X0_F16 | _cabi.LP_FL_XIN_F16)
     d.rng_seed = 1
+    d.tune = tune_from_env(_cabi)
     keep = (bufs, mask, coef, sig, ve, abt)
     return d, keep, n_el
+
+
+def tune_from_env(_cabi):
+    """lp_step_desc.tune for the micro-benchmark scripts (scripts/microbench_*.py): the A/B switches used to be
+    LANPAINT_AMD_TUNE_* variables read INSIDE the library; the library no longer looks at the environment, the scripts
+    translate the same variables into the descriptor field."""
+    t = 0
+    vec = os.environ.get("LANPAINT_AMD_TUNE_VEC")
+    if vec == "1":
+        t |= _cabi.LP_TUNE_VEC1
+    elif vec == "4":
+        t |= _cabi.LP_TUNE_VEC4
+    if os.environ.get("LANPAINT_AMD_TUNE_ES_NO_DECIDE"):
+        t |= _cabi.LP_TUNE_ES_NO_DECIDE
+    if os.environ.get("LANPAINT_AMD_TUNE_ES_NO_FOLD"):
+        t |= _cabi.LP_TUNE_ES_NO_FOLD
+    return t
 
 
 def graph_burst_us_per_launch(_cabi, workload, dev, reps=200, replays=20, every_stream=False, model_dtype=None):

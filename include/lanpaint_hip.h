@@ -12,9 +12,24 @@
  *   - every function returns int: 0 = ok, <0 = LP_E_* (lp_strerror() names it).
  *     No exception crosses the boundary.
  *   - all tensor pointers are DEVICE pointers owned by the caller (torch
- *     allocations); the library allocates nothing, keeps no global state, is
- *     re-entrant, enqueues on the caller's HIP stream and never synchronises --
- *     so it is safe under hipGraph capture.
+ *     allocations).  The library allocates no device memory, keeps no global
+ *     state (it reads nothing from the environment; developer switches travel
+ *     in lp_step_desc.tune) and is re-entrant.
+ *   - every entry point ENQUEUES on the caller's HIP stream and returns without
+ *     synchronising, so it may be called while that stream is being captured
+ *     into a hipGraph -- with these exceptions, which block the calling thread
+ *     and must NOT be called on a capturing stream:
+ *       lp_node_call          polls a pinned-host mailbox for the device's answer
+ *                             and falls back to hipStreamSynchronize after
+ *                             `spin_limit` polls; it also launches hipGraphExec_t
+ *                             handles (hipGraphLaunch), which a capture refuses;
+ *       lp_replay_call        launches a hipGraphExec_t / updates a graph node's
+ *                             arguments (host-side, not capturable);
+ *       lp_timer_elapsed_ns   waits for the timed launch (hipEventSynchronize);
+ *       lp_graph_*            host-side graph surgery, no stream involved.
+ *     lp_timer_create / lp_graph_clone_tail allocate HOST-side runtime handles
+ *     (events, a graph clone) that the caller releases with lp_timer_destroy /
+ *     lp_graph_release.
  *   - tensors are dense row-major fp32 in the latent's own layout
  *     [B, C, (F), H, W] flattened: n_el = B * el_per_row.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
@@ -28,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 13
+#define LP_ABI_VERSION 14
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -253,7 +268,8 @@ typedef struct lp_step_desc {
      * lane of the launch stores io_table_val[0..1] to io_table_out[0..1] (NULL = nothing).  The engine's replace
      * launch -- the one launch of a sigma call that stays outside the graph -- publishes { address of the sampler
      * latent x (lanpaint.py:156 writes it in place), address of this call's `out` } for the captured lp_finalize
-     * (lp_final_desc.io_table), so that the caller's tensors never have to be staged through static buffers. */
+     * (lp_final_desc.io_table), so that the caller's tensors never have to be staged through static buffers.
+     * io_table_out[2] is the "this sigma call is valid" word, see io_valid below.                              */
     uint64_t*    io_table_out;
     uint64_t     io_table_val[2];
     /* Inner early stop on the device (LP_FL_ES; earlystop.py:58-336 with the default metric).                 */
@@ -288,7 +304,17 @@ typedef struct lp_step_desc {
     double       sg_min_step_frac;
     int32_t      sg_schedule_len, sg_seq, sg_n_steps, sg_early_stop, sg_total_steps, sg_guess;
     double*      clk_out;
+    uint32_t     tune;           /* LP_TUNE_*: developer switches of this launch (micro-benchmarks, A/B runs); 0 in production */
+    uint32_t     io_valid;       /* with io_table_out: 1 = this launch also stores 1 into io_table_out[2], the word whose 0 voids a
+                                    captured lp_finalize.  Every replace launch that is not part of a speculated lp_node_call sets
+                                    it, so that a speculated run which voided itself and was then abandoned (an error return) cannot
+                                    leave later replays voided; lp_node_call clears it on the launches it queues itself -- there
+                                    the sigma rule owns the word.                                                              */
 } lp_step_desc;
+#define LP_TUNE_VEC1          (1u << 0)   /* one element per lane whatever the size                                          */
+#define LP_TUNE_VEC4          (1u << 1)   /* four elements per lane whenever layout and alignment allow                      */
+#define LP_TUNE_ES_NO_DECIDE  (1u << 2)   /* LP_FL_ES: do not enqueue the one-wave decision kernel behind the launch         */
+#define LP_TUNE_ES_NO_FOLD    (1u << 3)   /* LP_FL_ES_GATED: decision kernel after every launch instead of the folded verdict */
 #define LP_CLK_STAMPS 8  /* 0 entry, 1 operand loads issued, 2 noise generated, 3 operands arrived, 4 stop verdict
                             formed, 5 arithmetic done, 6 stores issued, 7 per-block sums written                */
 

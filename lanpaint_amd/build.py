@@ -56,9 +56,6 @@ def _compile(out, extra, verbose):
     # -amdgpu-kernarg-preload-count: leading scalar / pointer kernel arguments arrive in SGPRs (csrc/step_kernel.hip)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared",
            "-mllvm", "-amdgpu-kernarg-preload-count=14",
-           # hardware fp atomics (global_atomic_add_f64) for the early-stop accumulators instead of a compare-and-swap loop;
-           # torch's device allocations are coarse-grained, where they are well defined
-           "-munsafe-fp-atomics",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     cmd += extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:

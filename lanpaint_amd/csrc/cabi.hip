@@ -1,6 +1,8 @@
 // cabi.hip -- extern "C" surface of liblanpaint_hip.so (declared in include/lanpaint_hip.h).
-// Plain pointers and sizes in, int status out; nothing is allocated, no global state,
-// every launch goes to the caller's stream and nothing here synchronises.
+// Plain pointers and sizes in, int status out; no device allocation, no global state, nothing read from the environment.
+// Every entry point enqueues on the caller's stream and returns; the ones that block the calling thread or drive graph
+// handles from the host (lp_node_call, lp_replay_call, lp_timer_elapsed_ns, lp_graph_*) are listed in the header's
+// conventions block and are not capture-safe.
 #include <cmath>
 
 #include "lp_common.h"
@@ -176,19 +178,25 @@ static int node_wait(const lp_node_call_desc* c, int32_t want, hipStream_t s) {
     return __atomic_load_n(c->seq_out, __ATOMIC_ACQUIRE) == want ? LP_OK : LP_E_LAUNCH;
 }
 
-int lp_node_call(lp_node_call_desc* c, void* stream) {
-    if (!c || !c->sigma || !c->schedule || !c->times_out || !c->scalars_out || !c->seq_out || c->rows <= 0) return LP_E_INVALID;
-    hipStream_t s = as_stream(stream);
+// lp_node_call proper.  `*queued_spec` is set once a speculated run (which may have voided itself) is in the queue.
+static int node_call_body(lp_node_call_desc* c, hipStream_t s, bool* queued_spec) {
     const auto exec_for = [&](int32_t n) -> hipGraphExec_t {
         return (c->exec_by_count && n >= 0 && n < c->n_counts) ? static_cast<hipGraphExec_t>(c->exec_by_count[n]) : nullptr;
     };
     // Speculation: with a guess for the count and the device word the captured lp_finalize checks, the WHOLE call is queued
     // before the device has said anything; the sigma kernel compares the guess with the true count and voids the run on a miss.
-    const bool speculate = c->guess >= 0 && c->valid_word && exec_for(c->guess) != nullptr && c->replace;
+    // (Not with the inner early stop captured: a voided run would still post to its host mailbox.)
+    const bool speculate = c->guess >= 0 && c->valid_word && exec_for(c->guess) != nullptr && c->replace && !c->replace->es_reset;
     c->speculated = speculate ? 1 : 0;
     c->hit = 0;
     c->launched = 0;
     int rc = LP_OK;
+    // the replace launches queued here leave the "valid" word to the sigma rule (lp_step_desc.io_valid)
+    lp_step_desc rep;
+    if (c->replace) {
+        rep = *c->replace;
+        rep.io_valid = 0;
+    }
     // On a speculated call the answer is only a confirmation, so its arriving a little later costs nothing: the sigma
     // algebra rides in the replace launch (LP_PH_SIGMA) instead of a launch of its own.  Otherwise the small kernel goes
     // first -- its answer is what the host is waiting for.
@@ -197,7 +205,7 @@ int lp_node_call(lp_node_call_desc* c, void* stream) {
                             c->replace->replace_kind != LP_REPLACE_KNOWN && c->is_flow == ((c->replace->flags & LP_FL_FLOW) ? 1 : 0) &&
                             c->rows == c->replace->rows && c->fold_sigma;
     if (fold_sigma) {
-        lp_step_desc d = *c->replace;
+        lp_step_desc d = rep;
         d.phases |= LP_PH_SIGMA;
         d.sg_sigma = c->sigma; d.sg_schedule = c->schedule; d.sg_schedule_len = c->schedule_len; d.sg_times_out = c->times_out;
         d.sg_scalars_out = c->scalars_out; d.sg_seq_out = c->seq_out; d.sg_seq = c->seq; d.sg_valid_out = c->valid_word;
@@ -205,13 +213,15 @@ int lp_node_call(lp_node_call_desc* c, void* stream) {
         d.sg_min_step_frac = c->min_step_frac;
         rc = lp::step_dispatch(&d, s, nullptr);
         if (rc != LP_OK) return rc;
+        *queued_spec = true;
     } else {
         rc = lp::sigma_times_rule_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
                                            c->scalars_out, c->seq_out, c->seq, c->n_steps, c->early_stop, c->total_steps,
                                            c->min_step_frac, speculate ? c->guess : -1, c->valid_word, s);
         if (rc != LP_OK) return rc;
+        *queued_spec = speculate;
         if (c->replace) {                    // the part of the call that does not depend on the answer: queued before the wait
-            rc = lp::step_dispatch(c->replace, s, nullptr);
+            rc = lp::step_dispatch(&rep, s, nullptr);
             if (rc != LP_OK) return rc;
         }
     }
@@ -227,6 +237,7 @@ int lp_node_call(lp_node_call_desc* c, void* stream) {
         if (c->n_eff == c->guess) {          // the queued run is the call
             c->hit = 1;
             c->launched = 1;
+            *queued_spec = false;            // (the word is 1: the rule confirmed the guess)
             return LP_OK;
         }
         // a miss: the queued run voided itself.  Queue the call again, unconditionally valid this time.
@@ -234,7 +245,8 @@ int lp_node_call(lp_node_call_desc* c, void* stream) {
                                            c->scalars_out, c->seq_out, c->seq ^ 0x40000000, c->n_steps, c->early_stop,
                                            c->total_steps, c->min_step_frac, -1, c->valid_word, s);
         if (rc != LP_OK) return rc;
-        rc = lp::step_dispatch(c->replace, s, nullptr);
+        *queued_spec = false;                // the word is 1 again from here on
+        rc = lp::step_dispatch(&rep, s, nullptr);
         if (rc != LP_OK) return rc;
     }
     if (hipGraphExec_t e = exec_for(c->n_eff)) {
@@ -242,6 +254,24 @@ int lp_node_call(lp_node_call_desc* c, void* stream) {
         c->launched = 1;
     }
     return LP_OK;
+}
+
+int lp_node_call(lp_node_call_desc* c, void* stream) {
+    if (!c || !c->sigma || !c->schedule || !c->times_out || !c->scalars_out || !c->seq_out || c->rows <= 0) return LP_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    bool queued_spec = false;
+    const int rc = node_call_body(c, s, &queued_spec);
+    if (rc != LP_OK && queued_spec && c->valid_word) {
+        // An error return with a speculated run in the queue: that run may have zeroed the word the captured lp_finalize
+        // checks, and nothing after it is going to set it again -- every later replay on this device would be voided
+        // silently.  Put the word back (best effort: the rule kernel with no guess stores 1; its mailbox sequence number is
+        // one nobody waits for).  The engine's own replace launches also store 1 (lp_step_desc.io_valid), so the next
+        // ordinary sigma call heals the word even if this launch fails too.
+        (void)lp::sigma_times_rule_dispatch(c->sigma, c->rows, c->schedule, c->schedule_len, c->is_flow, c->times_out,
+                                            c->scalars_out, c->seq_out, c->seq ^ 0x20000000, c->n_steps, c->early_stop,
+                                            c->total_steps, c->min_step_frac, -1, c->valid_word, s);
+    }
+    return rc;
 }
 
 int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n) {

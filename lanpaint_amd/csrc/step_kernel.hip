@@ -19,7 +19,6 @@
 //   overdamped scheme           lanpaint.py:274-286 (second half-step uses the OLD C)
 //   back to model space         lanpaint.py:144-147, 163, 168
 #include <cstddef>
-#include <cstdlib>
 
 #include "lp_common.h"
 
@@ -656,6 +655,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         if (d.io_table_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
             d.io_table_out[0] = d.io_table_val[0];
             d.io_table_out[1] = d.io_table_val[1];
+            if (d.io_valid) d.io_table_out[2] = 1ull;      // (not on a speculated call: there the sigma rule owns the word)
         }
         if constexpr (PH == 0 || (PH & LP_PH_REPLACE) != 0) {
             if (d.es_reset && d.es && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -1027,7 +1027,9 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                         p3 = es_part[3][threadIdx.x];
             const float v = ((p0 + p1) + p2) + p3;                  // the block's sum, fp32, fixed order
             double* acc = es_acc_set(d, d.es_index) + static_cast<size_t>(blk % kEsSlots) * 8 + threadIdx.x;
-            (void)__hip_atomic_fetch_add(acc, static_cast<double>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // unsafeAtomicAdd: the hardware global_atomic_add_f64 for THIS add only (no compare-and-swap loop), instead of
+            // building the whole library with -munsafe-fp-atomics; well defined on torch's coarse-grained device allocations
+            (void)unsafeAtomicAdd(acc, static_cast<double>(v));
         }
         // the set of the iteration after this one starts from zero (nobody reads or adds to it during this launch)
         if (blk == 0 && threadIdx.x >= kWave) {
@@ -1072,24 +1074,8 @@ struct Timer {
     hipEvent_t start, stop;
 };
 
-struct Tune {
-    int vec = 0;              // 0 = automatic
-    bool es_no_decide = false, es_no_fold = false;
-    int64_t small_elems = 0;
-    Tune() {
-        // developer knobs for the micro-benchmarks (scripts/microbench_step.py); not an API
-        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_VEC")) vec = std::atoi(e);
-        if (const char* e = std::getenv("LANPAINT_AMD_TUNE_SMALL")) small_elems = std::atoll(e);
-        es_no_decide = std::getenv("LANPAINT_AMD_TUNE_ES_NO_DECIDE") != nullptr;
-        es_no_fold = std::getenv("LANPAINT_AMD_TUNE_ES_NO_FOLD") != nullptr;
-    }
-};
-
-static const Tune& tune() {
-    static const Tune t;
-    return t;
-}
-
+// Developer switches of a launch (lp_step_desc.tune, LP_TUNE_*): the micro-benchmarks A/B launch geometries and the two
+// early-stop layouts through the descriptor.  The library reads nothing from the environment and keeps no process-wide state.
 // ST launches: blockIdx.y = round * per_round + j, j-th batch row crossing that round of 4 bg elements (at most
 // ceil(4 bg / el_per_row) + 1 of them, never more than there are rows); 0 = not representable
 static unsigned st_segments(const lp_step_desc& d) {
@@ -1108,6 +1094,7 @@ static unsigned st_segments(const lp_step_desc& d) {
 #ifdef LP_TRACE_INSTANTIATIONS
 }  // namespace lp
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <string>
@@ -1152,7 +1139,6 @@ static void trace_note(int vec, int mode, unsigned ph, int x0w, int rng, bool st
 
 template <int VEC, int MODE, uint32_t PH, int X0W = 0, int RNG = 2, bool ST = false, int ES = 0>
 static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
-    const Tune& t = tune();
     const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
     constexpr int block = kBlock;
     int64_t bx = (groups + block - 1) / block;
@@ -1170,7 +1156,7 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
         // (LP_FL_ES_CLOSE).  Watched (eager) loop: the host waits for every verdict, so a one-wave kernel forms it right
         // after the launch.  (The folded kernel is its own instantiation: its extra live state would cost the plain
         // early-stop launch registers it does not need.)
-        const bool fold = (d.flags & LP_FL_ES_GATED) && !t.es_no_fold;
+        const bool fold = (d.flags & LP_FL_ES_GATED) && !(d.tune & LP_TUNE_ES_NO_FOLD);
         if constexpr (PH != 0) {
             // the phase-specialised early-stop kernels exist in their folded form only (the launches a replayed loop
             // repeats); a fused-phase launch that is not folded (a tuning switch) takes the run-time-phase kernel
@@ -1183,20 +1169,23 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
             else hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, 1>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
         }
         const bool close = fold && (d.flags & LP_FL_ES_CLOSE) && d.es_index + 1 == d.es_n_steps;
-        if ((d.phases & kPost) && !t.es_no_decide && !close && (!fold || d.es_index + 1 == d.es_n_steps)) {
+        if ((d.phases & kPost) && !(d.tune & LP_TUNE_ES_NO_DECIDE) && !close && (!fold || d.es_index + 1 == d.es_n_steps)) {
             if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
             hipLaunchKernelGGL(lp_es_decide_kernel, dim3(1), dim3(kWave), 0, stream, d, fold ? (d.es_index & 1) : 0);
         }
         return hipGetLastError();
-    }
-    LP_TRACE(ES);
-    if (timer) {
-        hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, timer->start,
-                              timer->stop, 0, LP_STEP_ARGS(d));
     } else {
-        hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+        // (inside `else`: after an `if constexpr` that returns, the statements below would still be instantiated for the
+        // early-stop launches -- eight lp_step_kernel<..., ES = 1> code objects nothing ever launched, round 3)
+        LP_TRACE(ES);
+        if (timer) {
+            hipExtLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, timer->start,
+                                  timer->stop, 0, LP_STEP_ARGS(d));
+        } else {
+            hipLaunchKernelGGL((lp_step_kernel<VEC, MODE, PH, X0W, RNG, ST, ES>), grid, dim3(block), 0, stream, LP_STEP_ARGS(d));
+        }
+        return hipGetLastError();
     }
-    return hipGetLastError();
 }
 
 template <int VEC>
@@ -1330,11 +1319,9 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
                           aligned(d.xi_post, f_al) && aligned(d.xi_pre, f_al) && aligned(d.abt_el, f_al) &&
                           aligned(d.ve_el, f_al) && aligned(d.rsig_el, f_al) && aligned(d.corr_el, f_al);
     // small latents are latency bound: one element per lane puts 4x more waves on the chip
-    const Tune& t = tune();
-    const int64_t small = t.small_elems ? t.small_elems : (512 * 1024);
-    bool vec4 = can_vec4 && d.n_el > small;
-    if (t.vec == 4) vec4 = can_vec4;
-    if (t.vec == 1) vec4 = false;
+    bool vec4 = can_vec4 && d.n_el > 512 * 1024;
+    if (d.tune & LP_TUNE_VEC4) vec4 = can_vec4;
+    if (d.tune & LP_TUNE_VEC1) vec4 = false;
     const hipError_t err = vec4 ? launch_phase<4>(d, stream, timer) : launch_phase<1>(d, stream, timer);
     return err == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }

@@ -287,7 +287,12 @@ class LanPaint:
              that is cheap to enqueue (< AUTO_MAX_BACKBONE_HOST_US per call: a launch-bound loop, the
              case a graph helps) the second call with the same latent_image / mask / model_options
              objects is captured, the capture is CHECKED against an eager run of the same call
-             (rng="torch": bitwise), and from then on replayed.  A backbone that cannot be captured
+             (rng="torch" only: bitwise, from the same generator state.  rng="philox" replays draw from a
+             device-side launch counter, eager launches from a host-side one, so the two streams differ
+             by construction and a philox capture is used unchecked -- pass graph=False to keep a stateful
+             backbone eager).  The check costs one warm-up, one replay and one eager run of the call on
+             clones of x: about 3 x (n_steps + 1) extra calls into the model on that one sigma call, which
+             a call-counting backbone will see.  A backbone that cannot be captured
              (host sync inside it), that draws from torch's generator, or whose replay differs from
              eager keeps the engine eager for good, with a warning.  Expensive backbones are never
              captured: the Langevin launches are noise next to them.
@@ -752,7 +757,17 @@ class LanPaint:
             nd._lp_table = table
             nd.replace, nd.exec_by_count, nd.n_counts = table[2], table[0], len(table[1])
             nd.valid_word = self._rng_state(x.device).data_ptr() + 32
-        _cabi.check(self._lib.lp_node_call(ctypes.byref(nd), stream), "lp_node_call")
+        rc = self._lib.lp_node_call(ctypes.byref(nd), stream)
+        if rc != _cabi.LP_OK:
+            # A failed call may have left a speculated, self-voided run in the queue.  The library tries to restore the word
+            # the captured lp_finalize checks; do not rely on it: restore it from here as well (an ordinary torch write in
+            # stream order) and forget every capture of this engine, so nothing replays against half-published state.
+            try:
+                self._rng_state(x.device)[4] = 1
+            except Exception:
+                pass
+            self._forget_captures()
+            _cabi.check(rc, "lp_node_call")
         n_eff = nd.n_eff
         if not nd.launched:
             # no capture for this count yet: the ordinary path captures it (and re-enqueues the replace step, which reads
@@ -766,6 +781,15 @@ class LanPaint:
         self._iterations_run += cap.ran
         self.last_inner_steps = cap.ran
         return out, n_eff
+
+    def _forget_captures(self):
+        """Drop every captured sigma call (after a failed native call: the next call takes the full path again)."""
+        self._last_cap = None
+        for cap in self._graphs.values():
+            cap.alive = False
+            cap.node_table = None
+            cap.siblings = {}
+        self._graphs.clear()
 
     def _node_table(self, cap0, n_max, model_options):
         """hipGraphExec_t of the tail graph captured for every inner-step count 0 .. n_max of this call shape (NULL where
@@ -855,13 +879,16 @@ class LanPaint:
         be launch bound?  The first call with a new (latent_image, mask, model_options, shape) starts the record (and
         runs eagerly: its plain loop times the backbone calls); later calls of the same job ask it."""
         a = self._auto
-        if a is not None and a[0][0] is self.latent_image and a[0][1] is latent_mask and a[0][2] is model_options \
+        if a is not None and a[0][0]() is self.latent_image and a[0][1]() is latent_mask and a[0][2] == id(model_options) \
                 and a[0][3] == x.shape and a[0][4] == x.device:
             if self._es_opts is not None:
                 return False             # (the inner early stop is captured on request only: graph=True)
             return a[1] >= 1 and 1e6 * a[2] < self.AUTO_MAX_BACKBONE_HOST_US
         # [signature, eager calls seen, cheapest per-call mean of the backbone's host time so far (s)]
-        self._auto = [(self.latent_image, latent_mask, model_options, x.shape, x.device), 0, float("inf")]
+        # (weak references / an id: the record must not keep a finished job's tensors and options alive; a recycled id
+        # only means one more eager call before the capture, whose key checks the dict by identity anyway)
+        self._auto = [(weakref.ref(self.latent_image), weakref.ref(latent_mask), id(model_options), x.shape, x.device), 0,
+                      float("inf")]
         return False
 
     def _auto_capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW):
@@ -1047,7 +1074,10 @@ class LanPaint:
         counter = self._rng_state(dev)
         cap = _CapturedCall(counter)
         if replace_in_graph:
-            cap.graph = torch.cuda.CUDAGraph(keep_graph=True)      # the hipGraph_t stays: node 0 has to be found in it
+            try:
+                cap.graph = torch.cuda.CUDAGraph(keep_graph=True)  # the hipGraph_t stays: node 0 has to be found in it
+            except (TypeError, RuntimeError):                      # a torch build without `keep_graph`: the round-2 layout
+                replace_in_graph = False
         # captures that differ only in the step count (KSamplerX0Inpaint's n_eff ramp) share ONE workspace: sigma
         # calls are serialised on the stream, and the n_steps-independent replace launch can then be enqueued
         # before the count is known (begin_call / finish_call)
@@ -1326,7 +1356,7 @@ class LanPaint:
         if ws.static_io and not per_el:
             # a replayed call: its lp_finalize may be a node of the graph; this launch tells it where x and out live
             st.out = out if out is not None else torch.empty_like(xc)
-            d.io_table_out = self._rng_state(xc.device).data_ptr() + 16
+            d.io_table_out, d.io_valid = self._rng_state(xc.device).data_ptr() + 16, 1     # (word 2: "this call is valid")
             d.io_table_val[0], d.io_table_val[1] = xc.data_ptr(), st.out.data_ptr()
         # inner early stop evaluated on the device (default metric, row-table call): this launch resets the state
         st.es = None
@@ -1346,7 +1376,7 @@ class LanPaint:
             self._launch_step(stream)
         st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
         st.k0_desc = _cabi.LpStepDesc.from_buffer_copy(d) if ws.static_io else None
-        d.io_table_out = None          # the think-loop launches share this descriptor
+        d.io_table_out, d.io_valid = None, 0          # the think-loop launches share this descriptor
         d.es_reset = 0
         return st
 

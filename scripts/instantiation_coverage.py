@@ -24,11 +24,96 @@ PHASES = {1: "REPLACE", 2: "POST_FIRST", 4: "POST_STEADY", 8: "PRE_HALF", 16: "E
 
 
 def product_instantiations(lib=LIB):
-    """Template argument lists of every lp_step_kernel the host library carries a launch stub for."""
+    """Template argument lists of every lp_step_kernel the host library carries a launch stub for (nm on the host symbols)."""
     out = subprocess.run(["nm", "-C", lib], check=True, capture_output=True, text=True).stdout
     found = set()
     for m in re.finditer(r"__device_stub__lp_step_kernel<([^>]*)>", out):
         found.add(", ".join(a.strip() for a in m.group(1).split(",")))
+    return found
+
+
+# ---- the DEVICE side: what the gfx950 code objects inside the library really contain ------------------------------------
+# A host launch stub exists only for a kernel some host code names; a kernel can be instantiated on the device side without
+# one (round 3: eight lp_step_kernel<..., ES = 1> code objects came from statements behind an `if constexpr` that returned).
+# So the set is read from the code objects themselves: ELF section .hip_fatbin of the .so -> clang offload bundles -> the
+# hipv4-amdgcn-amd-amdhsa--gfx950 entries (AMDGPU ELF) -> FUNC symbols of their .symtab.  Pure Python: no ROCm tool needed.
+def _elf_sections(blob):
+    """{name: (offset, size, link, entsize)} of an ELF64 little-endian image."""
+    import struct
+    if blob[:4] != b"\x7fELF" or blob[4] != 2 or blob[5] != 1:
+        raise ValueError("not an ELF64 LE image")
+    shoff, = struct.unpack_from("<Q", blob, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", blob, 0x3A)
+    raw = []
+    for i in range(shnum):
+        name, _ty, _fl, _addr, off, size, link, _info, _al, entsize = struct.unpack_from("<IIQQQQIIQQ", blob, shoff + i * shentsize)
+        raw.append((name, off, size, link, entsize))
+    stroff = raw[shstrndx][1]
+    out = {}
+    for i, (name, off, size, link, entsize) in enumerate(raw):
+        end = blob.index(b"\0", stroff + name)
+        out.setdefault(blob[stroff + name:end].decode(), (off, size, link, entsize, i))
+    out["__by_index__"] = raw
+    return out
+
+
+def _code_objects(lib, target_prefix="hipv4-amdgcn-amd-amdhsa--gfx950"):
+    """The device ELF images bundled into `lib` for the target."""
+    import struct
+    blob = open(lib, "rb").read()
+    off, size = _elf_sections(blob)[".hip_fatbin"][:2]
+    fat = blob[off:off + size]
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    images, pos = [], fat.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from("<Q", fat, pos + len(magic))
+        p = pos + len(magic) + 8
+        for _ in range(n):
+            e_off, e_size, t_size = struct.unpack_from("<QQQ", fat, p)
+            triple = fat[p + 24:p + 24 + t_size].decode()
+            p += 24 + t_size
+            if triple.startswith(target_prefix) and e_size:
+                images.append(fat[pos + e_off:pos + e_off + e_size])
+        pos = fat.find(magic, pos + len(magic))
+    return images
+
+
+def _func_symbols(image):
+    import struct
+    sec = _elf_sections(image)
+    if ".symtab" not in sec:
+        return []
+    off, size, link, entsize = sec[".symtab"][:4]
+    stroff = sec["__by_index__"][link][1]
+    names = []
+    for i in range(size // (entsize or 24)):
+        st_name, st_info = struct.unpack_from("<IB", image, off + i * (entsize or 24))
+        if (st_info & 0xF) == 2:                                  # STT_FUNC (the kernel; its descriptor <name>.kd is an OBJECT)
+            end = image.index(b"\0", stroff + st_name)
+            names.append(image[stroff + st_name:end].decode())
+    return names
+
+
+_MANGLED = re.compile(r"^_ZN2lp14lp_step_kernelILi(\d+)ELi(\d+)ELj(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)EE")
+
+
+def device_kernels(lib=LIB):
+    """Mangled names of every kernel (FUNC symbol) in the gfx950 code objects of `lib`."""
+    names = set()
+    for image in _code_objects(lib):
+        names.update(_func_symbols(image))
+    return names
+
+
+def device_instantiations(lib=LIB):
+    """Template argument lists of every lp_step_kernel<...> the DEVICE code of `lib` contains, in the spelling of
+    product_instantiations()."""
+    found = set()
+    for name in device_kernels(lib):
+        m = _MANGLED.match(name)
+        if m:
+            v, mode, ph, x0w, rng, st, es = m.groups()
+            found.add(f"{v}, {mode}, {ph}u, {x0w}, {rng}, {'true' if st == '1' else 'false'}, {es}")
     return found
 
 
@@ -45,15 +130,18 @@ def describe(inst):
 def main():
     trace, dst = sys.argv[1], sys.argv[2]
     launched = {ln.strip() for ln in open(trace) if ln.strip()}
-    have = product_instantiations()
-    doc = {"_doc": "lp_step_kernel<%s> instantiations of liblanpaint_hip.so (nm) and the ones the GPU test suite launched "
-                   "(coverage build of the same sources, scripts/instantiation_coverage.py)" % ", ".join(FIELDS),
-           "library_bytes": os.path.getsize(LIB), "count": len(have), "launched_count": len(have & launched),
+    have, stubs = device_instantiations(), product_instantiations()
+    doc = {"_doc": "lp_step_kernel<%s> instantiations in the gfx950 code objects of liblanpaint_hip.so (read from the bundled "
+                   "device ELF images, not from the host stubs) and the ones the GPU test suite launched (coverage build of "
+                   "the same sources, scripts/instantiation_coverage.py)" % ", ".join(FIELDS),
+           "library_bytes": os.path.getsize(LIB), "count": len(have), "host_stub_count": len(stubs),
+           "device_only": sorted(have - stubs), "host_only": sorted(stubs - have),
+           "launched_count": len(have & launched),
            "instantiations": [describe(i) for i in sorted(have)],
            "launched_by_gpu_tests": sorted(have & launched), "never_launched": sorted(have - launched),
            "launched_but_not_in_library": sorted(launched - have)}
     json.dump(doc, open(dst, "w"), indent=1)
-    print(f"{len(have)} instantiations, {len(have & launched)} launched by the GPU tests, never launched: {len(have - launched)}")
+    print(f"{len(have)} device-side instantiations ({len(stubs)} host stubs, {os.path.getsize(LIB)} bytes), {len(have & launched)} launched by the GPU tests, never launched: {len(have - launched)}")
     for i in sorted(have - launched):
         print("  never launched:", i)
 

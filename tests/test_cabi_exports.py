@@ -146,9 +146,35 @@ def test_every_step_kernel_instantiation_is_launched_by_a_gpu_test(hip_lib):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_instantiation_coverage.json")))
     assert files, "no committed instantiation coverage (scripts/instantiation_coverage.py)"
     cov = json.load(open(files[-1]))
-    have = ic.product_instantiations(_cabi.LIB_PATH)
+    # the DEVICE side is the truth: a kernel can sit in the code object without a host launch stub (round 3 shipped eight)
+    have = ic.device_instantiations(_cabi.LIB_PATH)
+    stubs = ic.product_instantiations(_cabi.LIB_PATH)
+    assert have == stubs, f"device code vs host stubs: device only {sorted(have - stubs)}, host only {sorted(stubs - have)}"
     listed = {i["args"] for i in cov["instantiations"]}
     assert have == listed, f"library vs coverage file: only in library {sorted(have - listed)}, only in file {sorted(listed - have)}"
     assert cov["never_launched"] == [], cov["never_launched"]
     assert set(cov["launched_by_gpu_tests"]) == have
     assert len(have) <= 100, "the instantiation set grew past what round 3 pruned it to; prune or justify"
+
+
+def test_product_library_reads_nothing_from_the_environment(hip_lib):
+    """The header promises a library without global state: no getenv / setenv / secure_getenv among the symbols the
+    product .so imports (round 3 read LANPAINT_AMD_TUNE_* into a process-wide static; the switches now travel in
+    lp_step_desc.tune), and no LANPAINT_* variable name among its strings."""
+    import subprocess
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _cabi.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    for sym in ("getenv", "secure_getenv", "setenv", "putenv"):
+        assert not any(ln.split()[-1].split("@")[0] == sym for ln in undefined.splitlines() if ln.strip()), sym
+    blob = open(_cabi.LIB_PATH, "rb").read()
+    assert b"LANPAINT_AMD_" not in blob and b"LANPAINT_" not in blob
+
+
+def test_device_code_holds_only_the_kernels_the_sources_name(hip_lib):
+    """Every kernel in the gfx950 code objects is one of ours (lp::...), and the count of step-kernel instantiations on the
+    device equals the count of host launch stubs."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import instantiation_coverage as ic
+    kernels = ic.device_kernels(_cabi.LIB_PATH)
+    assert kernels and all(k.startswith("_ZN2lp") for k in kernels), sorted(k for k in kernels if not k.startswith("_ZN2lp"))[:5]
+    assert len(ic.device_instantiations(_cabi.LIB_PATH)) == len(ic.product_instantiations(_cabi.LIB_PATH))
