@@ -106,6 +106,19 @@ class StubBackbone:
         return heads[0], heads[1]
 
 
+def shared_conditioning(workload, device, seed=0):
+    """Synthetic stand-ins, shape and dtype right, for the conditioning tensors every replica of a job shares and rank 0
+    therefore broadcasts with the mask and the known latent at set-up: SDXL text states [1, 77, 2048] + pooled
+    / ADM vector [1, 2816]; SD1.5 [1, 77, 768]; Flux T5 states [1, 512, 4096] + CLIP pooled [1, 768]; Wan UMT5 states
+    [1, 512, 4096]; bf16.  The stub backbone does not read them -- they are there so that the one packed broadcast has the size
+    and the layout of a real job's, and every rank reports a checksum of what it received."""
+    shapes = {"c1_sd15": {"cond": (1, 77, 768)},
+              "c2_sdxl": {"cond": (1, 77, 2048), "pooled": (1, 2816)}, "c3_sdxl_b4": {"cond": (1, 77, 2048), "pooled": (1, 2816)},
+              "c4_flux": {"cond": (1, 512, 4096), "pooled": (1, 768)}}.get(workload, {"cond": (1, 512, 4096)})
+    g = torch.Generator(device="cpu").manual_seed(1000 + seed)
+    return {k: torch.randn(v, generator=g).to(torch.bfloat16).to(device) for k, v in shapes.items()}
+
+
 def temporal_known_frames(latent_frames):
     """SURVEY.md 8d, C5: an 81-frame video whose second half (pixel frames >= P // 2) is inpainted, brought to the
     latent grid as reshape_mask's video path does (nodes.py:100-122): nearest-exact frame index (ATen's fp32 formula)
@@ -168,6 +181,90 @@ def schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_th
     return x
 
 
+PARITY_TOL = 1e-5                # BASELINE.json north_star: output MSE vs the reference < 1e-5
+
+
+def _lerp_np(start, end, w):
+    """torch.lerp(start, end, w) in numpy fp32 (ATen's two-sided formula)."""
+    w = np.float32(w)
+    d = (end - start).astype(np.float32)
+    return (start + w * d).astype(np.float32) if w < 0.5 else (end - d * (np.float32(1) - w)).astype(np.float32)
+
+
+def parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow, max_sigmas=None):
+    """ONE schedule pass of the engine that is about to be timed -- same object, same launch mode (graph replay / eager),
+    same noise generator, same mask format -- in lockstep with the CPU oracle (oracle/lanpaint_oracle.py, the checker) fed
+    the very draws the engine's kernels generate:
+      rng="philox": lp_philox_normal(seed, sequence number, slot) for the sequence numbers this call's launches use (the
+                    device-side counter of a replayed loop / the host-side one of eager launches, read around the call:
+                    LanPaint.rng_position); iteration i draws slot 0 of launch i for its POST half-step and slot 1 of launch
+                    i - 1 for its PRE half-step (lanpaint.py:277,280,283);
+      rng="torch":  what torch.randn returns from the generator state the call starts in (drawn first, state restored).
+    Returns {"mse_x", "mse_denoised_max", ...}; MSE in float64 over all elements, final latent and every denoised."""
+    import ctypes
+    from lanpaint_amd import _cabi
+    from oracle.lanpaint_oracle import OracleLanPaint
+    lib, dev = _cabi.load(), x0.device
+    shape, n_el = tuple(x0.shape), x0.numel()
+    ns = len(sig_list) if max_sigmas is None else max(1, min(len(sig_list), int(max_sigmas)))
+    per_call = max(0, 2 * n_think - 1)
+    stream = lambda: torch.cuda.current_stream(dev).cuda_stream     # noqa: E731
+
+    def philox(seq, slot):
+        out = torch.empty(n_el, dtype=torch.float32, device=dev)
+        _cabi.check(lib.lp_philox_normal(out.data_ptr(), n_el, seed, seq, slot, stream()), "lp_philox_normal")
+        return out.cpu().numpy().reshape(shape)
+
+    seed = int(engine.philox_seed if engine.philox_seed is not None else 0) & 0xFFFFFFFFFFFFFFFF
+    draws = []
+    model = StubBackbone(flow)
+    oracle = OracleLanPaint(model, n_think, HYPER["Friction"], float(engine.chara_lamb), float(engine.chara_beta),
+                            float(engine.step_size), is_flow=flow, min_step_frac=float(engine.min_step_frac),
+                            randn=lambda like: draws.pop(0))
+    to_np = lambda t: t.detach().cpu().numpy()                      # noqa: E731
+    y_n, noise_n, mask_n = to_np(y), to_np(noise), to_np(mask)
+    xg, xo = x0.clone(), to_np(x0).copy()
+    worst, modes, drawn = 0.0, [], 0
+    for i in range(ns):
+        if engine.rng == "philox":
+            c0, p0 = engine.rng_position(dev)
+        else:                      # the reference's own stream: draw what the call will draw, put the generator back
+            state = torch.cuda.get_rng_state(dev)
+            draws[:] = [to_np(torch.randn(shape, device=dev)) for _ in range(per_call)]
+            after = engine.rng_position(dev)[0]
+            torch.cuda.set_rng_state(state, dev)
+        den_g = engine(xg, y, noise, sig_list[i], mask, times_list[i], None, 0, n_steps=n_think)
+        if engine.rng == "philox":
+            c1, p1 = engine.rng_position(dev)
+            if c1 != c0:           # a replayed loop: launch k drew with sequence number c0 + k
+                base, used, mode = c0, c1 - c0, "graph"
+            else:                  # eager launches: 2^48 + the host-side launch count
+                base, used, mode = (1 << 48) + p0, p1 - p0, "eager"
+            assert used == n_think, f"sigma call {i}: {used} noise-drawing launches, expected {n_think} ({mode})"
+            modes.append(mode)
+            draws[:] = [philox(base + k // 2, k % 2) for k in range(per_call)]
+        else:
+            assert engine.rng_position(dev)[0] == after, "the engine did not leave torch's generator where the reference would"
+            modes.append("torch")
+        drawn += len(draws)
+        den_o = oracle(xo, y_n, noise_n, to_np(sig_list[i]), mask_n, tuple(to_np(t) for t in times_list[i]), None, 0,
+                       n_steps=n_think)
+        assert not draws, "oracle and engine disagree on the number of draws of a sigma call"
+        worst = max(worst, float(np.mean((to_np(den_g).astype(np.float64) - den_o) ** 2)))
+        if i + 1 < len(sig_list):
+            w = float(ratios[i].reshape(-1)[0])
+            xg = torch.lerp(den_g, xg, ratios[i])
+            xo = _lerp_np(den_o, xo, w)
+    mse_x = float(np.mean((to_np(xg).astype(np.float64) - xo) ** 2))
+    ok = bool(np.isfinite(mse_x) and np.isfinite(worst) and mse_x < PARITY_TOL and worst < PARITY_TOL)
+    return {"mse_x": mse_x, "mse_denoised_max": worst, "tolerance": PARITY_TOL, "ok": ok, "sigmas_checked": ns,
+            "sigmas_in_schedule": len(sig_list), "think_iterations_checked": ns * n_think, "draws": drawn,
+            "launch_modes": {m: modes.count(m) for m in sorted(set(modes))},
+            "checker": "oracle/lanpaint_oracle.py (numpy fp32 restatement of the reference, pinned to reference-generated "
+                       "fixtures) on the draws the engine's own kernels generated, sigma call by sigma call, Euler update "
+                       "between sigmas; the engine object, launch mode, generator and mask format are the timed ones"}
+
+
 def run_gpu(args):
     import torch.distributed as dist
     from lanpaint_amd import LanPaint, _cabi
@@ -184,7 +281,14 @@ def run_gpu(args):
     backend = args.dist_backend
     if world > 1 and backend == "nccl" and n_dev < world:
         # RCCL refuses two ranks on one device ("Duplicate GPU detected"): a box with fewer GPUs than ranks can only
-        # rehearse the N > 1 path over gloo.  The line says so (dist.backend / dist.backend_requested).
+        # REHEARSE the N > 1 path over gloo, and only when asked to -- a run that was meant to measure RCCL scaling must not
+        # quietly turn into something else (the line's top-level `collective` says which library carried the run).
+        if not args.allow_gloo_fallback:
+            if rank == 0:
+                print(f"bench.py: --gpus {world} over RCCL needs {world} devices, this box has {n_dev}.  Pass --dist-backend gloo "
+                      "(or --allow-gloo-fallback) to rehearse the multi-rank path on fewer devices; no line is printed.",
+                      file=sys.stderr, flush=True)
+            raise SystemExit(4)
         backend = "gloo"
     numa = lpd.bind_to_device_numa(dev_index) if not args.no_numa_bind else None
     lpd.init(backend, dev)                              # "nccl" IS RCCL on ROCm; no-op at world size 1
@@ -211,10 +315,13 @@ def run_gpu(args):
     sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), lpd.replica_seed(args.seed, rank), dev, tt)
-    bcast = {}
-    if world > 1:      # all replicas inpaint the same image with the same mask: ONE packed RCCL broadcast at setup
-        job = lpd.broadcast_job({"mask": mask, "y": y} if rank == 0 else None, src=0, device=dev, stats=bcast)
+    bcast, cond = {}, None
+    if world > 1:      # all replicas inpaint the same image with the same mask under the same conditioning: ONE packed
+        # broadcast from rank 0 at set-up -- mask, known latent, cond tensors -- and nothing afterwards
+        job = lpd.broadcast_job(dict({"mask": mask, "y": y}, **shared_conditioning(args.workload, dev, args.seed)) if rank == 0 else None,
+                                src=0, device=dev, stats=bcast)
         mask, y = job["mask"], job["y"]
+        cond = {k: v for k, v in job.items() if k not in ("mask", "y")}
         x0 = (float(sig_np[0]) * noise + (1 - float(sig_np[0])) * y) if flow else (y + noise * float(sig_np[0]))
     if len(shape) == 5 and (args.mask or "temporal") == "temporal" and rank == 0:
         # job set-up as a workflow does it: the pixel-resolution video mask goes through reshape_mask's video path
@@ -241,6 +348,17 @@ def run_gpu(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Before anything is timed: does THIS engine, in THIS configuration, compute what the reference computes?  One schedule
+    # pass against the CPU oracle on the same draws (rank 0; bounded on the video-latent shapes, where a numpy pass over the
+    # whole schedule would take minutes).  No `value` is printed when the pass is off by more than the stated tolerance.
+    parity = None
+    if rank == 0 and not args.no_parity_check:
+        n_par = args.parity_sigmas if args.parity_sigmas > 0 else (n_sig if int(np.prod(shape)) <= 512 * 1024 else 2)
+        try:
+            parity = parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow, max_sigmas=n_par)
+        except Exception as e:
+            parity = {"ok": False, "error": repr(e)}
+
     # untimed set-up before the W warm-up steps: graph capture and lazy initialisation, then ~0.3 s of the very
     # workload so the clocks have ramped (a 1.3 ms step otherwise gets timed on a chip that is still waking up:
     # back-to-back default runs on one box read 100 k / 100 k / 112 k it/s without it)
@@ -266,11 +384,17 @@ def run_gpu(args):
     dist_info = lpd.gather_rank_reports({
         "rank": rank, "device": f"cuda:{dev_index}", "device_name": torch.cuda.get_device_name(dev),
         "pci_bus_id": _pci_bus_id(dev_index), "numa": numa, "pid": os.getpid(), "steps": args.steps, "iterations": int(iters_local),
-        "elapsed_s": elapsed, "it_s": iters_local / elapsed, "final_checksum": float(x_last.double().sum().item())})
+        "elapsed_s": elapsed, "it_s": iters_local / elapsed, "final_checksum": float(x_last.double().sum().item()),
+        "rows": int(shape[0]),
+        # what this rank holds of the shared job after the broadcast: equal on every rank, or the broadcast did not deliver
+        "shared_checksum": (float(sum(t.double().sum().item() for t in (mask, y, *(cond or {}).values()))) if world > 1 else None)})
     if dist_info is not None and rank == 0:
         dist_info.update({"backend_requested": args.dist_backend, "broadcast_bytes": bcast.get("bytes"),
                           "broadcast_ms": bcast.get("ms"), "launcher": os.environ.get("LANPAINT_BENCH_LAUNCHER", "external"),
                           "collectives_in_timed_region": 0,
+                          "shared_tensors": {k: list(v.shape) for k, v in dict({"mask": mask, "y": y}, **(cond or {})).items()},
+                          "shared_checksums_equal": len({r.get("shared_checksum") for r in dist_info["per_rank"]}) == 1,
+                          "global_rows": sum(r.get("rows", 0) for r in dist_info["per_rank"]),
                           "note": "weak scaling: every rank runs the whole workload on its own replica (seed + rank); one packed "
                                   "broadcast of mask + known latent at set-up, no collective inside the timed loop; value = "
                                   "sum of the ranks' iterations / slowest rank's time"})
@@ -322,9 +446,11 @@ def run_gpu(args):
     mask_desc = {"box": "50% box mask", "blob": "centred disc mask",
                  "temporal": f"temporal mask (second half of the video inpainted: latent frames >= "
                              f"{temporal_known_frames(shape[2]) if len(shape) == 5 else 0} after the 5-tap union)"}[kind]
+    parity_failed = parity is not None and not parity.get("ok")
     line = {
         "metric": "langevin_think_iterations_per_sec",
-        "value": iters_total / tmax,
+        "value": None if parity_failed else iters_total / tmax,
+        "parity_check": parity,
         "unit": "think-iterations/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * tmax / args.steps,
@@ -334,10 +460,14 @@ def run_gpu(args):
                                f"{n_think} think iterations, {mask_desc}, stub backbone x->(0.9x,0.8x), "
                                f"{'flow' if flow else 'VE/Karras'} schedule",
                    "rng": args.rng, "mask_format": args.mask_format, "launch": "hipGraph replay per sigma call" if args.graph else "eager launches",
-                   "replicas": args.gpus, "iterations_per_step": n_sig * n_think,
+                   "replicas": args.gpus, "rows_per_gpu": b, "global_rows": b * args.gpus, "iterations_per_step": n_sig * n_think,
                    "latent_elements_per_gpu": n_el, "lambda": HYPER["Lambda"], "beta": HYPER["Beta"],
                    "step_size": HYPER["StepSize"]},
         "latent_rows_x_iterations_per_s": iters_total * b / tmax,
+        # which library carried the ranks: "rccl" (torch.distributed "nccl" on ROCm), "gloo" (a rehearsal on fewer devices than
+        # ranks: NOT a scaling measurement), None at N = 1
+        "collective": (None if dist_info is None else ("rccl" if dist_info["backend"] == "nccl" else dist_info["backend"])),
+        "distinct_devices": (1 if dist_info is None else dist_info["distinct_devices"]),
         "host_binding": numa,
         "repeats": ({"values": repeat_values, "median": float(np.median(repeat_values)), "min": min(repeat_values),
                      "max": max(repeat_values), "note": f"further timed blocks of {args.steps} steps each, same bracketing"}
@@ -349,7 +479,12 @@ def run_gpu(args):
         "dist": dist_info,
     }
     line.update(extras)
+    if parity_failed:
+        line["error"] = ("parity_check failed: the timed configuration does not reproduce the oracle within the stated tolerance; "
+                         f"no value is reported (measured {iters_total / tmax:.1f} it/s is void)")
     emit_line(line)
+    if parity_failed:
+        raise SystemExit(3)
 
 
 def _latest_profile_json(pattern):
@@ -904,12 +1039,27 @@ def extra_lines(args, dev):
     return out
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(workload, budget_s):
-    """The CPU oracle (port of the reference engine: the same eager op chain on torch-CPU
-    fp32 tensors) on the same workload, bounded to ~budget_s seconds.  Timed at 1 thread
-    and at min(8, host CPUs) threads (the reference's tensors are tiny: more threads only
-    add fork/join cost); the faster of the two is reported, with its thread count."""
+    """The reference's CPU path next to the GPU number: the UNMODIFIED reference engine
+    -- oracle/_ref, the reference's own lanpaint.py compiled to bytecode where it lies by oracle/build_ref.py -- driven over
+    the same schedule with the same stub on this box's host cores, at 1 thread and at os.cpu_count() threads: one warm-up
+    pass discarded, median of 5 timed passes (`kind: "reference"`).  Without oracle/_ref (a checkout that never saw
+    /root/reference) the CPU port of the reference (oracle/lanpaint_oracle.py on torch-CPU tensors) stands in
+    (`kind: "port"`).  Bounded: when five passes of the whole schedule would not fit `budget_s` per thread setting the
+    sample is the first sigma calls of the schedule, and says so.  The port is timed beside the reference at 1 thread
+    (median of 3) so the ratio between the two is a number of THIS run."""
     from oracle.lanpaint_oracle import OracleLanPaint, TorchBackend
+    from oracle import ref_engine
     shape, flow, n_sig, n_think = WORKLOADS[workload]
     sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))   # noqa: E731
@@ -918,41 +1068,71 @@ def cpu_baseline(workload, budget_s):
     sig_list = [torch.full((b,), float(s), dtype=torch.float32) for s in sig_np]
     times_list = [times_from_sigma(s, flow) for s in sig_list]
     ratios = euler_ratios(sig_list, len(shape))
-    eng = OracleLanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
-                         HYPER["StepSize"], is_flow=flow, min_step_frac=HYPER["MinStepFrac"], backend=TorchBackend())
-    saved = torch.get_num_threads()
-    results = []
-    try:
-        for threads in sorted({1, min(8, os.cpu_count() or 1)}):
-            torch.set_num_threads(threads)
-            schedule_pass(eng, x0, y, noise, mask, sig_list[:3], times_list[:3], ratios[:2], n_think)   # warm-up
-            it0, t0, passes = eng.iterations_run, time.perf_counter(), 0
-            while time.perf_counter() - t0 < budget_s / 2:
-                schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
-                passes += 1
+    ref_cls = ref_engine.load_reference()
+
+    def make(kind):
+        if kind == "reference":     # the reference's own constructor (lanpaint.py:8)
+            return ref_cls(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
+                           IS_FLUX=False, IS_FLOW=flow, MinStepFrac=HYPER["MinStepFrac"])
+        return OracleLanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
+                              HYPER["StepSize"], is_flow=flow, min_step_frac=HYPER["MinStepFrac"], backend=TorchBackend())
+
+    def timed(eng, n_sigmas, passes):
+        """it/s of each of `passes` passes over the first n_sigmas sigma calls, after one discarded pass."""
+        vals = []
+        for k in range(passes + 1):
+            t0 = time.perf_counter()
+            schedule_pass(eng, x0, y, noise, mask, sig_list[:n_sigmas], times_list[:n_sigmas], ratios[:max(0, n_sigmas - 1)], n_think)
             dt = time.perf_counter() - t0
-            results.append(((eng.iterations_run - it0) / dt, threads, passes, dt))
+            if k:
+                vals.append(n_sigmas * n_think / dt)
+        return vals
+
+    kind = "reference" if ref_cls is not None else "port"
+    import warnings
+    warnings.filterwarnings("ignore", message="In CPU autocast")      # (the reference wraps its loop in torch.autocast(fp32))
+    saved = torch.get_num_threads()
+    n_cpu = os.cpu_count() or 1
+    per_threads, port_vals, sample_sigmas = {}, None, n_sig
+    try:
+        for threads in sorted({1, n_cpu}):
+            torch.set_num_threads(threads)
+            eng = make(kind)
+            per_sigma = float("inf")                            # how long is one sigma call here?  (3 calls, twice: the first
+            for _ in range(2):                                  # round also wakes the thread pool up)
+                t0 = time.perf_counter()
+                schedule_pass(eng, x0, y, noise, mask, sig_list[:3], times_list[:3], ratios[:2], n_think)
+                per_sigma = min(per_sigma, (time.perf_counter() - t0) / 3)
+            share = budget_s / 2                                # per thread setting: 1 discarded + 5 timed passes
+            n_s = n_sig if 6 * n_sig * per_sigma <= share else max(1, int(share / (6 * per_sigma)))
+            sample_sigmas = min(sample_sigmas, n_s)
+            vals = timed(eng, n_s, 5)
+            per_threads[threads] = {"median_it_s": float(np.median(vals)), "min_it_s": min(vals), "max_it_s": max(vals),
+                                    "passes": len(vals), "sigma_calls_per_pass": n_s}
+        if kind == "reference":                                 # the port beside it, 1 thread
+            torch.set_num_threads(1)
+            port_vals = timed(make("port"), per_threads[1]["sigma_calls_per_pass"], 3)
     finally:
         torch.set_num_threads(saved)
-    best = max(results)
-    detail = "; ".join(f"{t} thread(s): {v:.1f} it/s over {p} passes in {d:.1f} s" for v, t, p, d in results)
-    out = {"value": best[0], "unit": "think-iterations/s", "cores": best[1], "kind": "port",
-           "sample": f"full passes of the {workload} schedule ({n_sig} sigmas x {n_think}) with "
-                     f"oracle/lanpaint_oracle.py on torch-CPU fp32 tensors, {os.cpu_count()} host CPUs; {detail}"}
-    # the reference itself cannot travel to the GPU box; the build container timed it next to this port
-    # (scripts/cpu_ref_vs_port.py -> profiles/r*_cpu_reference_vs_port.json): quote that ratio with the number
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference_vs_port.json")))
-    if files:
-        try:
-            ref = json.load(open(files[-1]))
-            out["port_over_reference"] = ref["port_over_reference"]
-            out["reference_estimate"] = best[0] / ref["port_over_reference"]
-            out["reference_note"] = (f"unmodified reference vs this port, {ref['workload']}, 1 thread, build container "
-                                     f"({ref['cpu']}): {ref['reference_it_per_s']:.1f} vs {ref['port_it_per_s']:.1f} it/s "
-                                     f"({os.path.basename(files[-1])}); reference_estimate = value / port_over_reference")
-        except Exception:
-            pass
+    best_threads = max(per_threads, key=lambda t: per_threads[t]["median_it_s"])
+    whole = sample_sigmas == n_sig
+    detail = "; ".join(f"{t} thread(s): median {v['median_it_s']:.1f} it/s of {v['passes']} passes "
+                       f"({v['min_it_s']:.1f} .. {v['max_it_s']:.1f})" for t, v in sorted(per_threads.items()))
+    engine_desc = ("the UNMODIFIED reference engine (oracle/_ref: /root/reference/src/LanPaint/lanpaint.py compiled to "
+                   "bytecode by oracle/build_ref.py)" if kind == "reference"
+                   else "oracle/lanpaint_oracle.py (CPU port of the reference) on torch-CPU fp32 tensors -- oracle/_ref is not "
+                        "staged in this checkout")
+    out = {"value": per_threads[best_threads]["median_it_s"], "unit": "think-iterations/s", "cores": best_threads, "kind": kind,
+           "threads": {str(t): v for t, v in sorted(per_threads.items())}, "host_cpus": n_cpu, "cpu_model": _cpu_model(),
+           "sample": f"{'whole passes' if whole else f'the first {sample_sigmas} sigma calls'} of the {workload} schedule "
+                     f"({n_sig} sigmas x {n_think}), stub backbone, {engine_desc}; one warm-up pass discarded, median of 5; {detail}"}
+    if kind == "reference":
+        m = ref_engine.manifest() or {}
+        out["reference_source_sha256"] = {k: v.get("source_sha256") for k, v in m.get("modules", {}).items()}
+    if port_vals:
+        port = float(np.median(port_vals))
+        out["port_1_thread_it_s"] = port
+        out["port_over_reference"] = port / per_threads[1]["median_it_s"]
     return out
 
 
@@ -1056,11 +1236,21 @@ def main():
     ap.add_argument("--mask", default=None, choices=["box", "temporal", "blob"],
                     help="synthetic mask; default: 50 %% box for image latents, second half of the video inpainted for video latents")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="budget of the cpu_baseline leg (split between the 1-thread and the all-threads setting)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL (default).  With fewer GPUs than ranks RCCL cannot run (duplicate device) and the "
-                         "ranks fall back to gloo by themselves; the line's dist.backend says which one carried the run")
+                    help="nccl = RCCL (default).  With fewer GPUs than ranks RCCL cannot run (duplicate device): the run exits "
+                         "non-zero unless --allow-gloo-fallback (or gloo) is given; the line's top-level `collective` says which "
+                         "library carried the ranks")
+    ap.add_argument("--allow-gloo-fallback", action="store_true",
+                    help="with --dist-backend nccl on a box with fewer GPUs than ranks: carry the ranks over gloo instead of "
+                         "exiting with an error (a rehearsal of the multi-rank path, not a scaling measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip the schedule pass against the CPU oracle that precedes the timed region")
+    ap.add_argument("--parity-sigmas", type=int, default=0,
+                    help="sigma calls of the schedule the parity pass covers (0: all of them up to 512 Ki latent elements, "
+                         "the first 2 above)")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="do not pin the process (each rank) to the CPU cores of its GPU's NUMA node")
     ap.add_argument("--extras", type=int, default=1, help="1: also report node_default_schedule and with_backbone (N=1)")

@@ -362,6 +362,17 @@ class LanPaint:
     def iterations_run(self, v):
         self._iterations_run = v
 
+    def rng_position(self, device):
+        """Where the engine's own noise streams stand (checkers reproduce the draws of the next sigma call from this):
+        rng="philox": (device-side launch counter the replayed launches of this engine add to their sequence numbers -- one
+        host read --, host-side count of eager launches; an eager launch k draws with sequence number 2^48 + k);
+        rng="torch": (offset of the device generator, its seed)."""
+        if self.rng == "philox":
+            st = self._rng_counters.get(device)
+            return (int(st[0].item()) if st is not None else 0, int(self._philox_offset))
+        gen = self._generator(device)
+        return (int(gen.get_offset()), int(gen.initial_seed()))
+
     # ------------------------------------------------------------------ inner early stop, host side
     def _es_options(self, model_options):
         """The part of LanPaintEarlyStopper.from_options that needs no device data (earlystop.py:63-103): threshold,

@@ -204,8 +204,20 @@ def run_full_schedule(name):
     model = MODELS["linear_tuple"](flow=sc["flow"])
     eng = ref_engine(dict(hyper=sc["hyper"], flow=sc["flow"]), model)
     x = _t(sc["x"].copy())
+    extra = {}
+    if sc["video_mask"]:
+        # the job's mask as a workflow builds it: the reference's reshape_mask (video path) of the pixel-resolution denoise
+        # mask, then KSamplerX0Inpaint's threshold + inversion (nodes.py:281-283)
+        ref = _import_ref_nodes()
+        dm = ref.reshape_mask(_t(gc.video_pixel_mask(sc["shape"])), sc["shape"], video_inpainting=True)
+        lm = (1.0 - (dm > 0.5).float()).contiguous()
+        assert tuple(lm.shape) == tuple(sc["shape"])
+        sc["mask"] = lm.numpy()
+        extra["mask_bits"] = np.packbits(lm.numpy().reshape(-1) > 0.5)
+        extra["mask_known"] = np.int64(int(lm.sum().item()))
     y, noise, mask = _t(sc["y"]), _t(sc["noise"]), _t(sc["mask"])
     sig, b = sc["sigmas"], sc["shape"][0]
+    row_scale = _t(sc["row_scale"])
     draws, used, orig = gc.seeded_xi_stream(sc["xi_seed"], sc["shape"]), [], torch.randn_like
 
     def fed(t, *a, **kw):
@@ -215,7 +227,7 @@ def run_full_schedule(name):
     rec = {}
     try:
         for i in range(len(sig)):
-            s = torch.full((b,), float(sig[i]), dtype=torch.float32)
+            s = torch.full((b,), float(sig[i]), dtype=torch.float32) * row_scale
             den = eng(x, y, noise, s, mask, gc.times_from_sigma(s, sc["flow"]), None, 0)
             if i % gc.FULL_SCHEDULE_STRIDE == 0 or i == len(sig) - 1:
                 rec.update({f"den{i}_{k}": v for k, v in gc.digest(den.numpy(), sc["xi_seed"] + 10 + i).items()})
@@ -225,7 +237,7 @@ def run_full_schedule(name):
         torch.randn_like = orig
     rec.update({f"x_{k}": v for k, v in gc.digest(x.numpy(), sc["xi_seed"] + 1).items()})
     np.savez_compressed(os.path.join(HERE, name + ".npz"), n_draws=np.int64(len(used)), model_calls=np.int64(model.calls),
-                        xi_seed=np.int64(sc["xi_seed"]), shape=np.asarray(sc["shape"], dtype=np.int64), sigmas=sig, **rec)
+                        xi_seed=np.int64(sc["xi_seed"]), shape=np.asarray(sc["shape"], dtype=np.int64), sigmas=sig, **extra, **rec)
     return len(used), model.calls
 
 

@@ -194,8 +194,29 @@ FULL_SCHEDULES = {
     "full_c1_sd15":  dict(shape=(1, 4, 64, 64), flow=False, n_sigmas=20, n_think=5, seed=60, xi_seed=4260),
     "full_c2_sdxl":  dict(shape=(1, 4, 128, 128), flow=False, n_sigmas=30, n_think=5, seed=61, xi_seed=4261),
     "full_c4_flux":  dict(shape=(1, 16, 64, 64), flow=True, n_sigmas=28, n_think=10, seed=62, xi_seed=4262),
+    # C3 = SDXL batch of 4 rows (BASELINE configs[2], the per-GPU share of batch 32): every row walks its OWN sigma ramp
+    # (row r sits at ROW_SCALE[r] x the Karras schedule), so the whole schedule runs through the reference's per-row
+    # broadcast (lanpaint.py:23-33) and its flow-form replace step for per-row sigma (:89-92)
+    "full_c3_sdxl_b4": dict(shape=(4, 4, 128, 128), flow=False, n_sigmas=30, n_think=5, seed=63, xi_seed=4263,
+                            row_scale=(1.0, 0.9, 0.8, 0.7)),
+    # C5 = Wan 1x16x21x60x104 video latent (configs[4]); the latent mask is the REFERENCE's reshape_mask(video_inpainting=True)
+    # (nodes.py:59-133) of an 81-frame 480x832 pixel mask (video_pixel_mask below), kept in the fixture as bits
+    "full_c5_wan":   dict(shape=(1, 16, 21, 60, 104), flow=True, n_sigmas=30, n_think=5, seed=64, xi_seed=4264, video_mask=True),
 }
 FULL_SCHEDULE_STRIDE = 5
+
+
+def video_pixel_mask(latent_shape):
+    """ComfyUI denoise mask (1 = inpaint) of the C5 job at PIXEL resolution, [F, H, W] = [4 (f - 1) + 1, 8 h, 8 w]: the second
+    half of the video is inpainted whole; in the first half a rectangle is inpainted over a run of frames and
+    a thin stroke on ONE frame -- spatial nearest-exact picks (480 -> 60, 832 -> 104), frames the 81 -> 21 resample skips, and
+    the 5-tap temporal union all matter for the result."""
+    f, h, w = 4 * (latent_shape[2] - 1) + 1, 8 * latent_shape[3], 8 * latent_shape[4]
+    m = np.zeros((f, h, w), dtype=np.float32)
+    m[f // 2:] = 1.0
+    m[9:27, 117:363, 203:601] = 1.0           # edges off the 8-pixel grid on purpose
+    m[5, 40:44, 100:700] = 1.0                # a 4-pixel stroke on a single frame: survives only if a latent row picks it
+    return m
 
 
 def build_full_schedule(name):
@@ -208,8 +229,14 @@ def build_full_schedule(name):
     x = (sig[0] * noise + (1 - sig[0]) * y).astype(np.float32) if flow else (y + noise * sig[0]).astype(np.float32)
     hyper = dict(HYPER_DEFAULT)
     hyper["NSteps"] = c["n_think"]
-    return dict(name=name, shape=shape, flow=flow, sigmas=sig, x=x, y=y, noise=noise, mask=box_mask(shape), hyper=hyper,
-                xi_seed=c["xi_seed"], n_draws=len(sig) * (2 * c["n_think"] - 1))
+    row_scale = np.asarray(c.get("row_scale", (1.0,) * shape[0]), dtype=np.float32)
+    if "row_scale" in c:                      # x_t of row r starts at ITS sigma
+        x = (y + noise * (sig[0] * row_scale).reshape((-1,) + (1,) * (len(shape) - 1))).astype(np.float32)
+    # (video_mask: the latent mask comes from reshape_mask -- the reference's when the fixture is made, ours in the GPU test;
+    # `mask` is then filled in by the caller)
+    return dict(name=name, shape=shape, flow=flow, sigmas=sig, x=x, y=y, noise=noise,
+                mask=None if c.get("video_mask") else box_mask(shape), hyper=hyper, xi_seed=c["xi_seed"],
+                n_draws=len(sig) * (2 * c["n_think"] - 1), row_scale=row_scale, video_mask=bool(c.get("video_mask")))
 
 
 def seeded_xi_stream(xi_seed, shape):

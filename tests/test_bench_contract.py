@@ -23,10 +23,61 @@ def test_workloads_match_baseline_configs():
 
 def test_cpu_baseline_leg_is_bounded_and_json_serialisable():
     import bench
+    from oracle import ref_engine
     out = bench.cpu_baseline("c1_sd15", 0.6)
     json.dumps(out)
-    assert out["kind"] == "port" and out["unit"] == "think-iterations/s" and out["value"] > 0 and out["cores"] >= 1
-    assert "oracle/lanpaint_oracle.py" in out["sample"]
+    staged = ref_engine.load_reference() is not None
+    assert out["kind"] == ("reference" if staged else "port") and out["unit"] == "think-iterations/s" and out["value"] > 0
+    assert out["cores"] in (1, os.cpu_count()) and set(out["threads"]) == {"1", str(os.cpu_count())} and out["cpu_model"]
+    assert all(v["passes"] == 5 and v["sigma_calls_per_pass"] >= 1 for v in out["threads"].values())      # median of 5, bounded sample
+    if staged:
+        assert "oracle/_ref" in out["sample"] and 0.5 < out["port_over_reference"] < 2.0 and len(out["reference_source_sha256"]) == 3
+    else:
+        assert "oracle/lanpaint_oracle.py" in out["sample"]
+
+
+def test_cpu_baseline_falls_back_to_the_port_without_the_staged_reference(monkeypatch):
+    import bench
+    from oracle import ref_engine
+    monkeypatch.setattr(ref_engine, "load_reference", lambda: None)
+    out = bench.cpu_baseline("c1_sd15", 0.4)
+    assert out["kind"] == "port" and "oracle/lanpaint_oracle.py" in out["sample"] and out["value"] > 0
+
+
+def test_staged_reference_is_the_reference():
+    """oracle/_ref (bytecode compiled from /root/reference by oracle/build_ref.py) IS the unmodified engine: where the
+    reference tree is present the staged sources' hashes equal the tree's, and the staged engine reproduces a golden fixture
+    bit for bit (the fixtures were written by importing that same file)."""
+    import hashlib
+    import numpy as np
+    import pytest
+    import torch
+    from oracle import ref_engine
+    from tests import golden_cases as gc
+    from tests.helpers import load_golden, xi_list
+    from tests.stubs import MODELS
+    cls = ref_engine.load_reference()
+    if cls is None:
+        pytest.skip("oracle/_ref not staged in this checkout")
+    m = ref_engine.manifest()
+    for name, rec in m["modules"].items():
+        src = os.path.join("/root/reference/src/LanPaint", name + ".py")
+        if os.path.exists(src):
+            assert hashlib.sha256(open(src, "rb").read()).hexdigest() == rec["source_sha256"], name
+    case, g = gc.build_case("ve_basic"), load_golden("ve_basic")
+    draws = iter(xi_list(g))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
+    orig = torch.randn_like
+    torch.randn_like = lambda like, *a, **k: t(next(draws)).to(like.dtype)
+    try:
+        h = case["hyper"]
+        eng = cls(MODELS[case["model"]](), h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], IS_FLUX=False,
+                  IS_FLOW=False, MinStepFrac=h["MinStepFrac"])
+        x = t(case["x"].copy())
+        out = eng(x, t(case["y"]), t(case["noise"]), t(case["sigma"]), t(case["mask"]), tuple(t(v) for v in case["times"]), None, 0)
+    finally:
+        torch.randn_like = orig
+    assert np.array_equal(x.numpy(), g["x_out"]) and np.array_equal(out.numpy(), g["out"])
 
 
 def test_pmc_traffic_lookup_reads_committed_profile():
@@ -61,4 +112,4 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
-                assert "liblanpaint_oracle" not in src, f
+                assert "liblanpaint_oracle" not in src and "ref_engine" not in src and "_lanpaint_reference_engine" not in src, f

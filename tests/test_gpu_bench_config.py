@@ -1,0 +1,125 @@
+"""The configuration bench.py PUBLISHES, tested as such: the engine object the bench times --
+hipGraph replay of every sigma call, noise generated inside the kernels, bit-packed mask -- over the whole BASELINE
+schedule against the CPU oracle fed the very draws the kernels generate, through the function the bench itself runs before
+its timed region (bench.parity_check).  Tolerance: BASELINE.json's MSE < 1e-5 on the final latent and on every denoised;
+what the build achieves (asserted too) is < 1e-9."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _job(workload, mask_format, seed=0, mask_kind=None):
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    shape, flow, n_sig, n_think = bench.WORKLOADS[workload]
+    sig_np = bench.flow_sigmas(n_sig) if flow else bench.karras_sigmas(n_sig)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    bench.MASK_KIND = mask_kind
+    x0, y, noise, mask = bench.make_inputs(shape, flow, float(sig_np[0]), seed, dev, tt)
+    mask = bench.attach_mask_format(mask, mask_format)
+    sig_list = [torch.full((shape[0],), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+    times_list = [bench.times_from_sigma(s, flow) for s in sig_list]
+    ratios = bench.euler_ratios(sig_list, len(shape))
+    return dict(x0=x0, y=y, noise=noise, mask=mask, sig_list=sig_list, times_list=times_list, ratios=ratios,
+                n_think=n_think, flow=flow, n_sig=n_sig, shape=shape)
+
+
+def _engine(job, **kw):
+    import bench
+    from lanpaint_amd import LanPaint
+    h = bench.HYPER
+    return LanPaint(bench.StubBackbone(job["flow"]), job["n_think"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"],
+                    IS_FLOW=job["flow"], MinStepFrac=h["MinStepFrac"], **kw)
+
+
+def _check(job, eng, **kw):
+    import bench
+    return bench.parity_check(eng, job["x0"], job["y"], job["noise"], job["mask"], job["sig_list"], job["times_list"],
+                              job["ratios"], job["n_think"], job["flow"], **kw)
+
+
+def test_the_published_configuration_against_the_oracle():
+    """BENCH.config literally: c2_sdxl 1x4x128x128, 30 Karras sigmas x 5, rng=philox, graph replay, bit-packed mask."""
+    job = _job("c2_sdxl", "bits")
+    eng = _engine(job, rng="philox", philox_seed=0, graph=True)
+    r = _check(job, eng)
+    assert r["ok"] and r["sigmas_checked"] == 30 and r["draws"] == 30 * 9 and r["think_iterations_checked"] == 150
+    assert r["launch_modes"] == {"graph": 30}, r["launch_modes"]          # every call was a replay, none fell back to eager
+    assert r["mse_x"] < 1e-5 and r["mse_denoised_max"] < 1e-5, r
+    assert r["mse_x"] < 1e-9 and r["mse_denoised_max"] < 1e-9, r          # what the build achieves
+    assert len(eng._graphs) == 1 and eng.iterations_run == 150
+
+
+def test_the_engine_built_with_no_optional_keyword_against_the_oracle():
+    """`engine_defaults`: LanPaint(Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX, IS_FLOW) -- graph="auto",
+    rng="torch" (the reference's own randn stream, generated in-kernel), the reference's fp32 mask -- against the oracle on
+    what torch.randn itself returns from the same generator state; the generator must end every call where the reference's
+    draws would leave it (checked inside parity_check)."""
+    import torch
+    import bench
+    from lanpaint_amd import LanPaint
+    job = _job("c2_sdxl", "f32")
+    h = bench.HYPER
+    eng = LanPaint(bench.StubBackbone(False), job["n_think"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], False, False)
+    assert eng.graph == "auto" and eng.rng == "torch"
+    torch.manual_seed(20240924)
+    r = _check(job, eng)
+    assert r["ok"] and r["launch_modes"] == {"torch": 30} and r["draws"] == 270
+    assert r["mse_x"] < 1e-9 and r["mse_denoised_max"] < 1e-9, r
+    assert len(eng._graphs) == 1 and not eng._graph_blocked               # auto mode did capture (and verify) the call
+
+
+@pytest.mark.parametrize("workload,kw,fmt,max_sigmas", [
+    ("c2_sdxl", dict(rng="philox", philox_seed=3, graph=False), "bits", None),      # eager launches, host-side launch counter
+    ("c2_sdxl", dict(rng="torch", graph=True), "bits", None),                        # the reference's stream inside a replayed graph
+    ("c1_sd15", dict(rng="philox", philox_seed=1, graph=True), "bits", None),        # BASELINE configs[0] shape
+    ("c3_sdxl_b4", dict(rng="philox", philox_seed=2, graph=True), "bits", None),     # configs[2]: 4 rows per GPU
+    ("c4_flux", dict(rng="philox", philox_seed=4, graph=True), "bits", 10),          # configs[3], flow, 10 iterations per sigma
+    ("c5_wan", dict(rng="philox", philox_seed=5, graph=True), "bits", 2),            # configs[4]: video latent, 16 B per lane
+    ("c5_wan", dict(rng="torch", graph=True), "f32", 1),                             # ... ATen-strided lanes, fp32 mask
+])
+def test_other_bench_configurations_against_the_oracle(workload, kw, fmt, max_sigmas):
+    import torch
+    job = _job(workload, fmt)
+    eng = _engine(job, **kw)
+    torch.manual_seed(7)
+    r = _check(job, eng, max_sigmas=max_sigmas)
+    assert r["ok"] and r["mse_x"] < 1e-9 and r["mse_denoised_max"] < 1e-9, r
+    want = "torch" if kw["rng"] == "torch" else ("graph" if kw["graph"] else "eager")
+    assert set(r["launch_modes"]) == {want}, r["launch_modes"]
+
+
+def test_the_check_has_teeth():
+    """A checker that cannot fail proves nothing: hand it the wrong noise stream (sequence numbers off by one) and it must
+    report a failure, not a small number."""
+    job = _job("c1_sd15", "bits")
+    eng = _engine(job, rng="philox", philox_seed=0, graph=True)
+    good = _check(job, eng, max_sigmas=3)
+    assert good["ok"]
+    real = eng.rng_position
+    eng.rng_position = lambda dev: tuple(v + (1 if k == 0 else 0) for k, v in enumerate(real(dev)))
+    bad = _check(job, eng, max_sigmas=3)
+    assert not bad["ok"] and bad["mse_x"] > 1e-3, bad
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_carries_the_parity_check():
+    """`python bench.py` prints `parity_check` for the configuration it times and a `value` only next to ok = true."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "0",
+           "--prewarm-seconds", "0.05", "--no-cpu-baseline", "--no-large-shape", "--extras", "0"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    pc = line["parity_check"]
+    assert pc["ok"] and pc["sigmas_checked"] == 30 and pc["launch_modes"] == {"graph": 30}
+    assert pc["mse_x"] < 1e-9 and pc["mse_denoised_max"] < 1e-9 and line["value"] > 0

@@ -14,11 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(backend, extra=()):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", backend, "--steps", "3",
-           "--warmup", "1", "--repeats", "1", "--prewarm-seconds", "0.05", "--cpu-seconds", "1.0", "--no-large-shape", *extra]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+def _cmd(backend, gpus=2, extra=()):
+    return [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dist-backend", backend, "--steps", "3",
+            "--warmup", "1", "--repeats", "1", "--prewarm-seconds", "0.05", "--cpu-seconds", "1.0", "--no-large-shape", *extra]
+
+
+def _env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def _run(backend, extra=(), gpus=2, timeout=600):
+    p = subprocess.run(_cmd(backend, gpus, extra), env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -27,7 +33,10 @@ def _run(backend, extra=()):
 
 def _check(line, backend):
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["collective"] == ("rccl" if backend == "nccl" else backend)         # top level: impossible to miss
+    assert line["parity_check"]["ok"]
     d = line["dist"]
+    assert line["distinct_devices"] == d["distinct_devices"] and d["shared_checksums_equal"]
     assert d["backend"] == backend and d["world_size"] == 2 and d["ranks_reporting"] == 2
     assert d["launcher"] == "bench.py self-spawn" and d["collectives_in_timed_region"] == 0
     assert len(d["per_rank_it_s"]) == 2 and all(v > 0 for v in d["per_rank_it_s"])
@@ -53,10 +62,14 @@ def test_bench_two_ranks_without_a_launcher_gloo():
 def test_bench_two_ranks_without_a_launcher_rccl():
     import torch
     if torch.cuda.device_count() < 2:
-        # asking for nccl with one device must still produce the line (automatic gloo fallback, said in the line)
-        line = _run("nccl")
+        # RCCL cannot carry two ranks on one device.  Asking for it there is an ERROR (no line, exit code != 0) ...
+        p = subprocess.run(_cmd("nccl"), env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert "--allow-gloo-fallback" in p.stderr
+        # ... unless the caller explicitly accepts a gloo rehearsal, which the line then states at top level
+        line = _run("nccl", extra=("--allow-gloo-fallback",))
         d = _check(line, "gloo")
-        assert d["backend_requested"] == "nccl" and d["distinct_devices"] == 1
+        assert d["backend_requested"] == "nccl" and d["distinct_devices"] == 1 and line["collective"] == "gloo"
         return
     d = _check(_run("nccl"), "nccl")
     assert d["rccl_version"] and d["distinct_devices"] == 2
@@ -82,3 +95,30 @@ def test_bench_two_ranks_under_torch_distributed_run():
     d = line["dist"]
     assert line["n_gpus"] == 2 and d["world_size"] == d["ranks_reporting"] == 2 and d["launcher"] == "external"
     assert all(r["iterations"] == 3 * line["config"]["iterations_per_step"] for r in d["per_rank"])
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("workload,rows", [("c3_sdxl_b4", 4), ("c5_wan", 1)])
+def test_bench_eight_ranks_rehearse_the_multi_gpu_configurations_baseline_names(workload, rows):
+    """BASELINE.json configs[2] (SDXL batch 32 = 4 rows per GPU, mask / known latent / SDXL-shaped cond broadcast) and
+    configs[4] (Wan video latent, batch-sharded over 8 GPUs) in their EIGHT-rank form: eight processes, one packed broadcast
+    from rank 0, no collective in the timed region, every rank the full K steps on its own replica.  On a box with fewer
+    than eight devices the ranks share them and travel over gloo -- a rehearsal of the code path (rendezvous, broadcast,
+    per-rank seeds, reduction, the line), not a scaling measurement; with eight devices the same command runs over RCCL."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
+    line = _run(backend, gpus=8, timeout=1400,
+                extra=("--workload", workload, "--steps", "2", "--repeats", "0", "--no-cpu-baseline", "--extras", "0"))
+    d = line["dist"]
+    assert line["n_gpus"] == 8 and d["world_size"] == d["ranks_reporting"] == 8 and line["collective"] == ("rccl" if backend == "nccl" else "gloo")
+    assert line["config"]["rows_per_gpu"] == rows and line["config"]["global_rows"] == 8 * rows == d["global_rows"]
+    assert d["collectives_in_timed_region"] == 0 and d["shared_checksums_equal"]
+    per = d["per_rank"]
+    assert [r["rank"] for r in per] == list(range(8)) and len({r["pid"] for r in per}) == 8
+    assert all(r["iterations"] == 2 * line["config"]["iterations_per_step"] for r in per)
+    assert len({r["final_checksum"] for r in per}) == 8                               # eight different replicas (seed + rank)
+    shared = d["shared_tensors"]
+    assert set(shared) >= {"mask", "y", "cond"} and (workload != "c3_sdxl_b4" or (shared["cond"] == [1, 77, 2048] and shared["pooled"] == [1, 2816]))
+    n_el = line["config"]["latent_elements_per_gpu"]
+    assert d["broadcast_bytes"] >= 2 * 4 * n_el + 2 * 77 * 2048
+    assert line["parity_check"]["ok"] and line["value"] > 0

@@ -246,9 +246,10 @@ def test_full_c2_schedule_mse_below_target():
 
 @pytest.mark.parametrize("name", sorted(gc.FULL_SCHEDULES))
 def test_full_baseline_schedule_matches_the_reference_run(name):
-    """BASELINE.json's C1 / C2 / C4 as WHOLE schedules against a run of the unmodified reference engine (no oracle in
+    """BASELINE.json's C1 ... C5 as WHOLE schedules against a run of the unmodified reference engine (no oracle in
     between): tests/golden/full_*.npz holds digests of every fifth denoised and of the final x; C2 -- SDXL 1x4x128x128,
-    30 sigmas x 5 -- is the configuration the headline metric is quoted on.  Same xi stream (numpy seed), engine defaults."""
+    30 sigmas x 5 -- is the configuration the headline metric is quoted on, C3 four rows each on its own sigma ramp, C5 the
+    5-D video latent whose mask comes through reshape_mask's video path.  Same xi stream (numpy seed), engine defaults."""
     import torch
     from lanpaint_amd import LanPaint
     from tests.helpers import assert_digest, load_golden
@@ -264,9 +265,18 @@ def test_full_baseline_schedule_matches_the_reference_run(name):
     model = MODELS["linear_tuple"](flow=flow)
     eng = LanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], IS_FLOW=flow,
                    MinStepFrac=h["MinStepFrac"], rng=rng)
+    if sc["video_mask"]:
+        # C5: the job's latent mask through OUR reshape_mask (lp_reshape_mask, video path) and KSamplerX0Inpaint's threshold +
+        # inversion, from the pixel-resolution mask -- bit for bit the reference's (kept in the fixture as packed bits)
+        from lanpaint_amd import nodes as lpn
+        dm = lpn.reshape_mask(tt(gc.video_pixel_mask(sc["shape"])), sc["shape"], video_inpainting=True)
+        lm = (1.0 - (dm > 0.5).float()).contiguous()
+        assert np.array_equal(np.packbits(lm.cpu().numpy().reshape(-1) > 0.5), g["mask_bits"])
+        sc["mask"] = lm.cpu().numpy()
     x, y, noise, mask = tt(sc["x"].copy()), tt(sc["y"]), tt(sc["noise"]), tt(sc["mask"])
+    row_scale = tt(sc["row_scale"])
     for i in range(len(sig)):
-        s = torch.full((sc["shape"][0],), float(sig[i]), dtype=torch.float32, device=DEV)
+        s = torch.full((sc["shape"][0],), float(sig[i]), dtype=torch.float32, device=DEV) * row_scale
         den = eng(x, y, noise, s, mask, gc.times_from_sigma(s, flow), None, 0)
         if f"den{i}_sums" in g.files:
             assert_digest(den.cpu().numpy(), g, f"den{i}", int(g["xi_seed"]) + 10 + i, f"{name}: denoised[{i}]", rel=5e-5)

@@ -77,8 +77,9 @@ def test_oracle_matches_the_reference_sampler_callable(name):
 
 @pytest.mark.parametrize("name", sorted(gc.FULL_SCHEDULES))
 def test_oracle_matches_reference_full_baseline_schedule(name):
-    """BASELINE.json's C1 / C2 / C4 as WHOLE schedules (C2 = the headline configuration: SDXL 1x4x128x128, 30 sigmas x 5)
-    run by the unmodified reference engine; the fixture holds digests of every fifth denoised and of the final x."""
+    """BASELINE.json's C1 ... C5 as WHOLE schedules (C2 = the headline configuration: SDXL 1x4x128x128, 30 sigmas x 5; C3 = four
+    rows each on its own sigma ramp; C5 = the 5-D video latent with the temporal mask through reshape_mask) run by the
+    unmodified reference engine; the fixture holds digests of every fifth denoised and of the final x."""
     sc = gc.build_full_schedule(name)
     g = load_golden(name)
     it = gc.seeded_xi_stream(int(g["xi_seed"]), sc["shape"])
@@ -92,8 +93,14 @@ def test_oracle_matches_reference_full_baseline_schedule(name):
     eng = OracleLanPaint(model, h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], is_flow=flow,
                          min_step_frac=h["MinStepFrac"], randn=randn)
     x = sc["x"].copy()
+    if sc["video_mask"]:
+        # C5: the job's latent mask through the ORACLE's reshape_mask (video path) from the pixel-resolution mask -- must be
+        # the reference's, bit for bit (the fixture keeps the reference's as packed bits)
+        dm = orc.reshape_mask(gc.video_pixel_mask(sc["shape"]), sc["shape"], video_inpainting=True)
+        sc["mask"] = orc.binarize_and_invert(dm).astype(np.float32)
+        assert np.array_equal(np.packbits(sc["mask"].reshape(-1) > 0.5), g["mask_bits"]) and int(sc["mask"].sum()) == int(g["mask_known"])
     for i in range(len(sig)):
-        s = np.full((sc["shape"][0],), sig[i], dtype=np.float32)
+        s = np.full((sc["shape"][0],), sig[i], dtype=np.float32) * sc["row_scale"]
         den = eng(x, sc["y"], sc["noise"], s, sc["mask"], gc.times_from_sigma(s, flow), None, 0)
         if f"den{i}_sums" in g.files:
             assert_digest(den, g, f"den{i}", int(g["xi_seed"]) + 10 + i, f"{name}: denoised[{i}]", rel=2e-5)
