@@ -290,6 +290,7 @@ def run_gpu(args):
                       file=sys.stderr, flush=True)
             raise SystemExit(4)
         backend = "gloo"
+    affinity0 = os.sched_getaffinity(0)
     numa = lpd.bind_to_device_numa(dev_index) if not args.no_numa_bind else None
     lpd.init(backend, dev)                              # "nccl" IS RCCL on ROCm; no-op at world size 1
 
@@ -436,8 +437,12 @@ def run_gpu(args):
         dist.destroy_process_group()
     if rank != 0:
         return
-    if not args.no_cpu_baseline:     # rank 0 only, after the process group is gone: ~12 s of host time nobody waits for
+    if not args.no_cpu_baseline:     # rank 0 only, after the process group is gone: ~20 s of host time nobody waits for
         try:
+            try:
+                os.sched_setaffinity(0, affinity0)      # the baseline is the reference on the BOX's host cores, not on one NUMA node's
+            except Exception:
+                pass
             cpu = cpu_baseline(args.workload, args.cpu_seconds)
         except Exception as e:
             cpu = {"error": repr(e)}
@@ -1092,24 +1097,44 @@ def cpu_baseline(workload, budget_s):
     import warnings
     warnings.filterwarnings("ignore", message="In CPU autocast")      # (the reference wraps its loop in torch.autocast(fp32))
     saved = torch.get_num_threads()
-    n_cpu = os.cpu_count() or 1
-    per_threads, port_vals, sample_sigmas = {}, None, n_sig
+    # "all threads" = the CPUs this process may run on (a rank pinned to its GPU's NUMA node must not start one thread per CPU
+    # of the whole box: oversubscribed OpenMP teams turn every tiny op into scheduler round trips)
+    n_cpu, n_usable = os.cpu_count() or 1, len(os.sched_getaffinity(0))
+    per_threads, skipped, port_vals, sample_sigmas = {}, {}, None, n_sig
+    t_leg = time.perf_counter()
     try:
-        for threads in sorted({1, n_cpu}):
+        for threads in sorted({1, n_usable}):
             torch.set_num_threads(threads)
-            eng = make(kind)
-            per_sigma = float("inf")                            # how long is one sigma call here?  (3 calls, twice: the first
-            for _ in range(2):                                  # round also wakes the thread pool up)
-                t0 = time.perf_counter()
-                schedule_pass(eng, x0, y, noise, mask, sig_list[:3], times_list[:3], ratios[:2], n_think)
-                per_sigma = min(per_sigma, (time.perf_counter() - t0) / 3)
             share = budget_s / 2                                # per thread setting: 1 discarded + 5 timed passes
+            # what does ONE small elementwise op cost at this thread count?  (a sigma call is ~170 of them per think iteration;
+            # on a many-core host the fork / join of a large team can cost more than the op)
+            a = x0 * 0.9
+            for _ in range(5):
+                a = x0 * 0.9 + y
+            t0 = time.perf_counter()
+            for _ in range(20):
+                a = x0 * 0.9 + y
+            per_op = (time.perf_counter() - t0) / 40
+            est_sigma = per_op * 170 * n_think
+            if threads != 1 and 3 * est_sigma > share:
+                skipped[str(threads)] = {"per_small_op_us": 1e6 * per_op, "estimated_s_per_sigma_call": est_sigma,
+                                         "note": f"not sampled: at {threads} threads one small elementwise op costs "
+                                                 f"{1e6 * per_op:.0f} us on this host, a sigma call ~{est_sigma:.1f} s -- more than the "
+                                                 f"{share:.0f} s this setting may take"}
+                continue
+            eng = make(kind)
+            per_sigma = float("inf")                            # one sigma call, twice (the first also wakes the thread pool up)
+            for _ in range(2):
+                t0 = time.perf_counter()
+                schedule_pass(eng, x0, y, noise, mask, sig_list[:1], times_list[:1], [], n_think)
+                per_sigma = min(per_sigma, time.perf_counter() - t0)
             n_s = n_sig if 6 * n_sig * per_sigma <= share else max(1, int(share / (6 * per_sigma)))
+            passes = 5 if 6 * n_s * per_sigma <= 2 * share else max(1, min(5, int(2 * share / (n_s * per_sigma)) - 1))
             sample_sigmas = min(sample_sigmas, n_s)
-            vals = timed(eng, n_s, 5)
+            vals = timed(eng, n_s, passes)
             per_threads[threads] = {"median_it_s": float(np.median(vals)), "min_it_s": min(vals), "max_it_s": max(vals),
-                                    "passes": len(vals), "sigma_calls_per_pass": n_s}
-        if kind == "reference":                                 # the port beside it, 1 thread
+                                    "passes": len(vals), "sigma_calls_per_pass": n_s, "per_small_op_us": 1e6 * per_op}
+        if kind == "reference" and time.perf_counter() - t_leg < 2 * budget_s:      # the port beside it, 1 thread
             torch.set_num_threads(1)
             port_vals = timed(make("port"), per_threads[1]["sigma_calls_per_pass"], 3)
     finally:
@@ -1123,7 +1148,8 @@ def cpu_baseline(workload, budget_s):
                    else "oracle/lanpaint_oracle.py (CPU port of the reference) on torch-CPU fp32 tensors -- oracle/_ref is not "
                         "staged in this checkout")
     out = {"value": per_threads[best_threads]["median_it_s"], "unit": "think-iterations/s", "cores": best_threads, "kind": kind,
-           "threads": {str(t): v for t, v in sorted(per_threads.items())}, "host_cpus": n_cpu, "cpu_model": _cpu_model(),
+           "threads": {str(t): v for t, v in sorted(per_threads.items())}, "threads_not_sampled": skipped or None,
+           "host_cpus": n_cpu, "usable_cpus": n_usable, "cpu_model": _cpu_model(), "leg_seconds": time.perf_counter() - t_leg,
            "sample": f"{'whole passes' if whole else f'the first {sample_sigmas} sigma calls'} of the {workload} schedule "
                      f"({n_sig} sigmas x {n_think}), stub backbone, {engine_desc}; one warm-up pass discarded, median of 5; {detail}"}
     if kind == "reference":

@@ -28,10 +28,14 @@ def test_cpu_baseline_leg_is_bounded_and_json_serialisable():
     json.dumps(out)
     staged = ref_engine.load_reference() is not None
     assert out["kind"] == ("reference" if staged else "port") and out["unit"] == "think-iterations/s" and out["value"] > 0
-    assert out["cores"] in (1, os.cpu_count()) and set(out["threads"]) == {"1", str(os.cpu_count())} and out["cpu_model"]
-    assert all(v["passes"] == 5 and v["sigma_calls_per_pass"] >= 1 for v in out["threads"].values())      # median of 5, bounded sample
+    n_all = len(os.sched_getaffinity(0))
+    assert out["cores"] in (1, n_all) and out["cpu_model"] and out["usable_cpus"] == n_all
+    assert set(out["threads"]) | set(out["threads_not_sampled"] or {}) == {"1", str(n_all)} and "1" in out["threads"]
+    assert all(1 <= v["passes"] <= 5 and v["sigma_calls_per_pass"] >= 1 for v in out["threads"].values())   # median of <= 5, bounded sample
+    assert out["leg_seconds"] < 20.0
     if staged:
-        assert "oracle/_ref" in out["sample"] and 0.5 < out["port_over_reference"] < 2.0 and len(out["reference_source_sha256"]) == 3
+        assert "oracle/_ref" in out["sample"] and len(out["reference_source_sha256"]) == 3
+        assert out.get("port_over_reference") is None or 0.4 < out["port_over_reference"] < 2.5     # (timed when the budget allows)
     else:
         assert "oracle/lanpaint_oracle.py" in out["sample"]
 
