@@ -1054,6 +1054,18 @@ def _cpu_model():
     return None
 
 
+def _usable_cpus():
+    """CPUs this process can really use: its affinity mask, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(workload, budget_s):
     """The reference's CPU path next to the GPU number: the UNMODIFIED reference engine
     -- oracle/_ref, the reference's own lanpaint.py compiled to bytecode where it lies by oracle/build_ref.py -- driven over
@@ -1099,11 +1111,16 @@ def cpu_baseline(workload, budget_s):
     saved = torch.get_num_threads()
     # "all threads" = the CPUs this process may run on (a rank pinned to its GPU's NUMA node must not start one thread per CPU
     # of the whole box: oversubscribed OpenMP teams turn every tiny op into scheduler round trips)
-    n_cpu, n_usable = os.cpu_count() or 1, len(os.sched_getaffinity(0))
+    n_cpu, n_usable = os.cpu_count() or 1, _usable_cpus()
     per_threads, skipped, port_vals, sample_sigmas = {}, {}, None, n_sig
     t_leg = time.perf_counter()
+    # 1 thread, then "all threads"; when the all-threads team is pathological on this host (the per-op probe below: a
+    # container may show 256 CPUs and schedule far fewer) the next smaller team of the ladder is tried instead
+    ladder = [1] + [t for t in dict.fromkeys([n_usable, 64, 16, 8]) if 1 < t <= n_usable]
     try:
-        for threads in sorted({1, n_usable}):
+        for threads in ladder:
+            if threads != 1 and any(t != 1 for t in per_threads):
+                break                                           # one multi-thread setting has been sampled
             torch.set_num_threads(threads)
             share = budget_s / 2                                # per thread setting: 1 discarded + 5 timed passes
             # what does ONE small elementwise op cost at this thread count?  (a sigma call is ~170 of them per think iteration;
@@ -1120,7 +1137,7 @@ def cpu_baseline(workload, budget_s):
                 skipped[str(threads)] = {"per_small_op_us": 1e6 * per_op, "estimated_s_per_sigma_call": est_sigma,
                                          "note": f"not sampled: at {threads} threads one small elementwise op costs "
                                                  f"{1e6 * per_op:.0f} us on this host, a sigma call ~{est_sigma:.1f} s -- more than the "
-                                                 f"{share:.0f} s this setting may take"}
+                                                 f"{share:.1f} s this setting may take"}
                 continue
             eng = make(kind)
             per_sigma = float("inf")                            # one sigma call, twice (the first also wakes the thread pool up)
