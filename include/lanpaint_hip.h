@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 14
+#define LP_ABI_VERSION 15
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -149,9 +149,10 @@ typedef struct lp_hyper {
 #define LP_FL_ES_GATED      (1u << 14) /* with LP_FL_ES, a launch of a loop the host does not watch (hipGraph replay): once
                                           lp_es_state.stopped is set the launch only re-emits x_in from the committed x_t;
                                           otherwise PRE_HALF is TENTATIVE -- x_t is stored in its post-iteration state, the
-                                          half-step only feeds x_in -- and a POST_STEADY launch first redoes that half-step
-                                          from the same noise (in-kernel generators only), so stopping after iteration i
-                                          leaves exactly the reference's state after i iterations.                        */
+                                          state after the half-step goes to es_xte and feeds x_in -- and a POST_STEADY
+                                          launch starts from es_xte, so stopping after iteration i leaves exactly the
+                                          reference's state after i iterations (round 3 redid the half-step from the same
+                                          noise instead of storing it: a second Philox block per element).               */
 #define LP_FL_ES_CLOSE      (1u << 15) /* with LP_FL_ES_GATED on the LAST launch of a loop (es_index + 1 == es_n_steps) whose
                                           verdict is folded into the launches (small grids): no closing decision kernel
                                           follows.  The launch, having applied the verdict of the iteration before, accounts
@@ -159,6 +160,11 @@ typedef struct lp_hyper {
                                           verdict of the last iteration is never formed -- stopping after the last iteration
                                           changes nothing (earlystop.py:313 only breaks a loop that is over) -- and its trace
                                           record is not written, so a caller that wants the full trace leaves the flag off.  */
+#define LP_FL_ES_RING_BITS  (1u << 16) /* with LP_FL_ES and LP_FL_MASK_BITS: es_ring is the BIT-PACKED ring (lp_pack_mask of lp_boundary_ring's
+                                          output; bit = ring pixel).  With a hard mask the ring weight is 0 or 1 (ring pixels are
+                                          inpaint pixels: 1 - m = 1), so the launch reads 0.125 B / element for it and derives the
+                                          weight in registers.  The phase-specialised hard-mask kernels take only this form; an fp32
+                                          ring next to a bit-packed mask runs through the run-time kernels.                          */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 
@@ -277,7 +283,8 @@ typedef struct lp_step_desc {
                                     between them); also given to the launch that resets it                     */
     float*       es_x0s[3];      /* the three rotating x0s buffers (== es->x0s_buf, as launch arguments so the kernel
                                     selects one by slot index instead of chasing a pointer through the state)     */
-    const float* es_ring;        /* mask-edge ring weight (lp_boundary_ring; 4-D latents), or NULL           */
+    const float* es_ring;        /* mask-edge ring weight (lp_boundary_ring; 4-D latents) as fp32, or bit-packed with
+                                    LP_FL_ES_RING_BITS, or NULL                                              */
     double*      es_partials;    /* device scratch, LP_ES_ACC_DOUBLES doubles: the accumulator sets the blocks of an
                                     LP_FL_ES launch add their six sums into (set = es_index mod LP_ES_ACC_SETS, slot =
                                     block mod LP_ES_ACC_SLOTS).  The es_reset launch clears all of it; launch i clears
@@ -304,6 +311,9 @@ typedef struct lp_step_desc {
     double       sg_min_step_frac;
     int32_t      sg_schedule_len, sg_seq, sg_n_steps, sg_early_stop, sg_total_steps, sg_guess;
     double*      clk_out;
+    float*       es_xte;         /* LP_FL_ES_GATED: n_el floats, the state after the TENTATIVE first half-step of the next
+                                    iteration (lanpaint.py:280).  A gated launch stores it next to the committed x_t; the next
+                                    launch of the loop starts from it, a stopped loop never looks at it again.             */
     uint32_t     tune;           /* LP_TUNE_*: developer switches of this launch (micro-benchmarks, A/B runs); 0 in production */
     uint32_t     io_valid;       /* with io_table_out: 1 = this launch also stores 1 into io_table_out[2], the word whose 0 voids a
                                     captured lp_finalize.  Every replace launch that is not part of a speculated lp_node_call sets

@@ -43,6 +43,16 @@ __device__ __forceinline__ float u01(uint32_t x) {
 
 // Two independent standard normals for element `elem` of launch `seq`.  v_sin_f32 /
 // v_cos_f32 take their argument in revolutions, which is exactly 2*pi*u.
+// (normal_pair_key: the same pair with the block's key given -- for element indices < 2^32 the key is philox_key(seed, seq, 0),
+// wave-uniform, and the compiler keeps the round keys in SGPRs)
+__device__ __forceinline__ void normal_pair_key(uint32_t c0, uint32_t c1, uint32_t key, float& z_post, float& z_pre) {
+    philox2x32_10(c0, c1, key);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c0)));
+    const float t = u01(c1);
+    z_post = r * __builtin_amdgcn_cosf(t);
+    z_pre = r * __builtin_amdgcn_sinf(t);
+}
+
 __device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_t seed, float& z_post, float& z_pre) {
     uint32_t c0 = static_cast<uint32_t>(elem), c1 = static_cast<uint32_t>(seq);
     philox2x32_10(c0, c1, philox_key(seed, seq, elem));
@@ -127,11 +137,22 @@ __device__ __forceinline__ void torch_normal4(uint32_t idx, uint64_t seed, uint6
 
 // ---- 16/32-bit float conversions ----------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(static_cast<uint32_t>(h) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN kept quiet
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return static_cast<uint16_t>(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950's own conversion instruction (v_cvt_pk_bf16_f32, one VALU op per PAIR; the
+// shift / add / compare sequence it replaces was ~7 ops per element of a kernel that is VALU-bound at streaming sizes)
+typedef __bf16 lp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    const __bf16 b = static_cast<__bf16>(f);
+    uint16_t h;
+    __builtin_memcpy(&h, &b, 2);
+    return h;
+}
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {      // lo in bits 0..15
+    const lp_f32x2 v = {lo, hi};
+    const lp_bf16x2 b = __builtin_convertvector(v, lp_bf16x2);
+    uint32_t w;
+    __builtin_memcpy(&w, &b, 4);
+    return w;
 }
 __device__ __forceinline__ float f16_to_f32(uint16_t h) {
     _Float16 v;
@@ -144,9 +165,15 @@ __device__ __forceinline__ uint16_t f32_to_f16(float f) {
     __builtin_memcpy(&h, &v, 2);
     return h;
 }
+// two fp32 -> one dword of two half-width values of storage type `dt` (DT_BF16 / DT_F16), `lo` in bits 0..15
+__device__ __forceinline__ uint32_t pack_half2(int dt, float lo, float hi);
 
 // ---- vector loads / stores ------------------------------------------------------
 enum : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+__device__ __forceinline__ uint32_t pack_half2(int dt, float lo, float hi) {
+    if (dt == DT_BF16) return f32x2_to_bf16x2(lo, hi);
+    return static_cast<uint32_t>(f32_to_f16(lo)) | (static_cast<uint32_t>(f32_to_f16(hi)) << 16);
+}
 
 // Where the V elements of one lane live.  Normally V consecutive elements from index i (an int64_t).  `Strided`:
 // element k at i + k * s while that is < n -- the element-to-thread map of ATen's random kernels (a thread's
@@ -311,18 +338,60 @@ __device__ __forceinline__ void store_any(void* __restrict__ p, int dt, int64_t 
     if (dt == DT_F32) {
         store_f32<V>(static_cast<float*>(p), i, v);
     } else {
-        uint16_t h[V];
-#pragma unroll
-        for (int k = 0; k < V; ++k) h[k] = (dt == DT_BF16) ? f32_to_bf16(v[k]) : f32_to_f16(v[k]);
         uint16_t* q = static_cast<uint16_t*>(p) + i;
         if constexpr (V == 4) {
             u2 t;
-            t.x = h[0] | (uint32_t(h[1]) << 16); t.y = h[2] | (uint32_t(h[3]) << 16);
+            t.x = pack_half2(dt, v[0], v[1]); t.y = pack_half2(dt, v[2], v[3]);
             __builtin_nontemporal_store(t, reinterpret_cast<u2*>(q));
         } else {
 #pragma unroll
-            for (int k = 0; k < V; ++k) q[k] = h[k];
+            for (int k = 0; k < V; ++k) q[k] = (dt == DT_BF16) ? f32_to_bf16(v[k]) : f32_to_f16(v[k]);
         }
+    }
+}
+
+// ---- half-width streams at 16 bytes per access (round 4) -------------------------------------------------------------
+// A bf16 / fp16 stream read 8 bytes per lane (4 elements) moves half the bytes of an fp32 stream with the same number of
+// memory instructions, and 8-byte accesses run at 0.54-0.70x the per-byte rate of 16-byte ones on this part
+// (MI355X_MICROARCH.md, L1-bypassing loads): the 30 B / element launch was no faster than the 36 B one.  So the streaming
+// kernels (four elements per lane) fetch half-width data per LANE PAIR: the even lane loads the 16 bytes that hold the
+// eight elements of both lanes, the odd lane takes its half through one DPP move per dword (quad_perm, VALU -- no LDS);
+// stores go the other way.  Needs the stream 16-byte aligned and rows of a multiple of 8 elements (lp_step checks; other
+// launches take the 8-byte path).  Issue / decode split as above: load_raw_pair only issues, cvt_raw_pair exchanges.
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, false));
+}
+
+// i: this lane's first element (a multiple of 4; the pair's first element is a multiple of 8); pair_on: either lane of the pair
+// reads the stream (region-aware launches leave lines out that no lane reads)
+__device__ __forceinline__ void load_raw_pair(const void* __restrict__ p, int64_t i, bool pair_on, Raw<4>& r) {
+    if ((threadIdx.x & 1u) == 0u && pair_on) {
+        const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4*>(static_cast<const uint16_t*>(p) + i));
+        r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w;
+    }
+}
+
+__device__ __forceinline__ void cvt_raw_pair(int dt, const Raw<4>& r, float (&o)[4]) {
+    // odd lanes: words 2, 3 of the even partner (quad_perm [0,0,2,2]); even lanes keep their own words 0, 1
+    const uint32_t hi0 = dpp_quad<0xA0>(r.w[2]), hi1 = dpp_quad<0xA0>(r.w[3]);
+    const bool odd = (threadIdx.x & 1u) != 0u;
+    const uint32_t w0 = odd ? hi0 : r.w[0], w1 = odd ? hi1 : r.w[1];
+    const uint16_t h[4] = {static_cast<uint16_t>(w0 & 0xffffu), static_cast<uint16_t>(w0 >> 16),
+                           static_cast<uint16_t>(w1 & 0xffffu), static_cast<uint16_t>(w1 >> 16)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (dt == DT_BF16) ? bf16_to_f32(h[k]) : f16_to_f32(h[k]);
+}
+
+// every lane of the wave that is still running calls this (both lanes of a pair are active or neither: rows of 8 k elements)
+__device__ __forceinline__ void store_half_pair(void* __restrict__ p, int dt, int64_t i, const float (&v)[4]) {
+    const uint32_t w0 = pack_half2(dt, v[0], v[1]), w1 = pack_half2(dt, v[2], v[3]);
+    // even lanes: the two words of the odd partner (quad_perm [1,1,3,3]) behind their own
+    const uint32_t p0 = dpp_quad<0xF5>(w0), p1 = dpp_quad<0xF5>(w1);
+    if ((threadIdx.x & 1u) == 0u) {
+        const u4 t = {w0, w1, p0, p1};
+        __builtin_nontemporal_store(t, reinterpret_cast<u4*>(static_cast<uint16_t*>(p) + i));
     }
 }
 

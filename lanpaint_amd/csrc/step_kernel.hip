@@ -310,6 +310,7 @@ __device__ __forceinline__ uint64_t clk_real() {
         double* clk_o = d_arg.clk_out + (blockIdx.x == 0 ? 0 : 16);                                                  \
         for (int k = 0; k < LP_CLK_STAMPS; ++k) clk_o[k] = clk_t[k] ? static_cast<double>(clk_t[k] - clk_t[0]) : 0.0; \
         clk_o[15] = static_cast<double>(clk_real() - clk_r0);                                                        \
+        clk_o[14] = static_cast<double>(clk_r0 & 0xffffffffffffull);      /* absolute 100 MHz time of the block's entry */ \
     }
 #else
 #define LP_CLK_DECL
@@ -361,6 +362,9 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     // waits for the mask).  The rest of the descriptor arrives while those loads fly.  (Older firmware runs the
     // compiler's compatibility prologue, which loads the same SGPRs itself.)
     constexpr bool SMALL = VEC == 1;
+    // half-width backbone outputs (and a half-width x_in) of a streaming launch travel 16 bytes per lane PAIR (lp_common.h)
+    constexpr bool PAIR = X0W == 2 && VEC == 4 && !ST;
+    static_assert(!PAIR || ES == 0, "pair accesses: every lane that has not left the kernel is active");
     LP_CLK_DECL
     lp_step_desc d = d_arg;
     d.x_t = static_cast<float*>(a0); d.C = static_cast<float*>(a1);
@@ -429,19 +433,30 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             // wave-uniform again with readfirstlane where the verdict is formed): a scalar load would be waited for by
             // the next s_waitcnt lgkmcnt(0) -- the kernarg reads in front of the operand loads -- i.e. put its whole
             // round trip back in front of them; vector loads retire in order behind nothing.
-            uint32_t lane_zero;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));          // opaque: keeps the address in a VGPR
-            const uint2* sv = reinterpret_cast<const uint2*>(sp) + lane_zero;
+            // (Streaming sizes, VEC = 4: registers decide -- at 98 VGPRs the launch ran 4 waves per SIMD and the video latent's
+            // 2048 blocks took two rounds, 17.9 us against 9.5 for the plain launch.  There the state comes through SCALAR loads
+            // (the launch waits for it anyway, below) and the accumulator slot is fetched where the verdict is formed.)
+            if constexpr (VEC == 4) {
+                const uint2* sv = reinterpret_cast<const uint2*>(sp);    // wave-uniform address: s_load
 #pragma unroll
-            for (int k = 0; k < 8; ++k) es_words[k] = sv[k];
+                for (int k = 0; k < 8; ++k) es_words[k] = sv[k];
+            } else {
+                uint32_t lane_zero;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));          // opaque: keeps the address in a VGPR
+                const uint2* sv = reinterpret_cast<const uint2*>(sp) + lane_zero;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) es_words[k] = sv[k];
+            }
             es_keeper = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
             // lane l of the block's FIRST wave: slot l of the previous iteration's accumulator set (48 B); the other three
             // waves get the totals through LDS (a launch of 4 096 waves each reading the 3 KB set moved more bytes out of
             // L2 than the SDXL-batch operands themselves)
-            if (threadIdx.x < kWave) {
-                const double* src = es_acc_set(d, d.es_index - 1) + static_cast<size_t>(threadIdx.x) * 8;
+            if constexpr (VEC != 4) {
+                if (threadIdx.x < kWave) {
+                    const double* src = es_acc_set(d, d.es_index - 1) + static_cast<size_t>(threadIdx.x) * 8;
 #pragma unroll
-                for (int k = 0; k < kEsSums; ++k) es_fv[k] = src[k];
+                    for (int k = 0; k < kEsSums; ++k) es_fv[k] = src[k];
+                }
             }
         } else {                                     // wave-uniform scalar loads of the device-side stop state
             es_prev = d.es->cur_slot; es_anchor = d.es->anchor_slot; es_write = d.es->write_slot;
@@ -538,12 +553,82 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
     }
     const int64_t g = active ? g_raw : groups - 1;
     float es_p[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool es_zero_wave = false;           // the wave added nothing to its sums (mask-uniform, all known): no reduction tree needed
     {
         const auto i = [&] {
             if constexpr (ST) return Strided(g, static_cast<int64_t>(d.rng_bg), st_base, st_lo, st_hi);
             else return row_base + g * VEC;
         }();
 
+        // The verdict of iteration i - 1, formed inside launch i (folded loops): state -> totals of the accumulator slots ->
+        // stop rule.  Latency-bound sizes (VEC = 1) call it BEHIND the operand loads and the Philox rounds (one memory round
+        // trip instead of three); streaming sizes (VEC = 4) call it FIRST, before any operand load is issued: its twenty-odd
+        // registers then never overlap the operands', the launch stays at 8 waves per SIMD, and the history loads know which
+        // buffers they need (round 3: verdict behind the loads, 98 VGPRs, 4 waves per SIMD -- the video latent's 2048 blocks ran
+        // in two rounds, 17.9 us against 9.5 for the plain launch).
+        auto form_verdict = [&]() {
+                const int it = d.es_index;
+                {
+                    const auto u = [&](int w) { return __builtin_amdgcn_readfirstlane(static_cast<int>((w & 1) ? es_words[w >> 1].y : es_words[w >> 1].x)); };
+                    const auto u64 = [&](int w) { return (static_cast<uint64_t>(static_cast<uint32_t>(u(w + 1))) << 32) | static_cast<uint32_t>(u(w)); };
+                    static_assert(offsetof(lp_es_state, enabled) == 28 && offsetof(lp_es_state, seq_base) == 32 &&
+                                  offsetof(lp_es_state, abt_val) == 56, "lp_es_state layout");
+                    es_lite.stopped = u(0); es_lite.counter = u(1); es_lite.n_ran = u(2); es_lite.cur_slot = u(3);
+                    es_lite.anchor_slot = u(4); es_lite.write_slot = u(5); es_lite.enabled = u(7);
+                    es_lite.seq_base = static_cast<int64_t>(u64(8)); es_lite.total_ran = static_cast<int64_t>(u64(10));
+                    es_lite.threshold_eff = __longlong_as_double(static_cast<long long>(u64(12)));
+                    es_lite.abt_val = __longlong_as_double(static_cast<long long>(u64(14)));
+                }
+                if (it > 0 && es_lite.stopped == 0) {        // (block-uniform: every wave takes the barrier)
+                    // The block's FIRST wave totals the accumulator slots and applies the rule; the other three only take the
+                    // outcome -- stop flag and the three buffer roles -- from LDS.  (Round 3 had every wave redo the rule from
+                    // the totals: ~100 VALU instructions per wave of a launch that is VALU-bound at streaming sizes.)
+                    __shared__ int fold_out[4];
+                    if (threadIdx.x < kWave) {
+                        float tot[kEsSums];
+                        if constexpr (VEC == 4) {        // (fetched here, not at the top: twelve registers less across the loads)
+                            const double* src = es_acc_set(d, d.es_index - 1) + static_cast<size_t>(threadIdx.x) * 8;
+#pragma unroll
+                            for (int k = 0; k < kEsSums; ++k) es_fv[k] = src[k];
+                        }
+                        es_slot_total(es_fv, tot);
+                        const bool hp = es_lite.cur_slot >= 0, ha = es_lite.anchor_slot >= 0;
+                        es_decide(d, es_lite, tot, hp, ha, it - 1, es_keeper);
+                        if (threadIdx.x == 0) {
+                            fold_out[0] = es_lite.stopped; fold_out[1] = es_lite.cur_slot;
+                            fold_out[2] = es_lite.anchor_slot; fold_out[3] = es_lite.write_slot;
+                        }
+                    }
+                    __syncthreads();
+                    if (threadIdx.x >= kWave) {
+                        es_lite.stopped = fold_out[0]; es_lite.cur_slot = fold_out[1];
+                        es_lite.anchor_slot = fold_out[2]; es_lite.write_slot = fold_out[3];
+                    }
+                }
+                if ((fl & LP_FL_ES_CLOSE) && it + 1 == d.es_n_steps) {
+                    // last launch of the loop and no closing decision kernel (LP_FL_ES_CLOSE): unless the loop has
+                    // stopped, this launch commits iteration `it` -- account it now and tell the host the call is done
+                    if (es_lite.stopped == 0) {
+                        es_lite.n_ran = it + 1;
+                        es_lite.total_ran += 1;
+                    }
+                    if (es_keeper) {
+                        // (this launch's own slot only: other blocks may still be reading the other one; the next
+                        // reset takes the running count from whichever slot is ahead)
+                        es_store_dynamic(d.es + (it & 1), es_lite);
+                        if (double* host = d.es_host) {
+                            host[1] = static_cast<double>(es_lite.n_ran); host[2] = static_cast<double>(es_lite.stopped);
+                            host[3] = es_lite.enabled ? 1.0 : 0.0; host[4] = es_lite.threshold_eff; host[5] = es_lite.abt_val;
+                            host[6] = static_cast<double>(es_lite.total_ran);
+                            es_post_seq(host, es_lite.seq_base + LP_ES_SEQ_DONE);
+                        }
+                    }
+                } else if (es_keeper) {
+                    es_store_dynamic(d.es + (it & 1), es_lite);
+                }
+                es_prev = es_lite.cur_slot; es_anchor = es_lite.anchor_slot; es_write = es_lite.write_slot;
+                es_idle = es_lite.stopped != 0;      // stopped: only re-emit x_in from the committed x_t (stores below)
+        };
         // ---- issue every load of this launch before any arithmetic ---------------------
         float m[VEC], xt[VEC], yv[VEC], cv[VEC], x0[VEC], x0b[VEC], xi_a[VEC], xi_b[VEC], corr[VEC];
         float xv[VEC], kn[VEC], nv[VEC], rs[VEC], abt_e[VEC], ve_e[VEC];
@@ -561,8 +646,15 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         // reads: the loads run under the lanes' predicate, and a 128-byte line no active lane touches is not fetched
         // (eight lanes = 32 consecutive elements of one region; 50 % box on 1.2 GB: -7 %, disc -4 %).
         constexpr bool RA = HARD && VEC == 4 && !ST && (PH & kPost) != 0;
+        // Wave-uniform ARITHMETIC (round 4; the streaming kernel turned out VALU-bound, not bandwidth-bound: 538 VALU
+        // instructions per wave keep the SIMDs > 80 % busy, profiles/r04_sq_*.md): a wave whose 256 mask bits are all 0 or
+        // all 1 takes its region's coefficients from SGPRs -- no mask decode, no per-element selects -- through the very
+        // expressions of the per-element path (same operations on the same values: bit-identical results).
+        constexpr bool UNI = HARD && VEC == 4 && !ST && (PH & (kPost | LP_PH_PRE_HALF)) != 0 && (PH & LP_PH_REPLACE) == 0;
+        int uni = -1;                                // 0: every element inpaint, 1: every element known, -1: mixed
         bool need_x0 = true, need_known = true;
         bool lane_x0 = true, lane_known = true;
+        bool pair_x0 = true, pair_known = true;       // PAIR: either lane of the pair reads the stream
         if constexpr (PER_EL) {
             load_f32<VEC>(d.abt_el, i, abt_e);
             if (!flow) load_f32<VEC>(d.ve_el, i, ve_e);
@@ -577,16 +669,28 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 if constexpr (PER_EL) load_f32<VEC>(d.rsig_el, i, rs);
             }
         } else {
-            load_f32<VEC>(d.x_t, i, xt);
+            // a gated early-stop loop (below) starts iteration i >= 1 from the TENTATIVE state the launch before it left in
+            // es_xte -- x_t holds the committed post-iteration state, which only a stopped loop reads again
+            load_f32<VEC>((ES && es_gated && (ph & LP_PH_POST_STEADY)) ? d.es_xte : d.x_t, i, xt);
         }
         if ((ph & LP_PH_POST_STEADY) || ((ph & LP_PH_PRE_HALF) && !post)) load_f32<VEC>(d.C, i, cv);
+        if constexpr (UNI) {
+            const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;       // this lane's 4 mask bits
+            const bool any_known = __ballot(nib != 0u) != 0ull, any_inpaint = __ballot(nib != 0xFu) != 0ull;
+            uni = !any_known ? 0 : (!any_inpaint ? 1 : -1);
+        }
         if constexpr (RA) {
             if (!given && d.x0_big != d.x0 && !(fl & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP))) {   // (HARD: no corr_el)
                 const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;   // this lane's 4 mask bits
-                need_known = __ballot(nib != 0u) != 0ull;
-                need_x0 = __ballot(nib != 0xFu) != 0ull;
+                need_known = uni != 0;
+                need_x0 = uni != 1;
                 lane_known = nib != 0u;
                 lane_x0 = nib != 0xFu;
+                if constexpr (PAIR) {              // the pair's eight mask bits sit in the same word (its first element is 8 k)
+                    const uint32_t nib8 = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 24u)) & 0xFFu;
+                    pair_known = nib8 != 0u;
+                    pair_x0 = nib8 != 0xFFu;
+                }
             }
         }
         // ST: the same decision per SLOT -- the 64 elements one wave holds in slot k are consecutive.  A slot nobody in
@@ -605,8 +709,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             }
         }
         if (post) {
-            if (need_x0 && lane_x0) load_raw_w<VEC, X0W>(d.x0, x0dt, i_x0, x0_raw);
-            if (!(d.x0_big == d.x0 || given) && need_known && lane_known) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i_kn, x0b_raw);
+            if constexpr (PAIR) {
+                if (need_x0) load_raw_pair(d.x0, i, pair_x0, x0_raw);
+                if (!(d.x0_big == d.x0 || given) && need_known) load_raw_pair(d.x0_big, i, pair_known, x0b_raw);
+            } else {
+                if (need_x0 && lane_x0) load_raw_w<VEC, X0W>(d.x0, x0dt, i_x0, x0_raw);
+                if (!(d.x0_big == d.x0 || given) && need_known && lane_known) load_raw_w<VEC, X0W>(d.x0_big, x0dt, i_kn, x0b_raw);
+            }
         }
         // ---- from here on the descriptor proper is needed (the first wait for the argument segment) ----
         if constexpr (SMALL) load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
@@ -620,24 +729,36 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         }
         if ((ph & LP_PH_PRE_HALF) && host_pre) load_f32<VEC>(d.xi_pre, i, xi_b);
         // early stop: the previous x0s, the drift anchor and the ring weight the metric compares against
-        float x0p[VEC], anc[VEC], rg[VEC], xi_r[VEC], xt0[VEC], es_b0[VEC], es_b1[VEC], es_b2[VEC];
-        int es_dep_w = 0, es_dep_a = -1;
-        const bool es_redo = ES && es_gated && (ph & LP_PH_POST_STEADY);    // redo the tentative half-step of the last launch
+        float x0p[VEC], anc[VEC], rg[VEC], es_b0[VEC], es_b1[VEC], es_b2[VEC];
+        // The mask-edge ring weight (earlystop.py:32-49) of a HARD mask is 0 or 1 -- ring pixels are inpaint pixels, whose
+        // weight 1 - m is 1 -- so it travels as bits like the mask (LP_FL_ES_RING_BITS: 0.125 B instead of 4 B per element and
+        // one register instead of four; the phase-specialised hard-mask kernels take no other form, lp_step routes an fp32
+        // ring to the run-time kernels)
+        constexpr bool RING_BITS_ONLY = ES != 0 && HARD && PH != 0;
+        const bool ring_bits = RING_BITS_ONLY || (fl & LP_FL_ES_RING_BITS) != 0;
+        uint32_t rg_raw = 0u;
+        auto load_ring = [&]() {
+            if (!d.es_ring) return;
+            if (ring_bits) {
+                if constexpr (!ST) rg_raw = reinterpret_cast<const uint32_t*>(d.es_ring)[i >> 5];
+            } else {
+                if constexpr (!RING_BITS_ONLY) load_f32<VEC>(d.es_ring, i, rg);
+            }
+        };
+        auto ring_weight = [&](int k) -> float {
+            if (!d.es_ring) return 0.0f;
+            if (ring_bits) {
+                if constexpr (!ST) return static_cast<float>((rg_raw >> ((static_cast<uint32_t>(i) & 31u) + k)) & 1u);
+                else return 0.0f;
+            }
+            if constexpr (!RING_BITS_ONLY) return rg[k];
+            else return 0.0f;
+        };
         if constexpr (ES) {
             if (post) {
                 if constexpr (es_fold && VEC == 4) {
-                    // Streaming sizes: bytes count, one more dependent round trip does not.  The state this launch loaded is
-                    // the one BEFORE the pending verdict, and it already fixes what the verdict can select: the previous
-                    // x0s is the buffer the last iteration wrote (its write_slot), the drift anchor afterwards is either
-                    // the old anchor, that same buffer, or none.  So one history read, two while an anchor is held --
-                    // not three (C5: 52 -> 44 B per element; profiles/r03_microbench_es.log).
-                    es_dep_w = __builtin_amdgcn_readfirstlane(static_cast<int>(es_words[2].y));      // write_slot
-                    es_dep_a = __builtin_amdgcn_readfirstlane(static_cast<int>(es_words[2].x));      // anchor_slot
-                    if (d.es_index > 0) {
-                        load_f32<VEC>(es_dep_w == 0 ? d.es_x0s[0] : es_dep_w == 1 ? d.es_x0s[1] : d.es_x0s[2], i, es_b0);
-                        if (es_dep_a >= 0 && es_dep_a != es_dep_w)
-                            load_f32<VEC>(es_dep_a == 0 ? d.es_x0s[0] : es_dep_a == 1 ? d.es_x0s[1] : d.es_x0s[2], i, es_b1);
-                    }
+                    // (streaming sizes: see below -- the verdict is formed right here, behind the operand loads, and the history
+                    // loads follow it)
                 } else if constexpr (es_fold) {      // latency-bound sizes: which two of the three buffers the metric compares
                                                      // against is part of the pending verdict -- read all three, select later
                     load_f32<VEC>(d.es_x0s[0], i, es_b0);
@@ -647,10 +768,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                     if (es_prev >= 0) load_f32<VEC>(es_prev == 0 ? d.es_x0s[0] : es_prev == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0p);
                     if (es_anchor >= 0) load_f32<VEC>(es_anchor == 0 ? d.es_x0s[0] : es_anchor == 1 ? d.es_x0s[1] : d.es_x0s[2], i, anc);
                 }
-                if (d.es_ring) load_f32<VEC>(d.es_ring, i, rg);
+                if constexpr (!(es_fold && VEC == 4)) {
+                    load_ring();
+                }
             }
         }
 
+        if constexpr (ES == 2 && VEC == 4) form_verdict();      // operand loads in flight; history loads behind the noise (below)
         // per-call I/O pointers for the launches of this sigma call that live in a captured graph (lp_finalize)
         if (d.io_table_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
             d.io_table_out[0] = d.io_table_val[0];
@@ -698,88 +822,42 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                         const uint64_t li = static_cast<uint64_t>(elem_index(i, k));
                         if (draw_post) xi_a[k] = torch_normal(li, seed, seq, d.rng_bg, small);
                         if (draw_pre) xi_b[k] = torch_normal(li, seed, off_pre, d.rng_bg, small);
-                        if (es_redo) xi_r[k] = torch_normal(li, seed, seq - d.rng_inc, d.rng_bg, small);   // the last launch's PRE draw
                     }
                 }
             } else {
+                // every element index below 2^32 (any real latent): the Philox key does not depend on the element and its ten
+                // round keys are scalar -- one v_add less per round and element (lp_common.h, normal_pair_key)
+                const bool key_uniform = d.n_el <= 0xffffffffll;
+                const uint32_t key0 = philox_key(seed, seq, 0);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float za, zb;
-                    normal_pair(static_cast<uint64_t>(elem_index(i, k)), seq, seed, za, zb);
+                    const uint64_t e = static_cast<uint64_t>(elem_index(i, k));
+                    if (key_uniform) normal_pair_key(static_cast<uint32_t>(e), static_cast<uint32_t>(seq), key0, za, zb);
+                    else normal_pair(e, seq, seed, za, zb);
                     if (!host_post) xi_a[k] = za;
                     if (!host_pre) xi_b[k] = zb;
-                    if (es_redo) {                              // the sine branch of the last launch's pair
-                        normal_pair(static_cast<uint64_t>(elem_index(i, k)), seq - 1, seed, za, zb);
-                        xi_r[k] = zb;
-                    }
                 }
             }
         }
 
+        if constexpr (ES == 2 && VEC == 4) {
+            // exactly the buffers the metric compares against -- the previous x0s, the drift anchor while one is held, the ring
+            // bits of a 4-D latent -- now that the verdict (formed behind the operand loads, above) says which they are
+            if (post) {
+                if (es_prev >= 0) load_f32<VEC>(es_prev == 0 ? d.es_x0s[0] : es_prev == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0p);
+                if (es_anchor >= 0) load_f32<VEC>(es_anchor == 0 ? d.es_x0s[0] : es_anchor == 1 ? d.es_x0s[1] : d.es_x0s[2], i, anc);
+                load_ring();
+            }
+        }
         LP_CLK(2)
         LP_CLK_LOADS(3)
         // ---- folded early stop: the verdict of the previous iteration, now that its inputs have had time to arrive --
         if constexpr (ES) {
             if constexpr (es_fold) {
-                const int it = d.es_index;
-                {
-                    const auto u = [&](int w) { return __builtin_amdgcn_readfirstlane(static_cast<int>((w & 1) ? es_words[w >> 1].y : es_words[w >> 1].x)); };
-                    const auto u64 = [&](int w) { return (static_cast<uint64_t>(static_cast<uint32_t>(u(w + 1))) << 32) | static_cast<uint32_t>(u(w)); };
-                    static_assert(offsetof(lp_es_state, enabled) == 28 && offsetof(lp_es_state, seq_base) == 32 &&
-                                  offsetof(lp_es_state, abt_val) == 56, "lp_es_state layout");
-                    es_lite.stopped = u(0); es_lite.counter = u(1); es_lite.n_ran = u(2); es_lite.cur_slot = u(3);
-                    es_lite.anchor_slot = u(4); es_lite.write_slot = u(5); es_lite.enabled = u(7);
-                    es_lite.seq_base = static_cast<int64_t>(u64(8)); es_lite.total_ran = static_cast<int64_t>(u64(10));
-                    es_lite.threshold_eff = __longlong_as_double(static_cast<long long>(u64(12)));
-                    es_lite.abt_val = __longlong_as_double(static_cast<long long>(u64(14)));
-                }
-                if (it > 0 && es_lite.stopped == 0) {        // (block-uniform: every wave takes the barrier)
-                    __shared__ float fold_tot[kEsSums];
-                    float tot[kEsSums];
-                    if (threadIdx.x < kWave) {
-                        es_slot_total(es_fv, tot);
-                        if (threadIdx.x == 0) {
-#pragma unroll
-                            for (int k = 0; k < kEsSums; ++k) fold_tot[k] = tot[k];
-                        }
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int k = 0; k < kEsSums; ++k) tot[k] = fold_tot[k];
-                    const bool hp = es_lite.cur_slot >= 0, ha = es_lite.anchor_slot >= 0;
-                    es_decide(d, es_lite, tot, hp, ha, it - 1, es_keeper);
-                }
-                if ((fl & LP_FL_ES_CLOSE) && it + 1 == d.es_n_steps) {
-                    // last launch of the loop and no closing decision kernel (LP_FL_ES_CLOSE): unless the loop has
-                    // stopped, this launch commits iteration `it` -- account it now and tell the host the call is done
-                    if (es_lite.stopped == 0) {
-                        es_lite.n_ran = it + 1;
-                        es_lite.total_ran += 1;
-                    }
-                    if (es_keeper) {
-                        // (this launch's own slot only: other blocks may still be reading the other one; the next
-                        // reset takes the running count from whichever slot is ahead)
-                        es_store_dynamic(d.es + (it & 1), es_lite);
-                        if (double* host = d.es_host) {
-                            host[1] = static_cast<double>(es_lite.n_ran); host[2] = static_cast<double>(es_lite.stopped);
-                            host[3] = es_lite.enabled ? 1.0 : 0.0; host[4] = es_lite.threshold_eff; host[5] = es_lite.abt_val;
-                            host[6] = static_cast<double>(es_lite.total_ran);
-                            es_post_seq(host, es_lite.seq_base + LP_ES_SEQ_DONE);
-                        }
-                    }
-                } else if (es_keeper) {
-                    es_store_dynamic(d.es + (it & 1), es_lite);
-                }
-                es_prev = es_lite.cur_slot; es_anchor = es_lite.anchor_slot; es_write = es_lite.write_slot;
-                es_idle = es_lite.stopped != 0;      // stopped: only re-emit x_in from the committed x_t (stores below)
-                if (post) {
-                    if constexpr (VEC == 4) {       // es_b0 = the buffer the last iteration wrote (= es_prev), es_b1 = the old anchor
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) {
-                            x0p[k] = es_b0[k];
-                            anc[k] = es_anchor == es_dep_w ? es_b0[k] : es_b1[k];
-                        }
-                    } else {
+                if constexpr (VEC != 4) form_verdict();
+                if constexpr (VEC != 4) {
+                    if (post) {
 #pragma unroll
                         for (int k = 0; k < VEC; ++k) {
                             x0p[k] = es_prev == 0 ? es_b0[k] : es_prev == 1 ? es_b1[k] : es_b2[k];
@@ -788,17 +866,25 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                     }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) xt0[k] = xt[k];
         }
         LP_CLK(4)
         const bool live = active && !es_idle;         // lanes that commit results (a stopped folded loop only emits)
 
         // ---- decode what was loaded in a storage format --------------------------------------------
-        cvt_mask<VEC>(mfl, i, m_raw, m);
+        if (UNI && uni >= 0) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) m[k] = static_cast<float>(uni);
+        } else {
+            cvt_mask<VEC>(mfl, i, m_raw, m);
+        }
         if (post) {
-            cvt_raw<VEC>(x0dt, x0_raw, x0, i);
-            if (!(d.x0_big == d.x0 || given)) cvt_raw<VEC>(x0dt, x0b_raw, x0b, i);
+            if constexpr (PAIR) {
+                cvt_raw_pair(x0dt, x0_raw, x0);
+                if (!(d.x0_big == d.x0 || given)) cvt_raw_pair(x0dt, x0b_raw, x0b);
+            } else {
+                cvt_raw<VEC>(x0dt, x0_raw, x0, i);
+                if (!(d.x0_big == d.x0 || given)) cvt_raw<VEC>(x0dt, x0b_raw, x0b, i);
+            }
         }
 
         // ---- REPLACE: x = x(1-m) + known*m ; x_t = VP(x) -----------------------------------
@@ -825,15 +911,18 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         }
 
         // OU(x, dt/2, C) of lanpaint.py:280 for element k (table path or the reference's own formulas)
+        // (table form with the region's coefficients given: `q` is an SGPR set in a mask-uniform wave)
+        auto half_table = [&](float x, float c, float xi, const RegionCoef& q) -> float {
+            return rc.valid != 0.0f ? fmaf(q.e_half, x, fmaf(q.k_half, c, q.std_half * xi)) : x;
+        };
         auto half_step = [&](float x, float c, float xi, int k) -> float {
             const float mk = m[k];
             const bool table = HARD || (!PER_EL && ((mk == 0.0f) || (mk == 1.0f)));
             if (table) {
-                if (rc.valid != 0.0f) {
-                    const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
-                    return fmaf(q.e_half, x, fmaf(q.k_half, c, q.std_half * xi));
-                }
-                return x;
+                // (a branch, not a select between the two coefficient sets: each side then takes its set straight from SGPRs;
+                // a v_cndmask needs one of the two in VGPRs, ten registers pinned for the whole kernel)
+                if (mk == 1.0f) return half_table(x, c, xi, rc.reg[1]);
+                return half_table(x, c, xi, rc.reg[0]);
             }
             if constexpr (!HARD) {
                 ElemCoef e;
@@ -849,10 +938,6 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
 
         float x0s[VEC], xb[VEC];
         if constexpr (ES) {
-            if (es_redo) {          // the half-step the previous launch only emitted (same x_t, C and noise: same bits)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) xt[k] = half_step(xt[k], cv[k], xi_r[k], k);
-            }
             if (ph & LP_PH_POST_FIRST) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) xb[k] = xt[k];     // x_t_before of iteration 0 (earlystop.py:288)
@@ -880,27 +965,39 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) cv[k] = 0.0f;
             }
+            // table path of element k: two regions per row, no transcendental per element (`q`: the region's coefficients)
+            auto post_table = [&](int k, const RegionCoef& q, bool known_el) {
+                if (rc.valid != 0.0f) {
+                    const float s0 = (given || !known_el) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
+                    const float cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
+                    x0s[k] = s0;
+                    if (ph & LP_PH_POST_FIRST) {
+                        xt[k] = fmaf(q.e_full, xt[k], fmaf(q.k_full, cn, q.std_full * xi_a[k]));
+                    } else {
+                        const float xd = fmaf(cn - cv[k], q.dt, xt[k]);
+                        xt[k] = fmaf(q.e_half, xd, fmaf(q.k_half, cv[k], q.std_half * xi_a[k]));
+                    }
+                    cv[k] = cn;
+                } else {
+                    x0s[k] = x0[k];
+                }
+            };
+            if (UNI && uni >= 0) {               // mask-uniform wave: the region's coefficient set stays in SGPRs
+                if (uni == 0) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) post_table(k, rc.reg[0], false);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) post_table(k, rc.reg[1], true);
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float mk = m[k];
                 const bool table = HARD || (!PER_EL && !has_corr && ((mk == 0.0f) || (mk == 1.0f)));
                 if (table) {
-                    // table path: two regions per row, no transcendental per element
-                    if (rc.valid != 0.0f) {
-                        const RegionCoef& q = rc.reg[mk == 1.0f ? 1 : 0];
-                        const float s0 = (given || mk != 1.0f) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
-                        const float cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
-                        x0s[k] = s0;
-                        if (ph & LP_PH_POST_FIRST) {
-                            xt[k] = fmaf(q.e_full, xt[k], fmaf(q.k_full, cn, q.std_full * xi_a[k]));
-                        } else {
-                            const float xd = fmaf(cn - cv[k], q.dt, xt[k]);
-                            xt[k] = fmaf(q.e_half, xd, fmaf(q.k_half, cv[k], q.std_half * xi_a[k]));
-                        }
-                        cv[k] = cn;
-                    } else {
-                        x0s[k] = x0[k];
-                    }
+                    if (mk == 1.0f) post_table(k, rc.reg[1], true);
+                    else post_table(k, rc.reg[0], false);
                 } else if constexpr (!HARD) {
                     ElemCoef e;
                     if constexpr (PER_EL) {
@@ -941,10 +1038,28 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 if (live) {
                     store_f32<VEC>(es_write == 0 ? d.es_x0s[0] : es_write == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0s);
                     // weighted squared differences (earlystop.py:52-55): w1 = 1 - mask, w2 = ring
+                    if (UNI && uni == 1) {
+                        // every element of the wave is known: w1 = 1 - m = 0 and the ring (inpaint pixels next to known ones)
+                        // has none of them -- the wave adds exact zeros to all six sums, i.e. nothing
+                        es_zero_wave = true;
+                    } else if (UNI && uni == 0 && !d.es_ring) {
+                        // every element inpaint, no ring (5-D latents): w1 = 1 -- the products by 1.0f and the sums of the
+                        // weights are the same numbers without the multiplies
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            const float da = es_prev >= 0 ? x0s[k] - x0p[k] : xt[k] - xb[k];
+                            es_p[0] += da * da;
+                            es_p[1] += 1.0f;
+                            if (es_anchor >= 0) {
+                                const float db = x0s[k] - anc[k];
+                                es_p[4] += db * db;
+                            }
+                        }
+                    } else
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         const float w1 = 1.0f - m[k];
-                        const float w2 = d.es_ring ? rg[k] : 0.0f;
+                        const float w2 = ring_weight(k);
                         const float da = es_prev >= 0 ? x0s[k] - x0p[k] : xt[k] - xb[k];
                         const float da2 = da * da;
                         es_p[0] += da2 * w1;
@@ -968,10 +1083,19 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
 #pragma unroll
         for (int k = 0; k < VEC; ++k) xe[k] = xt[k];
         if (ph & LP_PH_PRE_HALF) {
+            if (UNI && uni == 0) {
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                xe[k] = half_step(xt[k], cv[k], xi_b[k], k);
-                if (!(ES && es_gated)) xt[k] = xe[k];
+                for (int k = 0; k < VEC; ++k) xe[k] = half_table(xt[k], cv[k], xi_b[k], rc.reg[0]);
+            } else if (UNI && uni == 1) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xe[k] = half_table(xt[k], cv[k], xi_b[k], rc.reg[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xe[k] = half_step(xt[k], cv[k], xi_b[k], k);
+            }
+            if (!(ES && es_gated)) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xt[k] = xe[k];
             }
         }
 
@@ -979,10 +1103,12 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         if (post && live) store_f32<VEC>(d.C, i, cv);
         if ((ph & kTouchXt) && live) store_f32<VEC>(d.x_t, i, xt);
         if constexpr (ES) {
-            if (es_fold && es_idle) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) xe[k] = xt0[k];
-            }
+            // gated loop: the state after the (tentative) half-step goes to es_xte, where the next launch picks it up; x_t
+            // keeps the post-iteration state.  (Round 3 had the next launch REDO the half-step from the same noise instead:
+            // a second Philox block + Box-Muller per element, ~200 VALU instructions per wave of a VALU-bound launch, to
+            // save these 4 bytes per element.)
+            if (es_gated && (ph & LP_PH_PRE_HALF) && live) store_f32<VEC>(d.es_xte, i, xe);
+            if (es_fold && es_idle) load_f32<VEC>(d.x_t, i, xe);       // stopped: re-emit x_in from the COMMITTED state
         }
 
         // ---- EMIT: model-space latent for the next backbone call --------------------------------
@@ -998,7 +1124,12 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 }
                 xo[k] = flow ? xe[k] / sc : xe[k] * sc;
             }
-            if (active) store_any<VEC>(d.x_in, xindt, i, xo);
+            if constexpr (PAIR) {
+                if (xindt != DT_F32) store_half_pair(d.x_in, xindt, i, xo);
+                else store_any<VEC>(d.x_in, xindt, i, xo);
+            } else {
+                if (active) store_any<VEC>(d.x_in, xindt, i, xo);
+            }
         }
     }
 
@@ -1015,7 +1146,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         // fp32 throughout, like the reference's own sums (earlystop.py:52-55), in a fixed order
         __shared__ float es_part[4][kEsSums];
         const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-        wave_sum_dpp(es_p);
+        if (!es_zero_wave) wave_sum_dpp(es_p);          // (a wave of known elements holds six exact zeros in every lane)
         if (lane == kWave - 1) {
 #pragma unroll
             for (int k = 0; k < kEsSums; ++k) es_part[wave][k] = es_p[k];
@@ -1188,6 +1319,8 @@ static hipError_t launch(const lp_step_desc& d, hipStream_t stream, Timer* timer
     }
 }
 
+static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
 template <int VEC>
 static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer* timer) {
     if (d.flags & LP_FL_PER_ELEMENT) return launch<VEC, MODE_PER_EL, 0>(d, stream, timer);
@@ -1196,10 +1329,15 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     // a bit-packed mask is hard by construction; the audio correction needs the general branch
     const bool hard = (d.flags & LP_FL_MASK_BITS) && d.corr_el == nullptr;
     const bool x0_half = x0_dtype(d.flags) != DT_F32;
+    // half-width heads of a streaming launch go 16 bytes per lane pair (lp_common.h): 16-byte aligned streams, rows of 8 k
+    // elements; anything else takes the run-time kernel with its 8-byte accesses
+    const bool pair_ok = VEC != 4 || !x0_half ||
+                         (aligned(d.x0, 16) && aligned(d.x0_big, 16) && (xin_dtype(d.flags) == DT_F32 || aligned(d.x_in, 16)) &&
+                          d.el_per_row % 8 == 0);
     if (d.flags & LP_FL_ES) {                                // inner early stop evaluated on the device
         // the two launches a loop repeats, specialised like the plain hot kernels (bit-packed mask, fp32 heads): the
         // run-time phase kernel spends 1.0 us of shader clock before its first operand load, these 0.6
-        if (hard && !x0_half && !d.xi_post && !d.xi_pre) {
+        if (hard && !x0_half && !d.xi_post && !d.xi_pre && (!d.es_ring || (d.flags & LP_FL_ES_RING_BITS))) {
             const bool rt = d.rng_kind == LP_RNG_TORCH;
             if (d.phases == (S | P | E))
                 return rt ? launch<VEC, MODE_HARD, S | P | E, 4, 1, false, 1>(d, stream, timer)
@@ -1228,6 +1366,7 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     (strided ? (x0_half ? launch<4, MODE_, PH_, 2, 1, true>(d, stream, timer) : launch<4, MODE_, PH_, 4, 1, true>(d, stream, timer)) \
      : x0_half ? (rng_torch ? launch<VEC, MODE_, PH_, 2, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 2, 0>(d, stream, timer)) \
                : (rng_torch ? launch<VEC, MODE_, PH_, 4, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 4, 0>(d, stream, timer)))
+    if (!pair_ok) return hard ? launch<VEC, MODE_HARD, 0>(d, stream, timer) : launch<VEC, MODE_ROW, 0>(d, stream, timer);
     if (hard) {
         switch (d.phases) {
             case S | P | E: return LP_HOT(MODE_HARD, S | P | E);   // steady state
@@ -1244,8 +1383,6 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     }
 #undef LP_HOT
 }
-
-static bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle) {
     Timer* timer = static_cast<Timer*>(timer_handle);
@@ -1303,9 +1440,10 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
         if (timer) return LP_E_UNSUPPORTED;      // an early-stop launch may be two kernels: no single event pair describes it
         if (per_el || !d.es || !d.es_partials || d.es_index < 0 || d.es_n_steps <= d.es_index) return LP_E_INVALID;
         if (!d.es_x0s[0] || !d.es_x0s[1] || !d.es_x0s[2]) return LP_E_INVALID;
-        if ((d.flags & LP_FL_ES_GATED) && (d.xi_post || d.xi_pre)) return LP_E_INVALID;   // the redo needs an in-kernel generator
+        if ((d.flags & LP_FL_ES_GATED) && !d.es_xte) return LP_E_INVALID;                 // the tentative-state buffer of a gated loop
         if ((d.flags & LP_FL_ES_CLOSE) && !(d.flags & LP_FL_ES_GATED)) return LP_E_INVALID;
-    } else if (d.flags & (LP_FL_ES_GATED | LP_FL_ES_CLOSE)) {
+        if ((d.flags & LP_FL_ES_RING_BITS) && (!(d.flags & LP_FL_MASK_BITS) || !aligned(d.es_ring, 4))) return LP_E_INVALID;
+    } else if (d.flags & (LP_FL_ES_GATED | LP_FL_ES_CLOSE | LP_FL_ES_RING_BITS)) {
         return LP_E_INVALID;
     }
 

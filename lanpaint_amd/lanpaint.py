@@ -166,6 +166,7 @@ class _DeviceStop:
         dev = like.device
         self.shape, self.device, self.n_cap = tuple(like.shape), dev, max(8, int(n_steps))
         self.x0s = [torch.empty_like(like) for _ in range(3)]
+        self.x_te = torch.empty_like(like)      # gated loops: the state after the tentative half-step (lp_step_desc.es_xte)
         init = _cabi.LpEsState()
         init.cur_slot = init.anchor_slot = -1
         for k in range(3):
@@ -180,7 +181,7 @@ class _DeviceStop:
         self.i64 = self.mailbox.view(torch.int64).numpy()
         self.seq_base = 0
         self.seen_total = 0         # of the device's running iteration count, what the engine has accounted already
-        self.ring = None            # (weakref(mask), version, ring tensor | None)
+        self.ring = None            # (weakref(mask), version, ring tensor | None, bit-packed ring | None)
 
     def matches(self, like, n_steps):
         return self.shape == tuple(like.shape) and self.device == like.device and n_steps <= self.n_cap
@@ -203,8 +204,19 @@ class _DeviceStop:
                     _cabi.check(_cabi.load().lp_boundary_ring(mask.data_ptr(), ring.data_ptr(), b * ch, h, w,
                                                               torch.cuda.current_stream(mask.device).cuda_stream),
                                 "lp_boundary_ring")
-            self.ring = c = (weakref.ref(key), ver, ring)
+            bits = None
+            if ring is not None:       # the bit-packed form the hard-mask kernels read (LP_FL_ES_RING_BITS): ring pixels are inpaint
+                # pixels, so with a binary mask the weight (1 - m) on them is exactly 1 and the ring IS a bit per element
+                bits = torch.empty(_cabi.mask_bits_bytes(ring.numel()), dtype=torch.uint8, device=ring.device)
+                with torch.cuda.device(mask.device):
+                    _cabi.check(_cabi.load().lp_pack_mask(ring.data_ptr(), ring.numel(), 0, bits.data_ptr(), None,
+                                                          torch.cuda.current_stream(mask.device).cuda_stream), "lp_pack_mask")
+            self.ring = c = (weakref.ref(key), ver, ring, bits)
         return c[2]
+
+    def ring_bits(self):
+        """Bit-packed form of the ring `ring_for` returned last (None for latents without a ring)."""
+        return self.ring[3] if self.ring is not None else None
 
     def wait(self, seq, device):
         """Block until the mailbox sequence word reaches `seq` (spin briefly, then sleep on the stream)."""
@@ -1376,13 +1388,16 @@ class LanPaint:
         if es is not None and es["device"] and not per_el and not st.compat and corr is None and n_steps > 0:
             ds = ds if ds is not None else self._device_stop(xc, n_steps)
             ring = ds.ring_for(latent_mask if latent_mask.shape == shape else m, m)
-            st.es = dict(es, ds=ds, seq=ds.next_seq(), ring=ring)
+            # a bit-packed mask is binary: the ring then travels as bits too (the phase-specialised kernels take no other form)
+            ring_bits = ds.ring_bits() if (ring is not None and m_flag == LP_FL_MASK_BITS) else None
+            st.es = dict(es, ds=ds, seq=ds.next_seq(), ring=ring, ring_flag=_cabi.LP_FL_ES_RING_BITS if ring_bits is not None else 0)
             d.es, d.es_reset, d.es_seq_base = ds.state.data_ptr(), 1, st.es["seq"]
             d.es_threshold, d.es_patience_eff, d.es_n_steps = es["threshold"], es["patience_eff"], n_steps
             d.es_host, d.es_partials = ds.mailbox.data_ptr(), ds.partials.data_ptr()
             for k in range(3):
                 d.es_x0s[k] = ds.x0s[k].data_ptr()
-            d.es_ring = ring.data_ptr() if ring is not None else None
+            d.es_ring = ring_bits.data_ptr() if ring_bits is not None else (ring.data_ptr() if ring is not None else None)
+            d.es_xte = ds.x_te.data_ptr()
         if not defer_launch:
             self._launch_step(stream)
         st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
@@ -1569,11 +1584,11 @@ class LanPaint:
             output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
             if gated:
                 close = LP_FL_ES_CLOSE if (last and self._es_close) else 0
-                alive = self._set_model_output(d, output, base_flags | LP_FL_ES | LP_FL_ES_GATED | close | self._emit(st, last), shape)
+                alive = self._set_model_output(d, output, base_flags | LP_FL_ES | LP_FL_ES_GATED | es["ring_flag"] | close | self._emit(st, last), shape)
                 d.phases = (LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY) | (0 if last else LP_PH_PRE_HALF) | LP_PH_EMIT
                 self._set_xi(d, ws.x_t, want_pre=not last)
             else:
-                alive = self._set_model_output(d, output, base_flags | LP_FL_ES, shape)
+                alive = self._set_model_output(d, output, base_flags | LP_FL_ES | es["ring_flag"], shape)
                 d.phases = LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY
                 self._set_xi(d, ws.x_t, want_pre=False)
             d.es_index = i

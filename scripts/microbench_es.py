@@ -55,6 +55,7 @@ def es_setup(gated, host=True, index=1):
         ds = _DeviceStop(keep[0]["x_t"], 64)
         d.flags |= _cabi.LP_FL_ES | (_cabi.LP_FL_ES_GATED if gated else 0)
         d.es, d.es_partials, d.es_host = ds.state.data_ptr(), ds.partials.data_ptr(), ds.mailbox.data_ptr() if host else None
+        d.es_xte = ds.x_te.data_ptr()
         for k in range(3):
             d.es_x0s[k] = ds.x0s[k].data_ptr()
         d.es_threshold, d.es_patience_eff, d.es_index, d.es_n_steps = 1e-30, 2, index, 64

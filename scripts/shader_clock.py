@@ -27,17 +27,18 @@ STAMPS = ["kernel entry", "operand loads issued", "noise generated", "operands a
           "arithmetic done", "stores issued", "block sums written"]
 
 
-def run(wl, early_stop):
+def run(wl, early_stop, half=False):
     dev = torch.device("cuda", 0)
     lib = _cabi.load()
     steady = _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT
-    d, keep, n_el = bench.standalone_step(_cabi, wl, dev, steady)
+    d, keep, n_el = bench.standalone_step(_cabi, wl, dev, steady, model_dtype=torch.bfloat16 if half else None)
     clk = torch.zeros(32, dtype=torch.float64, device=dev)
     d.clk_out = clk.data_ptr()
     if early_stop:
         ds = _DeviceStop(keep[0]["x_t"], 64)
         d.flags |= _cabi.LP_FL_ES | _cabi.LP_FL_ES_GATED
         d.es, d.es_partials, d.es_host = ds.state.data_ptr(), ds.partials.data_ptr(), None
+        d.es_xte = ds.x_te.data_ptr()
         for k in range(3):
             d.es_x0s[k] = ds.x0s[k].data_ptr()
         d.es_threshold, d.es_patience_eff, d.es_index, d.es_n_steps = 1e-30, 2, 1, 64
@@ -64,8 +65,10 @@ def run(wl, early_stop):
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / (40 * reps) * 1e6
     h = clk.cpu().numpy()
-    label = "early-stop launch (gated, verdict folded in)" if early_stop else "plain steady launch"
+    label = ("early-stop launch (gated, verdict folded in)" if early_stop else "plain steady launch") + (", bf16 heads in / bf16 x_in out" if half else "")
     print(f"\n{wl}, {label}: {us:.2f} us per launch in a replayed graph of {reps} (instrumented build)")
+    print(f"  the last block entered {(h[30] - h[14]) * 10.0:.0f} ns after the first one (s_memrealtime, 10 ns ticks): the time the "
+          f"dispatcher needs to start the launch's {d.el_per_row * d.rows // (4 if n_el > 512 * 1024 else 1) // 256} blocks")
     for name, o in (("first block", h[0:16]), ("last block", h[16:32])):
         last = max(o[:len(STAMPS)])
         ns_per_tick = o[15] * 10.0 / last if last else 0.0          # s_memrealtime counts 100 MHz
@@ -77,5 +80,9 @@ def run(wl, early_stop):
 
 if __name__ == "__main__":
     wl = sys.argv[1] if len(sys.argv) > 1 else "c2_sdxl"
-    run(wl, False)
-    run(wl, True)
+    if len(sys.argv) > 2 and sys.argv[2] == "bf16":          # fp32 heads against bf16 heads, plain launch
+        run(wl, False)
+        run(wl, False, half=True)
+    else:
+        run(wl, False)
+        run(wl, True)

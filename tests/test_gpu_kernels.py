@@ -556,6 +556,59 @@ def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase, r
     assert not torch.equal(res[0][0], x_t0) and torch.isfinite(res[0][0]).all()
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", ["temporal", "box", "blob"])
+@pytest.mark.parametrize("phase", ["steady", "first", "last"])
+def test_half_width_streams_in_lane_pairs_equal_the_eight_byte_path(lib, kind, phase, half):
+    """Round 4: bf16 / fp16 backbone outputs (and a half-width x_in) of a streaming launch are read / written 16 bytes per
+    LANE PAIR (even lane loads, DPP hands the odd lane its half).  The same launch on head / x_in buffers that sit 8 bytes off
+    a 16-byte boundary cannot take that path (lp_step routes it to the run-time kernel with 8-byte accesses): x_t, C and x_in
+    must come out bit for bit the same -- with the region-aware stream skipping (which predicates the pair loads) and
+    without it, on a mask of large uniform regions, one with mixed waves only and a disc."""
+    import torch
+    import bench
+    from lanpaint_amd import _cabi
+    dev = torch.device("cuda", 0)
+    dt = torch.bfloat16 if half == "bf16" else torch.float16
+    ph = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
+          "first": _cabi.LP_PH_POST_FIRST | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
+          "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT}[phase]
+    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
+    bench.MASK_KIND, bench.MASK_FORMAT = kind, "bits"
+    try:
+        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph, model_dtype=dt)
+    finally:
+        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    bufs = keep[0]
+    # copies of the two heads and an x_in buffer 8 bytes (4 half elements) off a 16-byte boundary
+    pad = {k: torch.zeros(n_el + 8, dtype=dt, device=dev) for k in ("x0", "x0b", "x_in")}
+    off = {k: pad[k][4:4 + n_el] for k in pad}
+    off["x0"].copy_(bufs["x0"].reshape(-1))
+    off["x0b"].copy_(bufs["x0b"].reshape(-1))
+    assert all(t.data_ptr() % 16 == 8 for t in off.values()) and all(bufs[k].data_ptr() % 16 == 0 for k in ("x0", "x0b", "x_in"))
+    st = torch.cuda.current_stream().cuda_stream
+    x_t0, c0 = bufs["x_t"].clone(), bufs["C"].clone()
+    res = {}
+    for skip in (0, _cabi.LP_FL_NO_REGION_SKIP):
+        for path in ("pair", "eight"):
+            bufs["x_t"].copy_(x_t0)
+            bufs["C"].copy_(c0)
+            src = bufs if path == "pair" else off
+            src["x_in"].zero_()
+            d.x0, d.x0_big, d.x_in = src["x0"].data_ptr(), src["x0b"].data_ptr(), src["x_in"].data_ptr()
+            d.flags = (d.flags & ~_cabi.LP_FL_NO_REGION_SKIP) | skip
+            d.rng_offset = 11
+            _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+            torch.cuda.synchronize()
+            res[(skip, path)] = [bufs["x_t"].clone(), bufs["C"].clone(), src["x_in"].reshape(-1).clone()]
+    ref = res[(0, "eight")]
+    for key, got in res.items():
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), key
+    assert not torch.equal(ref[0], x_t0) and torch.isfinite(ref[0]).all() and torch.isfinite(ref[2].float()).all()
+    assert float(ref[2].float().abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("n", [1, 2, 4])
 @pytest.mark.parametrize("stops", [False, True])
 def test_self_closing_gated_loop_through_the_c_abi(lib, stops, n):
@@ -583,6 +636,7 @@ def test_self_closing_gated_loop_through_the_c_abi(lib, stops, n):
         mailbox = torch.zeros(_cabi.LP_ES_TRACE0 + 8 * n, dtype=torch.float64, device=dev)
         base = d.flags
         d.es, d.es_partials, d.es_host = ds.state.data_ptr(), ds.partials.data_ptr(), mailbox.data_ptr()
+        d.es_xte = ds.x_te.data_ptr()
         for k in range(3):
             d.es_x0s[k] = ds.x0s[k].data_ptr()
         d.es_threshold, d.es_patience_eff, d.es_n_steps, d.es_seq_base = 1e-30, 2, n, 1000
