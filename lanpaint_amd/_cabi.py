@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -159,6 +159,7 @@ EXPORTS = {
     "lp_node_call": (C.c_int, [C.POINTER(LpNodeCallDesc), C.c_void_p]),
     "lp_effective_inner_steps": (C.c_int32, [C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double]),
     "lp_pack_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lp_pack_mask_latent": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lp_reshape_mask": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]),
 }
 

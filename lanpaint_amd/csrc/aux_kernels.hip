@@ -349,7 +349,7 @@ int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int 
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lp_pack_mask_kernel(const float* __restrict__ mask, int64_t n_el, uint32_t flags,
                                                            unsigned long long* __restrict__ bits,
-                                                           int32_t* __restrict__ nonbinary) {
+                                                           int32_t* __restrict__ nonbinary, float* __restrict__ latent_out) {
     const int64_t words = (n_el + 63) / 64;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -360,20 +360,22 @@ __global__ __launch_bounds__(256) void lp_pack_mask_kernel(const float* __restri
         const float v = (i < n_el) ? mask[i] : ((flags & LP_FL_MASK_DENOISE) ? 1.0f : 0.0f);
         soft |= !(v == 0.0f || v == 1.0f);
         const bool hi = v > 0.5f;
-        const unsigned long long word = __ballot((flags & LP_FL_MASK_DENOISE) ? !hi : hi);
+        const bool known = (flags & LP_FL_MASK_DENOISE) ? !hi : hi;
+        const unsigned long long word = __ballot(known);
         if (lane == 0) bits[w] = word;
+        if (latent_out && i < n_el) latent_out[i] = known ? 1.0f : 0.0f;       // the fp32 latent_mask of nodes.py:281-283
     }
     if (nonbinary && !(flags & LP_FL_MASK_DENOISE) && __ballot(soft) != 0ull && lane == 0) *nonbinary = 1;
 }
 
-int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary,
+int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, float* latent_out,
                        hipStream_t stream) {
     if (!mask || !bits || n_el <= 0 || (flags & ~LP_FL_MASK_DENOISE) || !aligned(bits, 8)) return LP_E_INVALID;
     const int64_t words = (n_el + 63) / 64;
     int64_t bx = (words + 3) / 4;                       // 4 waves per block
     if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(lp_pack_mask_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, mask, n_el, flags,
-                       static_cast<unsigned long long*>(bits), nonbinary);
+                       static_cast<unsigned long long*>(bits), nonbinary, latent_out);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 

@@ -28,7 +28,8 @@ int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, in
 int wmse_dispatch(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
                   double* scratch, int scratch_blocks, hipStream_t stream);
 int torch_normal_dispatch(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t bg, hipStream_t stream);
-int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, hipStream_t stream);
+int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, float* latent_out,
+                       hipStream_t stream);
 int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int sw, float* dst, int db, int dc, int df,
                           int dh, int dw, int taps, int binarize, hipStream_t stream);
 }  // namespace lp
@@ -290,7 +291,12 @@ int lp_torch_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, ui
 }
 
 int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream) {
-    return lp::pack_mask_dispatch(mask, n_el, flags, bits, nonbinary, as_stream(stream));
+    return lp::pack_mask_dispatch(mask, n_el, flags, bits, nonbinary, nullptr, as_stream(stream));
+}
+
+int lp_pack_mask_latent(const float* mask, int64_t n_el, uint32_t flags, void* bits, float* latent_out, void* stream) {
+    if (!latent_out) return LP_E_INVALID;
+    return lp::pack_mask_dispatch(mask, n_el, flags, bits, nullptr, latent_out, as_stream(stream));
 }
 
 int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,

@@ -89,7 +89,11 @@ def pack_mask(latent_mask: torch.Tensor, *, denoise_mask: bool = False, check: b
     launch of the think loop reads 0.125 B instead of 4 B per element for it.  Returns the fp32 latent mask
     (1 = known) carrying `_lp_bits`; with `denoise_mask=True` the input is ComfyUI's denoise_mask and
     nodes.py:281-283 (`1 - (dm > 0.5)`) is folded into the same launch.  `check` (one host read) rejects soft
-    masks, for which the packed form would not be equivalent.  The mask must not be modified afterwards."""
+    masks, for which the packed form would not be equivalent.
+    The packed copy follows the tensor it was made from: the engine compares the tensor's version counter on every call
+    and re-packs IN PLACE (same bits buffer: captured graphs stay valid) when the mask was rewritten; a tensor without a
+    version counter (torch.inference_mode) is re-packed on every sigma call -- one small launch, what the reference does
+    on every call anyway (nodes.py:277-283)."""
     if not latent_mask.is_cuda:
         raise ValueError("pack_mask needs a mask on a HIP device")
     src = _as_f32c(latent_mask)
@@ -106,7 +110,40 @@ def pack_mask(latent_mask: torch.Tensor, *, denoise_mask: bool = False, check: b
     if out.dtype != torch.float32 or not out.is_contiguous():
         out = src
     out._lp_bits = bits
+    # what the bits were made from: (weak reference to the source tensor, its version then, denoise form?) -- see refresh_packed_mask
+    out._lp_bits_of = (weakref.ref(latent_mask), tensor_version(latent_mask), bool(denoise_mask))
     return out
+
+
+def refresh_packed_mask(packed: torch.Tensor, source: torch.Tensor = None) -> bool:
+    """Bring the bit-packed copy attached to `packed` (pack_mask's return value) up to date with the tensor it was made from
+    (`source`, default: the recorded one), IN PLACE -- same bits buffer, same fp32 latent mask tensor, so captured graphs and
+    the engine's identity checks keep matching.  A source with a version counter is re-packed only when the counter moved;
+    an inference tensor (no counter) every time.  One launch (lp_pack_mask_latent).  Returns True when it re-packed."""
+    rec = getattr(packed, "_lp_bits_of", None)
+    bits = getattr(packed, "_lp_bits", None)
+    if rec is None or bits is None:
+        return False
+    src = source if source is not None else rec[0]()
+    if src is None or not src.is_cuda or src.numel() != packed.numel():
+        return False
+    ver = tensor_version(src)
+    if ver != -1 and ver == rec[1] and (source is None or source is rec[0]()):
+        return False
+    s32 = _as_f32c(src)
+    denoise = rec[2]
+    # the fp32 latent mask is rewritten too unless it IS the source (pack_mask(latent_mask): the caller's own tensor)
+    same = (not denoise) and s32.data_ptr() == packed.data_ptr()
+    lib = _cabi.load()
+    with torch.cuda.device(src.device):
+        stream = raw_stream(src.device)
+        if same:
+            _cabi.check(lib.lp_pack_mask(s32.data_ptr(), s32.numel(), 0, bits.data_ptr(), None, stream), "lp_pack_mask")
+        else:
+            _cabi.check(lib.lp_pack_mask_latent(s32.data_ptr(), s32.numel(), _cabi.LP_FL_MASK_DENOISE if denoise else 0,
+                                                bits.data_ptr(), packed.data_ptr(), stream), "lp_pack_mask_latent")
+    packed._lp_bits_of = (weakref.ref(src), tensor_version(src) if same else ver, denoise)
+    return True
 
 
 def aten_randn_policy(numel: int, multi_processor_count: int, max_threads_per_multi_processor: int):
@@ -195,10 +232,13 @@ class _DeviceStop:
         mask tensor object `key` and version."""
         c = self.ring
         ver = (tensor_version(key), key.data_ptr())
-        if c is None or c[0]() is not key or c[1] != ver:
+        # (no version counter -- inference mode --: recomputed on every call; always into the SAME buffers when the shape allows,
+        # because captured early-stop launches bake the ring's address)
+        if c is None or c[0]() is not key or c[1] != ver or ver[0] == -1:
             ring = None
             if mask.dim() == 4:
-                ring = torch.empty_like(mask)
+                old = c[2] if c is not None else None
+                ring = old if (old is not None and old.shape == mask.shape and old.device == mask.device) else torch.empty_like(mask)
                 b, ch, h, w = mask.shape
                 with torch.cuda.device(mask.device):
                     _cabi.check(_cabi.load().lp_boundary_ring(mask.data_ptr(), ring.data_ptr(), b * ch, h, w,
@@ -207,7 +247,10 @@ class _DeviceStop:
             bits = None
             if ring is not None:       # the bit-packed form the hard-mask kernels read (LP_FL_ES_RING_BITS): ring pixels are inpaint
                 # pixels, so with a binary mask the weight (1 - m) on them is exactly 1 and the ring IS a bit per element
-                bits = torch.empty(_cabi.mask_bits_bytes(ring.numel()), dtype=torch.uint8, device=ring.device)
+                old_bits = c[3] if c is not None else None
+                n_bytes = _cabi.mask_bits_bytes(ring.numel())
+                bits = old_bits if (old_bits is not None and old_bits.numel() == n_bytes and old_bits.device == ring.device) \
+                    else torch.empty(n_bytes, dtype=torch.uint8, device=ring.device)
                 with torch.cuda.device(mask.device):
                     _cabi.check(_cabi.load().lp_pack_mask(ring.data_ptr(), ring.numel(), 0, bits.data_ptr(), None,
                                                           torch.cuda.current_stream(mask.device).cuda_stream), "lp_pack_mask")
@@ -355,6 +398,7 @@ class LanPaint:
         self._fdesc = _cabi.LpFinalDesc()
         self._hyper = _cabi.LpHyper()
         self._noise_check = None                 # (weakref(noise), version, verdict)
+        self.assume_static_noise = False         # see _noise_is_zero
         self._noise_regenerated = False
         self._iterations_run = 0                 # think iterations executed (it/s accounting)
         self.last_inner_steps = 0
@@ -530,7 +574,11 @@ class LanPaint:
         recycles addresses), so it is paid once per sampling run."""
         c = self._noise_check
         ver = (tensor_version(noise), noise.data_ptr())
-        if c is None or c[0]() is not noise or c[1] != ver:
+        # a tensor without a version counter (inference mode) could have been rewritten in place unnoticed: its verdict is
+        # only kept when the caller vouches for the run's noise (`assume_static_noise`: KSAMPLER.sample builds the engine for ONE
+        # run, whose noise tensor ComfyUI creates once and never touches); otherwise it is re-read every call like the reference
+        stale = ver[0] == -1 and not self.assume_static_noise
+        if c is None or c[0]() is not noise or c[1] != ver or stale:
             self._noise_check = c = (weakref.ref(noise), ver, bool(torch.mean(torch.abs(noise)) < 1e-8))
         return c[2]
 
@@ -657,6 +705,12 @@ class LanPaint:
                                "there is no CPU fallback" % x.device.type)
         if self.rng == "torch" and not self._check_torch_stream(x.device):
             self.rng = "torch-eager"
+        # a bit-packed copy made from THIS tensor (pack_mask(latent_mask)) follows it: re-packed in place when the tensor was
+        # rewritten since, or -- no version counter (inference mode) -- on every call; masks derived from another tensor
+        # (KSamplerX0Inpaint's, from ComfyUI's denoise_mask) are kept current by whoever derived them
+        rec = getattr(latent_mask, "_lp_bits_of", None)
+        if rec is not None and not rec[2] and rec[0]() is latent_mask:
+            refresh_packed_mask(latent_mask)
         self._es_opts = self._es_options(model_options)
         if self._es_pending is not None and (self._es_opts is None or self._es_opts["trace"] is not None
                                              or self._es_pending[0] is not self._ds):

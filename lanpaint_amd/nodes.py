@@ -28,7 +28,7 @@ import torch
 
 from . import _cabi
 from .blend import MaskBlend, gaussian_kernel_2d, merge_video_with_mask  # noqa: F401
-from .lanpaint import LanPaint, pack_mask, raw_stream, tensor_version
+from .lanpaint import LanPaint, pack_mask, raw_stream, refresh_packed_mask, tensor_version
 from .types import FusedCFGHeads
 
 try:                                    # ComfyUI present (or stubbed by tests)
@@ -337,6 +337,15 @@ class KSamplerX0Inpaint:
         denoise_mask_function may hand back a fresh tensor at a recycled address every step)."""
         c = self._mask_cache
         ver = (tensor_version(denoise_mask), denoise_mask.data_ptr())
+        if (c is not None and c[0]() is denoise_mask and c[1][1] == ver[1] and denoise_mask.is_cuda
+                and (c[1][0] != ver[0] or ver[0] == -1) and getattr(c[2], "_lp_bits", None) is not None):
+            # the same tensor object, possibly rewritten in place: its version counter moved, or it has none (ComfyUI runs its
+            # nodes under torch.inference_mode()).  The reference recomputes the mask on every call (nodes.py:277-283); here
+            # ONE launch re-derives both forms -- bits and fp32 -- into the buffers of the cached latent mask, so the object,
+            # its addresses and every capture made against them stay valid.
+            refresh_packed_mask(c[2], denoise_mask)
+            self._mask_cache = c = (c[0], ver, c[2])
+            return c[2]
         if c is None or c[0]() is not denoise_mask or c[1] != ver:
             if denoise_mask.is_cuda:
                 # binary by construction: the think loop streams 1 bit / element for it (one ballot launch)
@@ -525,6 +534,8 @@ class KSAMPLER(_KSAMPLER_BASE):
             EarlyStopPatience=getattr(patcher, "LanPaint_InnerPatience", 1),
             EarlyStopHook=extra_args.get("model_options", {}).get("lanpaint_semantic_hook", None),
             MinStepFrac=min_step_frac)
+        # this engine lives for ONE run; its noise tensor is created once per run (above / by the caller) and never rewritten
+        model_k.PaintMethod.assume_static_noise = True
         model_k.LanPaint_early_stop = patcher.LanPaint_EarlyStop
         model_k.LanPaint_min_step_frac = min_step_frac
 

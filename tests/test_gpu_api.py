@@ -706,3 +706,160 @@ def test_speculated_inner_step_counts_that_miss_leave_no_trace(rng, shape):
     for a, b in zip(res["0"][0] + [res["0"][1]], res["1"][0] + [res["1"][1]]):
         np.testing.assert_array_equal(a, b)
     assert torch.equal(res["0"][2], res["1"][2])
+
+
+# ---------------------------------------------------------------- caches vs tensors rewritten in place (round 4)
+def _oracle_schedule(sig, x0, y, noise, masks_by_call, n_think, draws):
+    """The oracle over a VE schedule whose latent mask may change from call to call (masks_by_call[i])."""
+    it = iter(draws)
+    o = orc.OracleLanPaint(MODELS["linear_tuple"](), n_think, 15.0, 5.0, 1.0, 0.2, randn=lambda like: next(it))
+    x, dens = x0.copy(), []
+    for i in range(len(sig)):
+        s = np.float32([sig[i]] * x0.shape[0])
+        den = o(x, y, noise, s, masks_by_call[i], orc.times_from_sigma(s, False), None, 0)
+        dens.append(den)
+        if i + 1 < len(sig):
+            x = (x + (x - den) / sig[i] * (sig[i + 1] - sig[i])).astype(np.float32)
+    return x, dens
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("inference", [False, True])
+def test_sampler_callable_follows_a_denoise_mask_rewritten_in_place(inference, graph):
+    """The reference recomputes its latent mask from `denoise_mask` on EVERY call (nodes.py:277-283), so a mask tensor that is
+    rewritten in place between two sigma calls takes effect at once.  KSamplerX0Inpaint keeps a packed copy per mask tensor:
+    it has to notice -- through the tensor's version counter, or, under torch.inference_mode() (how ComfyUI runs its nodes:
+    no counter), by re-deriving the copy on every call into the same buffers, so that eager launches AND replayed graphs
+    read the new mask.  Expected values: the oracle with the mask switched at the same call."""
+    import contextlib
+    import torch
+    from lanpaint_amd import LanPaint
+    from lanpaint_amd import nodes
+    shape, n_think, n_sig, switch = (1, 4, 16, 16), 3, 6, 3
+    sig = gc.karras_sigmas(n_sig, 0.1, 10.0)[:-1]
+    rng = np.random.default_rng(77)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    dm_a = np.zeros(shape, dtype=np.float32)
+    dm_a[..., 8:] = 1.0                                   # inpaint the right half ...
+    dm_b = np.zeros(shape, dtype=np.float32)
+    dm_b[..., :6, :] = 1.0                                # ... then (rewritten in place) the top rows
+    x0 = (y + noise * sig[0]).astype(np.float32)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    draws = gc.seeded_xi(4301, shape, n_sig * (2 * n_think - 1))
+    masks = [(1.0 - dm_a) if i < switch else (1.0 - dm_b) for i in range(n_sig)]
+    x_want, den_want = _oracle_schedule(sig, x0, y, noise, masks, n_think, draws)
+
+    class M(_DummyModel):
+        def __call__(self, x, sigma, model_options=None, seed=None):
+            return 0.9 * x, 0.8 * x
+
+    with (torch.inference_mode() if inference else contextlib.nullcontext()):
+        it = iter([tt(d) for d in draws])
+        model = M(_DummySampling())
+        model.model_type = "EPS"
+        k = nodes.KSamplerX0Inpaint(model, tt(np.concatenate([sig, [0.0]])))
+        k.latent_image, k.noise = tt(y), tt(noise)
+        # (recorded draws keep an engine eager; the replayed variant draws the same values from torch's generator instead)
+        k.PaintMethod = LanPaint(model, n_think, 15.0, 5.0, 1.0, 0.2, MinStepFrac=0.0, graph=graph,
+                                 rng=("torch" if graph else (lambda like: next(it))))
+        k.LanPaint_early_stop, k.LanPaint_min_step_frac = 0, 0.0
+        dm, x, mo = tt(dm_a), tt(x0), {}
+        if graph:      # torch's own stream: re-derive the expectation from what torch.randn returns for this seed
+            torch.manual_seed(991)
+            draws_t = [torch.randn(shape, device=DEV).cpu().numpy() for _ in range(len(draws))]
+            x_want, den_want = _oracle_schedule(sig, x0, y, noise, masks, n_think, draws_t)
+            torch.manual_seed(991)
+        for i in range(n_sig):
+            if i == switch:
+                dm.copy_(tt(dm_b))                        # IN PLACE: same tensor object, same address
+            s = torch.full((1,), float(sig[i]), dtype=torch.float32, device=DEV)
+            den = k(x, s, dm, model_options=mo, seed=0)
+            assert_close(den.cpu().numpy(), den_want[i], f"denoised[{i}]", rel=5e-5)
+            if i + 1 < n_sig:
+                x = x + (x - den) / float(sig[i]) * float(sig[i + 1] - sig[i])
+        assert_close(x.cpu().numpy(), x_want, "final x", rel=5e-5)
+        if graph:
+            assert len(k.PaintMethod._graphs) >= 1        # the rewritten mask did not cost the captures
+
+
+@pytest.mark.parametrize("inference", [False, True])
+def test_engine_repacks_a_packed_mask_that_was_rewritten_in_place(inference):
+    """`pack_mask(latent_mask)` attaches a bit-packed copy to the caller's mask; rewriting that mask in place afterwards used
+    to leave the copy stale.  The engine now re-packs it in place (version counter moved / no counter under inference mode)."""
+    import contextlib
+    import torch
+    from lanpaint_amd import LanPaint, pack_mask
+    shape, n_think, n_sig, switch = (2, 4, 16, 16), 2, 4, 2
+    sig = gc.karras_sigmas(n_sig, 0.2, 8.0)[:-1]
+    rng = np.random.default_rng(78)
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    m_a, m_b = gc.box_mask(shape), (rng.random(shape) > 0.5).astype(np.float32)
+    x0 = (y + noise * sig[0]).astype(np.float32)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    draws = gc.seeded_xi(4302, shape, n_sig * (2 * n_think - 1))
+    masks = [m_a if i < switch else m_b for i in range(n_sig)]
+    x_want, den_want = _oracle_schedule(sig, x0, y, noise, masks, n_think, draws)
+    with (torch.inference_mode() if inference else contextlib.nullcontext()):
+        it = iter([tt(d) for d in draws])
+        eng = LanPaint(MODELS["linear_tuple"](), n_think, 15.0, 5.0, 1.0, 0.2, rng=lambda like: next(it))
+        mask = pack_mask(tt(m_a))
+        bits_ptr = mask._lp_bits.data_ptr()
+        x, yg, ng = tt(x0), tt(y), tt(noise)
+        for i in range(n_sig):
+            if i == switch:
+                mask.copy_(tt(m_b))
+            s = torch.full((shape[0],), float(sig[i]), dtype=torch.float32, device=DEV)
+            den = eng(x, yg, ng, s, mask, gc.times_from_sigma(s, False), None, 0)
+            assert_close(den.cpu().numpy(), den_want[i], f"denoised[{i}]", rel=5e-5)
+            if i + 1 < n_sig:
+                x = x + (x - den) / float(sig[i]) * float(sig[i + 1] - sig[i])
+        assert_close(x.cpu().numpy(), x_want, "final x", rel=5e-5)
+        assert mask._lp_bits.data_ptr() == bits_ptr       # re-packed IN PLACE
+        assert np.array_equal(orc.unpack_mask_bits(mask._lp_bits.cpu().numpy(), mask.numel()).reshape(shape), m_b)
+
+
+def test_early_stop_ring_follows_the_mask_in_place_under_inference_mode():
+    """The mask-edge ring of the inner early stop (earlystop.py:32-49) is cached per mask tensor; a tensor without a version
+    counter gets it recomputed on every call, into the same buffers (captured early-stop launches bake their addresses)."""
+    import torch
+    from lanpaint_amd.lanpaint import _DeviceStop
+    shape = (1, 2, 12, 20)
+    rng = np.random.default_rng(5)
+    m_a, m_b = (rng.random(shape) > 0.5).astype(np.float32), (rng.random(shape) > 0.3).astype(np.float32)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    with torch.inference_mode():
+        mask = tt(m_a)
+        ds = _DeviceStop(mask, 4)
+        r1 = ds.ring_for(mask, mask)
+        p_ring, p_bits = r1.data_ptr(), ds.ring_bits().data_ptr()
+        assert np.array_equal(r1.cpu().numpy(), orc.boundary_weight(m_a, (1 - m_a).astype(np.float32)))
+        mask.copy_(tt(m_b))
+        r2 = ds.ring_for(mask, mask)
+        want = orc.boundary_weight(m_b, (1 - m_b).astype(np.float32))
+        assert r2.data_ptr() == p_ring and ds.ring_bits().data_ptr() == p_bits
+        assert np.array_equal(r2.cpu().numpy(), want)
+        assert np.array_equal(orc.unpack_mask_bits(ds.ring_bits().cpu().numpy(), mask.numel()).reshape(shape), (want > 0.5).astype(np.float32))
+
+
+def test_noise_verdict_is_rechecked_for_tensors_without_a_version_counter():
+    """lanpaint.py:51-52: noise that is all zeros is regenerated.  The verdict is cached per tensor version; an inference tensor
+    has none, so the engine re-reads it on every call unless the caller vouches for the run's noise (assume_static_noise,
+    which KSAMPLER.sample sets on the per-run engine it builds)."""
+    import torch
+    from lanpaint_amd import LanPaint
+    with torch.inference_mode():
+        eng = LanPaint(MODELS["linear_tuple"](), 2, 15.0, 5.0, 1.0, 0.2, rng="philox")
+        noise = torch.randn(1, 4, 8, 8, device=DEV)
+        assert eng._noise_is_zero(noise) is False
+        noise.zero_()
+        assert eng._noise_is_zero(noise) is True           # no counter: looked at again
+        eng.assume_static_noise = True
+        noise.normal_()
+        assert eng._noise_is_zero(noise) is True           # vouched for: the cached verdict stands
+    t = torch.randn(1, 4, 8, 8, device=DEV)
+    eng2 = LanPaint(MODELS["linear_tuple"](), 2, 15.0, 5.0, 1.0, 0.2, rng="philox")
+    assert eng2._noise_is_zero(t) is False
+    t.zero_()                                              # version counter moves: noticed without any flag
+    assert eng2._noise_is_zero(t) is True
