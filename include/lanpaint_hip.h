@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 16
+#define LP_ABI_VERSION 17
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -165,6 +165,15 @@ typedef struct lp_hyper {
                                           inpaint pixels: 1 - m = 1), so the launch reads 0.125 B / element for it and derives the
                                           weight in registers.  The phase-specialised hard-mask kernels take only this form; an fp32
                                           ring next to a bit-packed mask runs through the run-time kernels.                          */
+#define LP_FL_AV            (1u << 17) /* AV packs (MiniMax-H3 flat audio / video latents; lanpaint.py:60-74): every element runs on one of
+                                          TWO per-row time sets, chosen by a 0/1 indicator.  `coef` then holds two rows per batch row
+                                          (2 r: video times, 2 r + 1: audio times; lp_coeffs with 2 * rows inputs), `av_bits` the
+                                          bit-packed indicator (1 = audio; lp_pack_mask layout) and `av_frac` the share of audio
+                                          elements.  A wave whose elements all sit on one stream runs the ordinary table path on
+                                          that stream's row -- no per-element transcendental, where the reference-shaped
+                                          LP_FL_PER_ELEMENT form needs three full-size time tensors and evaluates exp / expm1 per
+                                          element; only the wave straddling the seam of a row uses the per-element formulas.
+                                          Not with LP_PH_COEFFS / LP_FL_PER_ELEMENT / LP_FL_ES_GATED.                          */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 
@@ -311,6 +320,9 @@ typedef struct lp_step_desc {
     double       sg_min_step_frac;
     int32_t      sg_schedule_len, sg_seq, sg_n_steps, sg_early_stop, sg_total_steps, sg_guess;
     double*      clk_out;
+    const void*  av_bits;        /* LP_FL_AV: bit-packed stream indicator, 1 = audio element (LP_MASK_BITS_BYTES(n_el) bytes)          */
+    float        av_frac;        /* LP_FL_AV: audio elements / all elements (the early-stop threshold uses the mean of the blended abt) */
+    uint32_t     reserved2;
     float*       es_xte;         /* LP_FL_ES_GATED: n_el floats, the state after the TENTATIVE first half-step of the next
                                     iteration (lanpaint.py:280).  A gated launch stores it next to the committed x_t; the next
                                     launch of the loop starts from it, a stopped loop never looks at it again.             */

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -28,7 +28,7 @@ LP_PH_REPLACE, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_EMIT, 
 LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
 LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED, LP_FL_MASK_BITS, LP_FL_NO_REGION_SKIP = 256, 512, 1024, 2048, 4096
-LP_FL_ES, LP_FL_ES_GATED, LP_FL_ES_CLOSE, LP_FL_ES_RING_BITS = 1 << 13, 1 << 14, 1 << 15, 1 << 16
+LP_FL_ES, LP_FL_ES_GATED, LP_FL_ES_CLOSE, LP_FL_ES_RING_BITS, LP_FL_AV = 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17
 LP_TUNE_VEC1, LP_TUNE_VEC4, LP_TUNE_ES_NO_DECIDE, LP_TUNE_ES_NO_FOLD = 1, 2, 4, 8
 
 
@@ -67,7 +67,8 @@ class LpStepDesc(C.Structure):
         ("sg_sigma", C.c_void_p), ("sg_schedule", C.c_void_p), ("sg_times_out", C.c_void_p), ("sg_scalars_out", C.c_void_p),
         ("sg_seq_out", C.c_void_p), ("sg_valid_out", C.c_void_p), ("sg_min_step_frac", C.c_double),
         ("sg_schedule_len", C.c_int32), ("sg_seq", C.c_int32), ("sg_n_steps", C.c_int32), ("sg_early_stop", C.c_int32),
-        ("sg_total_steps", C.c_int32), ("sg_guess", C.c_int32), ("clk_out", C.c_void_p), ("es_xte", C.c_void_p),
+        ("sg_total_steps", C.c_int32), ("sg_guess", C.c_int32), ("clk_out", C.c_void_p), ("av_bits", C.c_void_p), ("av_frac", C.c_float), ("reserved2", C.c_uint32),
+        ("es_xte", C.c_void_p),
         ("tune", C.c_uint32), ("io_valid", C.c_uint32),
     ]
 

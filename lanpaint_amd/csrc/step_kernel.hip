@@ -184,10 +184,18 @@ __device__ __forceinline__ double clamp01(double v) { return v <= 0.0 ? 0.0 : (v
 __device__ __forceinline__ void es_reset_state(const lp_step_desc& d, bool fold) {
     lp_es_state* es = d.es;
     const int n = fold ? (d.t_abt_stride ? d.rows : 1) : d.rows;
-    float sum = 0.0f;
-    for (int r = 0; r < n; ++r)
-        sum = sum + (fold ? d.t_abt[static_cast<int64_t>(r) * d.t_abt_stride]
-                          : d.coef[static_cast<int64_t>(r) * LP_COEF_STRIDE + LP_C_ABT]);
+    const bool av = (d.flags & LP_FL_AV) != 0;       // two table rows per batch row; the mean of the BLENDED abt tensor weighs
+    float sum = 0.0f;                                // them by the share of audio elements (lanpaint.py:70, earlystop.py:105-113)
+    for (int r = 0; r < n; ++r) {
+        if (av) {
+            const float v = d.coef[static_cast<int64_t>(2 * r) * LP_COEF_STRIDE + LP_C_ABT];
+            const float a = d.coef[static_cast<int64_t>(2 * r + 1) * LP_COEF_STRIDE + LP_C_ABT];
+            sum = sum + (v * (1.0f - d.av_frac) + a * d.av_frac);
+        } else {
+            sum = sum + (fold ? d.t_abt[static_cast<int64_t>(r) * d.t_abt_stride]
+                              : d.coef[static_cast<int64_t>(r) * LP_COEF_STRIDE + LP_C_ABT]);
+        }
+    }
     const double abt_val = static_cast<double>(sum / static_cast<float>(n));        // float(torch.mean(abt).item())
     const double a = clamp01(abt_val);
     const double thr_eff = d.es_threshold * clamp01(4.0 * a * (1.0 - a));
@@ -525,6 +533,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             }
         }
     } else {
+        if constexpr (PH == 0) {
+            // a replace launch that does not build the table (AV packs: lp_coeffs built both rows) still publishes the state
+            if ((ph & LP_PH_REPLACE) && d.rng_state_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+                d.rng_state_out[0] = d.rng_state_val[0];
+                d.rng_state_out[1] = d.rng_state_val[1];
+            }
+        }
         if constexpr (!PER_EL) {
             if constexpr (SMALL && PH != 0) rc = load_row_early(d.coef, row);
             else rc = load_row(d.coef, row);
@@ -559,6 +574,42 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             if constexpr (ST) return Strided(g, static_cast<int64_t>(d.rng_bg), st_base, st_lo, st_hi);
             else return row_base + g * VEC;
         }();
+
+        // ---- AV packs (LP_FL_AV; MiniMax-H3 flat audio / video packs, lanpaint.py:60-74) ---------------------------------------
+        // The reference blends per-stream times with a full-size 0/1 indicator (VE * (1 - ai) + VE_a * ai, ...): every element
+        // sits on exactly one of TWO per-row time sets.  The coefficient table then holds two rows per batch row (2 r: video,
+        // 2 r + 1: audio) and the indicator travels as bits; a wave whose elements all belong to one stream -- all but the
+        // wave that straddles the video / audio seam of a row -- simply takes that stream's row and runs the ordinary table
+        // path.  The straddling wave uses the reference's per-element formulas on the two rows' fp32 fields (elem_from_row).
+        // Run-time-phase row-table kernels only; the phase-specialised kernels never see the flag (lp_step routes it).
+        constexpr bool AVK = PH == 0 && MODE == MODE_ROW && !ST;
+        bool av_mixed = false;
+        uint32_t av_nib = 0u;                      // this lane's indicator bits (VEC of them)
+        RowCoef rc_b = rc;                         // the audio row where the wave needs both
+        if constexpr (AVK) {
+            if (fl & LP_FL_AV) {
+                const uint32_t word = static_cast<const uint32_t*>(d.av_bits)[i >> 5];
+                av_nib = (word >> (static_cast<uint32_t>(i) & 31u)) & ((1u << VEC) - 1u);
+                const bool any_audio = __ballot(active && av_nib != 0u) != 0ull;
+                const bool any_video = __ballot(active && av_nib != ((1u << VEC) - 1u)) != 0ull;
+                if (!any_audio) {
+                    rc = load_row(d.coef, 2 * row);
+                } else if (!any_video) {
+                    rc = load_row(d.coef, 2 * row + 1);
+                } else {
+                    av_mixed = true;
+                    rc = load_row(d.coef, 2 * row);
+                    rc_b = load_row(d.coef, 2 * row + 1);
+                }
+            }
+        }
+        // the row an element of a straddling wave belongs to (fields selected per lane), the launch's row otherwise
+        auto row_of = [&](int k) -> RowCoef {
+            if constexpr (AVK) {
+                if (av_mixed && ((av_nib >> k) & 1u)) return rc_b;
+            }
+            return rc;
+        };
 
         // The verdict of iteration i - 1, formed inside launch i (folded loops): state -> totals of the accumulator slots ->
         // stop rule.  Latency-bound sizes (VEC = 1) call it BEHIND the operand loads and the Philox rounds (one memory round
@@ -892,7 +943,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             if (d.replace_kind != LP_REPLACE_KNOWN) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const float r = PER_EL ? rs[k] : rc.rsigma;
+                    const float r = PER_EL ? rs[k] : (av_mixed ? row_of(k).rsigma : rc.rsigma);
                     kn[k] = (d.replace_kind == LP_REPLACE_VE) ? fmaf(nv[k], r, yv[k])
                                                               : (r * (d.noise_scale * nv[k]) + (1.0f - r) * yv[k]);
                 }
@@ -904,7 +955,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 if constexpr (PER_EL) {
                     sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
                 } else {
-                    sc = rc.scale;
+                    sc = av_mixed ? row_of(k).scale : rc.scale;
                 }
                 xt[k] = flow ? xr * sc : xr / sc;
             }
@@ -917,7 +968,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         };
         auto half_step = [&](float x, float c, float xi, int k) -> float {
             const float mk = m[k];
-            const bool table = HARD || (!PER_EL && ((mk == 0.0f) || (mk == 1.0f)));
+            const bool table = HARD || (!PER_EL && !av_mixed && ((mk == 0.0f) || (mk == 1.0f)));
             if (table) {
                 // (a branch, not a select between the two coefficient sets: each side then takes its set straight from SGPRs;
                 // a v_cndmask needs one of the two in VGPRs, ten registers pinned for the whole kernel)
@@ -929,7 +980,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 if constexpr (PER_EL) {
                     e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size, d.min_step_frac);
                 } else {
-                    e = elem_from_row(rc, mk);
+                    e = elem_from_row(row_of(k), mk);
                 }
                 if (e.valid) return ou_general(x, e.dt / 2.0f, e.a, c, e.d, xi);
             }
@@ -965,6 +1016,19 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) cv[k] = 0.0f;
             }
+            if constexpr (!HARD) {
+                if (has_corr) {       // lanpaint.py:173-180: both heads pulled towards the model-space input, before the split
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float sc;
+                        if constexpr (PER_EL) sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
+                        else sc = av_mixed ? row_of(k).scale : rc.scale;
+                        const float xm = flow ? xt[k] / sc : xt[k] * sc;
+                        x0[k] = xm + corr[k] * (x0[k] - xm);
+                        x0b[k] = xm + corr[k] * (x0b[k] - xm);
+                    }
+                }
+            }
             // table path of element k: two regions per row, no transcendental per element (`q`: the region's coefficients)
             auto post_table = [&](int k, const RegionCoef& q, bool known_el) {
                 if (rc.valid != 0.0f) {
@@ -994,7 +1058,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float mk = m[k];
-                const bool table = HARD || (!PER_EL && !has_corr && ((mk == 0.0f) || (mk == 1.0f)));
+                const bool table = HARD || (!PER_EL && !av_mixed && ((mk == 0.0f) || (mk == 1.0f)));
                 if (table) {
                     if (mk == 1.0f) post_table(k, rc.reg[1], true);
                     else post_table(k, rc.reg[0], false);
@@ -1004,14 +1068,9 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                         e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size,
                                             d.min_step_frac);
                     } else {
-                        e = elem_from_row(rc, mk);
+                        e = elem_from_row(row_of(k), mk);
                     }
-                    float h0 = x0[k], h1 = x0b[k];
-                    if (has_corr) {           // lanpaint.py:173-180
-                        const float xm = flow ? xt[k] / e.scale : xt[k] * e.scale;
-                        h0 = xm + corr[k] * (h0 - xm);
-                        h1 = xm + corr[k] * (h1 - xm);
-                    }
+                    const float h0 = x0[k], h1 = x0b[k];          // (the audio correction went into the heads above)
                     if (e.valid) {
                         float s0 = h0;
                         if (!given) {
@@ -1120,7 +1179,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 if constexpr (PER_EL) {
                     sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
                 } else {
-                    sc = rc.scale;
+                    sc = av_mixed ? row_of(k).scale : rc.scale;
                 }
                 xo[k] = flow ? xe[k] / sc : xe[k] * sc;
             }
@@ -1328,6 +1387,8 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
                        E = LP_PH_EMIT;
     // a bit-packed mask is hard by construction; the audio correction needs the general branch
     const bool hard = (d.flags & LP_FL_MASK_BITS) && d.corr_el == nullptr;
+    if (d.flags & LP_FL_AV)             // two time sets per row (AV packs): the run-time row-table kernels know the flag
+        return (d.flags & LP_FL_ES) ? launch<VEC, MODE_ROW, 0, 0, 2, false, 1>(d, stream, timer) : launch<VEC, MODE_ROW, 0>(d, stream, timer);
     const bool x0_half = x0_dtype(d.flags) != DT_F32;
     // half-width heads of a streaming launch go 16 bytes per lane pair (lp_common.h): 16-byte aligned streams, rows of 8 k
     // elements; anything else takes the run-time kernel with its 8-byte accesses
@@ -1401,6 +1462,12 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
             return LP_E_INVALID;
         if (!d.sg_sigma || !d.sg_schedule || d.sg_schedule_len <= 0 || !d.sg_scalars_out) return LP_E_INVALID;
         if (d.es_reset) return LP_E_UNSUPPORTED;      // (the early-stop reset reads abt from t_abt, which this launch only writes)
+    }
+    if (d.flags & LP_FL_AV) {      // coefficient table with two rows per batch row, built by lp_coeffs (not folded), indicator as bits
+        if (!d.av_bits || !aligned(d.av_bits, 4) || !d.coef || (d.flags & LP_FL_PER_ELEMENT) || (ph & (LP_PH_COEFFS | LP_PH_SIGMA)) ||
+            !(d.av_frac >= 0.0f && d.av_frac <= 1.0f))
+            return LP_E_INVALID;
+        if (d.flags & LP_FL_ES_GATED) return LP_E_UNSUPPORTED;      // (a stopped gated launch re-emits with ONE row's scale)
     }
     if (d.rng_kind != LP_RNG_PHILOX && d.rng_kind != LP_RNG_TORCH) return LP_E_INVALID;
     if (d.rng_kind == LP_RNG_TORCH && (d.rng_bg == 0 || (d.rng_inc & 3u) || d.rng_inc == 0)) return LP_E_INVALID;

@@ -146,6 +146,44 @@ def refresh_packed_mask(packed: torch.Tensor, source: torch.Tensor = None) -> bo
     return True
 
 
+def pack_indicator(indicator: torch.Tensor, shape) -> tuple:
+    """(bits, audio share) of an AV pack's stream indicator (lanpaint.py:68-73: 1 = audio element), or None when it is not a
+    0/1 tensor broadcastable to the latent -- then the reference-shaped per-element path runs.  Cached on the tensor (weak
+    identity + version; an inference tensor is re-packed on every call like a mask), one host read when first packed."""
+    if not indicator.is_cuda:
+        return None
+    ver = tensor_version(indicator)
+    rec = getattr(indicator, "_lp_av", None)
+    if rec is not None and rec[2] == tuple(shape) and rec[3] == ver and ver != -1:
+        return (rec[0], rec[1]) if rec[0] is not None else None
+    try:
+        full = _as_f32c(indicator if tuple(indicator.shape) == tuple(shape) else indicator.expand(shape))
+    except RuntimeError:
+        return None
+    n = full.numel()
+    bits = rec[0] if (rec is not None and rec[2] == tuple(shape) and rec[0].device == full.device) else \
+        torch.empty(_cabi.mask_bits_bytes(n), dtype=torch.uint8, device=full.device)
+    if rec is not None and rec[2] == tuple(shape) and ver == -1 and rec[0] is not None:
+        # no version counter: re-derive the bits in place on every call (no host read; the share of audio elements is a per-job
+        # constant of the pack layout and keeps its first value)
+        with torch.cuda.device(full.device):
+            _cabi.check(_cabi.load().lp_pack_mask(full.data_ptr(), n, 0, bits.data_ptr(), None, raw_stream(full.device)), "lp_pack_mask")
+        return bits, rec[1]
+    flag = torch.zeros(1, dtype=torch.int32, device=full.device)
+    with torch.cuda.device(full.device):
+        _cabi.check(_cabi.load().lp_pack_mask(full.data_ptr(), n, 0, bits.data_ptr(), flag.data_ptr(), raw_stream(full.device)),
+                    "lp_pack_mask")
+    frac = float(full.sum(dtype=torch.float64).item()) / n          # (the one host read; also waits for the flag)
+    if int(flag.item()):
+        indicator._lp_av = (None, 0.0, tuple(shape), ver)
+        return None
+    try:
+        indicator._lp_av = (bits, frac, tuple(shape), ver)
+    except Exception:
+        pass
+    return bits, frac
+
+
 def aten_randn_policy(numel: int, multi_processor_count: int, max_threads_per_multi_processor: int):
     """calc_execution_policy of ATen's random kernels for one fp32 randn of `numel` elements: 256-thread blocks, the
     grid capped at SMs * (maxThreadsPerSM / 256), four values per thread and loop trip.  Returns (block * grid,
@@ -185,6 +223,8 @@ class _Workspace:
         self.x_t = torch.empty_like(like)
         self.C = torch.empty_like(like)
         self.coef = torch.empty((like.shape[0], _cabi.LP_COEF_STRIDE), dtype=torch.float32, device=like.device)
+        self.coef_av = None      # lazily: [2 * rows][LP_COEF_STRIDE], two time sets per row (AV packs, LP_FL_AV)
+        self.av_times = None     # lazily: [4][2 * rows] interleaved (VE, abt, replace sigma, model time) inputs of that table
         self.x0s = []            # lazily: rotating buffers for LangevinState.x0 (early stop only)
         self.static_io = static_io
         if static_io:
@@ -942,7 +982,14 @@ class LanPaint:
         if any(t.numel() not in (1, rows) for t in (sigma, *current_times)):
             return False         # per-element times: the general path, eager only
         if self.audio_indicator is not None or self.audio_correction is not None:
-            return False
+            # AV packs replay only on the two-row table (LP_FL_AV: per-row time pairs + a 0/1 indicator), whose per-call inputs --
+            # the interleaved times, the correction tensor -- live in workspace buffers the prologue refreshes; the reference-
+            # shaped per-element form builds fresh full-size tensors per call, and a gated stop is not built for the table yet
+            if (self.audio_indicator is None or self.current_times_audio is None or self._es_opts is not None
+                    or any(t.numel() not in (1, rows) for t in self.current_times_audio)
+                    or os.environ.get("LANPAINT_AMD_AV_TABLE", "1") == "0"
+                    or pack_indicator(self.audio_indicator, x.shape) is None):
+                return False
         if self._es_opts is not None and (not self._es_opts["device"] or self.rng not in ("torch", "philox")):
             return False         # a custom distance_fn / a sharded batch keeps the stopper on the host; a gated loop
                                  # redoes its tentative half-step from a counter-based in-kernel generator only
@@ -1025,7 +1072,8 @@ class LanPaint:
                latent_mask.data_ptr(), m_c.data_ptr() if m_c is not None else 0, int(sigma.numel()),
                tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng, self._hyper_key(),
                self.model_dtype, None if self._es_opts is None else (self._es_opts["threshold"], self._es_opts["patience_eff"],
-                                                                      self._es_opts["trace"] is not None))
+                                                                      self._es_opts["trace"] is not None),
+               None if self.audio_indicator is None else (id(self.audio_indicator), self.audio_correction is not None))
         cap = self._graphs.get(key)
         if cap is not None and cap.model_options is not model_options:
             del self._graphs[key]        # another dict at a recycled id(): the captured backbone calls used the old one
@@ -1328,14 +1376,34 @@ class LanPaint:
         VE_Sigma, abt, Flow_t = current_times
         replace_sigma = sigma
         per_el = False
+        av = None                 # AV pack on the two-row table (LP_FL_AV): (bits, audio share, the four [2 rows] time arrays)
         if self.audio_indicator is not None and self.current_times_audio is not None:     # lanpaint.py:68-74
             VE_a, abt_a, Flow_a = self.current_times_audio
             ai = self.audio_indicator
-            VE_Sigma = VE_Sigma * (1 - ai) + VE_a * ai
-            abt = abt * (1 - ai) + abt_a * ai
-            replace_sigma = sigma * (1 - ai) + Flow_a * ai
-            current_times = (VE_Sigma, abt, Flow_t)
-        if abt.numel() not in (1, rows) or VE_Sigma.numel() not in (1, rows) or replace_sigma.numel() not in (1, rows):
+            row_sized = all(t.numel() in (1, rows) for t in (VE_Sigma, abt, sigma, Flow_t, VE_a, abt_a, Flow_a))
+            host_side = self._overridden("langevin_dynamics") or self._overridden("score_model") or \
+                self._overridden("prepare_step_size") or (self._es_opts is not None and not self._es_opts["device"])
+            packed = pack_indicator(ai, shape) if (row_sized and not host_side and
+                                                   os.environ.get("LANPAINT_AMD_AV_TABLE", "1") != "0") else None
+            if packed is not None:
+                # a 0/1 indicator and per-row times: the blend picks, per element, one of two per-row time sets exactly
+                # (x * 1 + y * 0 = x), so the kernels take the sets from a two-row table and the indicator as bits -- no
+                # full-size time tensors, no per-element transcendentals (the reference-shaped path below remains for anything else)
+                if ws.av_times is None or ws.av_times.shape[1] != 2 * rows:
+                    ws.av_times = torch.empty((4, 2 * rows), dtype=torch.float32, device=xc.device)
+                    ws.coef_av = torch.empty((2 * rows, _cabi.LP_COEF_STRIDE), dtype=torch.float32, device=xc.device)
+                tv = ws.av_times.view(4, rows, 2)
+                t_mod = Flow_t if flow else VE_Sigma
+                for k, (v, a) in enumerate(((VE_Sigma, VE_a), (abt, abt_a), (sigma, Flow_a), (t_mod, t_mod))):
+                    tv[k, :, 0] = v.reshape(-1)
+                    tv[k, :, 1] = a.reshape(-1)
+                av = (packed[0], packed[1])
+            else:
+                VE_Sigma = VE_Sigma * (1 - ai) + VE_a * ai
+                abt = abt * (1 - ai) + abt_a * ai
+                replace_sigma = sigma * (1 - ai) + Flow_a * ai
+                current_times = (VE_Sigma, abt, Flow_t)
+        if av is None and (abt.numel() not in (1, rows) or VE_Sigma.numel() not in (1, rows) or replace_sigma.numel() not in (1, rows)):
             per_el = True
         st.abt, st.current_times = abt, current_times
         t_src = Flow_t if flow else current_times[0]
@@ -1352,6 +1420,7 @@ class LanPaint:
         d.mask = m_c.data_ptr() if m_c is not None else m.data_ptr()
         d.x0s = None
         d.abt_el = d.ve_el = d.rsig_el = d.corr_el = None
+        d.av_bits, d.av_frac = None, 0.0
         keep = st.keep = [nz]          # tensors that must outlive the enqueued launches of this call
         corr = self.audio_correction
         if per_el:
@@ -1362,6 +1431,16 @@ class LanPaint:
             keep += [abt_el, ve_el, rs_el]
             d.abt_el, d.ve_el, d.rsig_el = abt_el.data_ptr(), ve_el.data_ptr(), rs_el.data_ptr()
             d.coef = None
+        elif av is not None:
+            # two time sets per row: the table (2 rows per batch row) comes from lp_coeffs on the interleaved inputs; the replace
+            # launch does not rebuild it (no LP_PH_COEFFS) and every launch of the call carries the indicator bits
+            st.base_flags = base_flags = base_flags | _cabi.LP_FL_AV
+            tv = ws.av_times
+            _cabi.check(lib.lp_coeffs(ctypes.byref(hyp), tv[0].data_ptr(), 1, tv[1].data_ptr(), 1, tv[2].data_ptr(), 1, None, 0,
+                                      tv[3].data_ptr(), 1, 2 * rows, ws.coef_av.data_ptr(), stream), "lp_coeffs")
+            d.coef, d.coef_out = ws.coef_av.data_ptr(), None
+            d.av_bits, d.av_frac = av[0].data_ptr(), float(av[1])
+            keep.append(av[0])
         else:
             flat = lambda t: _as_f32c(t if t.ndim == 1 else t.reshape(-1))       # noqa: E731
             ve_r, abt_r, rs_r, tm_r = flat(VE_Sigma), flat(abt), flat(replace_sigma), flat(t_model)
@@ -1373,12 +1452,18 @@ class LanPaint:
             d.coef = d.coef_out = ws.coef.data_ptr()
         if corr is not None:
             corr_el = _as_f32c(corr if corr.shape == shape else corr.expand(shape))
+            if ws.static_io:          # a replayed loop bakes the address: the call's correction goes through a workspace buffer
+                if getattr(ws, "corr", None) is None:
+                    ws.corr = torch.empty_like(ws.x_t)
+                ws.corr.copy_(corr_el)
+                corr_el = ws.corr
             keep.append(corr_el)
             d.corr_el = corr_el.data_ptr()
         if ws.static_io and not per_el:
             # replayed loop: the backbone reads its time / sigma from the table the prologue just refreshed
             n_t, n_s = (rows if t_model.numel() > 1 else 1), (rows if sigma.numel() > 1 else 1)
-            st.t_model, st.sigma_model = ws.coef[:n_t, _cabi.LP_C_TMODEL], ws.coef[:n_s, _cabi.LP_C_RSIGMA]
+            table = ws.coef if av is None else ws.coef_av.view(rows, 2 * _cabi.LP_COEF_STRIDE)     # (AV: the video row of each pair)
+            st.t_model, st.sigma_model = table[:n_t, _cabi.LP_C_TMODEL], table[:n_s, _cabi.LP_C_RSIGMA]
         else:
             st.t_model, st.sigma_model = t_model, sigma
 
@@ -1387,7 +1472,7 @@ class LanPaint:
         d.noise_scale = 1.0
         d.known = None
         d.noise = nz.data_ptr()
-        if replace_sigma.numel() == 1:
+        if replace_sigma.numel() == 1 and av is None:
             kind, ns = _noise_scaling_kind(ms)
             if kind == "callback":
                 known = _as_f32c(ms.noise_scaling(self.add_none_dims(replace_sigma), nz, y))
@@ -1428,7 +1513,7 @@ class LanPaint:
             d.rng_state_out = self._rng_state(xc.device).data_ptr()
             d.rng_state_val[0], d.rng_state_val[1] = gen.get_offset(), gen.initial_seed()
         d.flags = base_flags | self._emit(st, n_steps == 0)
-        d.phases = LP_PH_REPLACE | LP_PH_EMIT | (0 if per_el else _cabi.LP_PH_COEFFS)
+        d.phases = LP_PH_REPLACE | LP_PH_EMIT | (0 if (per_el or av is not None) else _cabi.LP_PH_COEFFS)
         st.out = None
         if ws.static_io and not per_el:
             # a replayed call: its lp_finalize may be a node of the graph; this launch tells it where x and out live
@@ -1439,7 +1524,7 @@ class LanPaint:
         st.es = None
         es = self._es_opts
         d.es, d.es_reset = None, 0
-        if es is not None and es["device"] and not per_el and not st.compat and corr is None and n_steps > 0:
+        if es is not None and es["device"] and not per_el and not st.compat and (corr is None or av is not None) and n_steps > 0:
             ds = ds if ds is not None else self._device_stop(xc, n_steps)
             ring = ds.ring_for(latent_mask if latent_mask.shape == shape else m, m)
             # a bit-packed mask is binary: the ring then travels as bits too (the phase-specialised kernels take no other form)
@@ -1454,7 +1539,7 @@ class LanPaint:
             d.es_xte = ds.x_te.data_ptr()
         if not defer_launch:
             self._launch_step(stream)
-        st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el
+        st.replace_kind_static = d.replace_kind != LP_REPLACE_KNOWN and not per_el and av is None
         st.k0_desc = _cabi.LpStepDesc.from_buffer_copy(d) if ws.static_io else None
         d.io_table_out, d.io_valid = None, 0          # the think-loop launches share this descriptor
         d.es_reset = 0

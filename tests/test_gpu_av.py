@@ -1,0 +1,156 @@
+"""AV packs (MiniMax-H3 flat audio / video latents; reference lanpaint.py:60-74, 173-180) on the two-row coefficient table
+(LP_FL_AV, round 4): a 0/1 stream indicator and per-row times mean every element sits on one of two per-row time sets, so
+the kernels read two table rows per batch row and the indicator as bits instead of three full-size blended time tensors
+and per-element exp / expm1.  Checked against the CPU oracle (which blends like the reference), against the reference's own
+golden AV cases (tests/golden/av_flat_*.npz run through this path by the parity suite), and against the reference-shaped
+per-element path of the same engine."""
+import numpy as np
+import pytest
+
+from oracle import lanpaint_oracle as orc
+from tests.helpers import assert_close
+from tests.stubs import MODELS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _case(shape, split, seed, soft=False, rows_differ=False):
+    rng = np.random.default_rng(seed)
+    b = shape[0]
+    y = rng.standard_normal(shape, dtype=np.float32)
+    noise = rng.standard_normal(shape, dtype=np.float32)
+    ai = np.zeros(shape, dtype=np.float32)
+    ai[..., split:] = 1.0                                    # the audio part of the flat pack
+    mask = (rng.random(shape) > 0.45).astype(np.float32)
+    if soft:
+        mask = rng.random(shape, dtype=np.float32)
+    t_v = np.float32([0.55 + (0.1 * r if rows_differ else 0.0) for r in range(b)])
+    t_a = np.float32([0.30 + (0.05 * r if rows_differ else 0.0) for r in range(b)])
+    if b > 1:            # (the reference blends `times * (1 - ai)`: per-row times of a batch have to broadcast against the latent)
+        t_v, t_a = t_v.reshape((b,) + (1,) * (len(shape) - 1)), t_a.reshape((b,) + (1,) * (len(shape) - 1))
+    times_v = orc.times_from_sigma(t_v, True)
+    times_a = orc.times_from_sigma(t_a, True)
+    corr = ((1.0 - ai) + np.float32(0.7) * ai).astype(np.float32)
+    bs = (-1,) + (1,) * (len(shape) - 1)
+    x = (t_v.reshape(bs) * noise + (1 - t_v.reshape(bs)) * y).astype(np.float32)
+    t_v = np.ascontiguousarray(t_v)
+    return dict(x=x, y=y, noise=noise, mask=mask, ai=ai, sigma=t_v, times_v=times_v, times_a=times_a, corr=corr)
+
+
+def _run_oracle(c, n_steps, draws, model_options=None):
+    it = iter(draws)
+    o = orc.OracleLanPaint(MODELS["linear_tuple"](flow=True), n_steps, 15.0, 5.0, 1.0, 0.2, is_flow=True, randn=lambda like: next(it))
+    x = c["x"].copy()
+    out = o(x, c["y"], c["noise"], c["sigma"], c["mask"], c["times_v"], model_options, 0,
+            current_times_audio=c["times_a"], audio_indicator=c["ai"], audio_correction=c["corr"])
+    return x, out, o
+
+
+def _run_engine(c, n_steps, draws, model_options=None, **kw):
+    import torch
+    from lanpaint_amd import LanPaint
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    it = iter([tt(d) for d in draws])
+    eng = LanPaint(MODELS["linear_tuple"](flow=True), n_steps, 15.0, 5.0, 1.0, 0.2, IS_FLOW=True, rng=lambda like: next(it), **kw)
+    x = tt(c["x"])
+    out = eng(x, tt(c["y"]), tt(c["noise"]), tt(c["sigma"]), tt(c["mask"]), tuple(tt(t) for t in c["times_v"]), model_options, 0,
+              current_times_audio=tuple(tt(t) for t in c["times_a"]), audio_indicator=tt(c["ai"]), audio_correction=tt(c["corr"]))
+    torch.cuda.synchronize()
+    return x.cpu().numpy(), out.cpu().numpy(), eng
+
+
+@pytest.mark.parametrize("shape,split,soft,rows_differ", [
+    ((1, 1, 24), 15, False, False),            # the reference test's flat pack
+    ((1, 2, 1000), 333, False, False),          # seam inside a wave, not on a multiple of anything
+    ((3, 4, 777), 500, False, True),            # batch rows on their own time pairs
+    ((2, 1, 4096), 4096 - 64, True, True),      # soft mask values: per-element branch on top of the table rows
+    ((1, 8, 66000), 40001, False, False),       # 528 000 elements: four elements per lane, seam inside a lane's quad
+])
+def test_av_table_path_matches_the_oracle_and_the_per_element_path(shape, split, soft, rows_differ, monkeypatch):
+    n_steps = 3
+    c = _case(shape, split, seed=len(shape) * 100 + split, soft=soft, rows_differ=rows_differ)
+    rng = np.random.default_rng(9)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(2 * n_steps - 1)]
+    x_o, out_o, _ = _run_oracle(c, n_steps, draws)
+    x_t, out_t, eng = _run_engine(c, n_steps, draws)
+    assert eng._desc.flags & (1 << 17), "the engine did not take the two-row table (LP_FL_AV)"
+    assert_close(x_t, x_o, "AV table path: x vs oracle", rel=3e-5)
+    assert_close(out_t, out_o, "AV table path: out vs oracle", rel=3e-5)
+    monkeypatch.setenv("LANPAINT_AMD_AV_TABLE", "0")            # the reference-shaped path: blended full-size times, per element
+    x_p, out_p, eng_p = _run_engine(c, n_steps, draws)
+    assert not (eng_p._desc.flags & (1 << 17)) and eng_p._desc.flags & (1 << 8)
+    assert_close(x_t, x_p, "AV table path vs per-element path: x", rel=3e-5)
+    assert_close(out_t, out_p, "AV table path vs per-element path: out", rel=3e-5)
+
+
+def test_av_pack_with_the_inner_early_stop_on_the_device():
+    """The stop rule of earlystop.py evaluated on the device for an AV pack (round 3 kept the host stopper for per-element
+    times): same iteration count, trace and outputs as the oracle's stopper, whose threshold scales with the mean of the
+    BLENDED abt tensor (earlystop.py:105-113) -- the device forms it from the two rows' abt and the share of audio elements."""
+    shape, split, n_steps = (2, 2, 600), 401, 10
+    c = _case(shape, split, seed=4, rows_differ=True)
+    rng = np.random.default_rng(10)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(2 * n_steps - 1)]
+    ran = {}
+    for thr in (5.0, 1e-9):
+        mo_o = {"lanpaint_semantic_stop": {"threshold": thr, "patience": 2}}
+        mo_e = {"lanpaint_semantic_stop": {"threshold": thr, "patience": 2}, "lanpaint_semantic_trace": []}
+        x_o, out_o, o = _run_oracle(c, n_steps, draws, mo_o)
+        x_e, out_e, eng = _run_engine(c, n_steps, draws, mo_e)
+        assert eng._desc.flags & (1 << 17) and eng._ds is not None          # AV table + device-side stopper buffers in use
+        assert eng.iterations_run == o.iterations_run, (thr, eng.iterations_run, o.iterations_run)
+        ran[thr] = eng.iterations_run
+        assert_close(x_e, x_o, f"thr={thr}: x", rel=3e-5)
+        assert_close(out_e, out_o, f"thr={thr}: out", rel=3e-5)
+        tr = mo_e["lanpaint_semantic_trace"]
+        assert len(tr) == eng.iterations_run and (thr < 1 or tr[-1]["stopped"])
+        st = o.last_stopper
+        if st is not None:
+            assert tr[0]["threshold_eff"] == pytest.approx(st.threshold_eff, rel=1e-5)
+    assert ran[5.0] < n_steps and ran[1e-9] == n_steps
+
+
+def test_indicator_that_is_not_binary_keeps_the_reference_shaped_path():
+    shape = (1, 1, 64)
+    c = _case(shape, 40, seed=1)
+    c["ai"] = (c["ai"] * 0.5).astype(np.float32)              # a soft indicator: blended times really vary per element
+    c["corr"] = ((1.0 - c["ai"]) + np.float32(0.7) * c["ai"]).astype(np.float32)
+    rng = np.random.default_rng(11)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(3)]
+    x_o, out_o, _ = _run_oracle(c, 2, draws)
+    x_e, out_e, eng = _run_engine(c, 2, draws)
+    assert eng._desc.flags & (1 << 8) and not (eng._desc.flags & (1 << 17))
+    assert_close(x_e, x_o, "soft indicator: x", rel=3e-5)
+    assert_close(out_e, out_o, "soft indicator: out", rel=3e-5)
+
+
+def test_av_pack_replays_as_a_graph_bitwise_equal_to_eager_launches():
+    """The table form is what makes an AV call capturable (round 3: eager only): its per-call inputs -- the two time pairs, the
+    correction tensor -- go through workspace buffers the prologue refreshes.  Three sigma calls with different times and
+    corrections, replayed vs eager launches under the same torch seed: bit for bit."""
+    import torch
+    from lanpaint_amd import LanPaint
+    shape, split, n_steps = (1, 4, 3000), 1777, 3
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    c = _case(shape, split, seed=21)
+    ai, y, noise, mask = tt(c["ai"]), tt(c["y"]), tt(c["noise"]), tt(c["mask"])
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(77)
+        eng = LanPaint(MODELS["linear_tuple"](flow=True), n_steps, 15.0, 5.0, 1.0, 0.2, IS_FLOW=True, graph=graph)
+        x, outs = tt(c["x"]), []
+        for k, (tv, ta, cc) in enumerate(((0.8, 0.6, 0.9), (0.5, 0.3, 0.7), (0.2, 0.1, 0.5))):
+            s_v, s_a = np.float32([tv]), np.float32([ta])
+            corr = tt(((1.0 - c["ai"]) + np.float32(cc) * c["ai"]).astype(np.float32))        # a fresh tensor per call, like nodes.py
+            out = eng(x, y, noise, tt(s_v), mask, tuple(tt(t) for t in orc.times_from_sigma(s_v, True)), None, 0,
+                      current_times_audio=tuple(tt(t) for t in orc.times_from_sigma(s_a, True)), audio_indicator=ai,
+                      audio_correction=corr)
+            outs.append(out.clone())
+            x = x + 0.1 * (out - x)
+        torch.cuda.synchronize()
+        res[graph] = (x.clone(), outs, len(eng._graphs))
+    assert res[True][2] >= 1 and res[False][2] == 0
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
