@@ -711,6 +711,8 @@ def tune_from_env(_cabi):
         t |= _cabi.LP_TUNE_ES_NO_DECIDE
     if os.environ.get("LANPAINT_AMD_TUNE_ES_NO_FOLD"):
         t |= _cabi.LP_TUNE_ES_NO_FOLD
+    if os.environ.get("LANPAINT_AMD_TUNE_ES_NO_ATOMICS"):
+        t |= _cabi.LP_TUNE_ES_NO_ATOMICS
     return t
 
 

@@ -337,6 +337,8 @@ typedef struct lp_step_desc {
 #define LP_TUNE_VEC4          (1u << 1)   /* four elements per lane whenever layout and alignment allow                      */
 #define LP_TUNE_ES_NO_DECIDE  (1u << 2)   /* LP_FL_ES: do not enqueue the one-wave decision kernel behind the launch         */
 #define LP_TUNE_ES_NO_FOLD    (1u << 3)   /* LP_FL_ES_GATED: decision kernel after every launch instead of the folded verdict */
+#define LP_TUNE_ES_NO_ATOMICS (1u << 4)   /* LP_FL_ES: the blocks do not add their sums to the accumulator set (WRONG verdicts: a
+                                             measurement switch that prices the atomics)                                    */
 #define LP_CLK_STAMPS 8  /* 0 entry, 1 operand loads issued, 2 noise generated, 3 operands arrived, 4 stop verdict
                             formed, 5 arithmetic done, 6 stores issued, 7 per-block sums written                */
 

@@ -29,7 +29,7 @@ LP_FL_FLOW, LP_FL_MASK_DENOISE, LP_FL_MASK_U8, LP_FL_WRITE_X0S = 1, 2, 4, 8
 LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_XIN_BF16, LP_FL_XIN_F16 = 16, 32, 64, 128
 LP_FL_PER_ELEMENT, LP_FL_X0S_GIVEN, LP_FL_CFG_FUSED, LP_FL_MASK_BITS, LP_FL_NO_REGION_SKIP = 256, 512, 1024, 2048, 4096
 LP_FL_ES, LP_FL_ES_GATED, LP_FL_ES_CLOSE, LP_FL_ES_RING_BITS, LP_FL_AV = 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17
-LP_TUNE_VEC1, LP_TUNE_VEC4, LP_TUNE_ES_NO_DECIDE, LP_TUNE_ES_NO_FOLD = 1, 2, 4, 8
+LP_TUNE_VEC1, LP_TUNE_VEC4, LP_TUNE_ES_NO_DECIDE, LP_TUNE_ES_NO_FOLD, LP_TUNE_ES_NO_ATOMICS = 1, 2, 4, 8, 16
 
 
 def mask_bits_bytes(n_el: int) -> int:

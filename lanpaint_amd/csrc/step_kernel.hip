@@ -354,7 +354,10 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES): 1 = per-block sums for the decision kernel
 // that follows, 2 = the launch first applies the verdict of the iteration before itself (gated loops, small grids).
 template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, int ES = 0>
-__global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const void* a2, const void* a3, const void* a4,
+// (the folded early-stop kernels at 16 B per lane hold ~106 SGPRs -- state, two coefficient regions, verdict -- and gfx950 grants a
+// wave at most 96 when eight share a SIMD: asking for 8 waves per EU makes the compiler keep the overflow in lanes of a spare
+// VGPR instead; at 7 waves the video latent's 2048 blocks, 8 per CU, need a second round)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 && VEC == 4 && PH != 0) ? 8 : 1))) void lp_step_kernel(void* a0, void* a1, const void* a2, const void* a3, const void* a4,
                                                        const void* a5, int32_t a_el_per_row, uint32_t a_flags,
                                                        const lp_step_desc d_arg) {
     constexpr bool PER_EL = MODE == MODE_PER_EL;
@@ -680,6 +683,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 es_prev = es_lite.cur_slot; es_anchor = es_lite.anchor_slot; es_write = es_lite.write_slot;
                 es_idle = es_lite.stopped != 0;      // stopped: only re-emit x_in from the committed x_t (stores below)
         };
+        if constexpr (ES == 2 && VEC == 4) form_verdict();
         // ---- issue every load of this launch before any arithmetic ---------------------
         float m[VEC], xt[VEC], yv[VEC], cv[VEC], x0[VEC], x0b[VEC], xi_a[VEC], xi_b[VEC], corr[VEC];
         float xv[VEC], kn[VEC], nv[VEC], rs[VEC], abt_e[VEC], ve_e[VEC];
@@ -825,7 +829,6 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             }
         }
 
-        if constexpr (ES == 2 && VEC == 4) form_verdict();      // operand loads in flight; history loads behind the noise (below)
         // per-call I/O pointers for the launches of this sigma call that live in a captured graph (lp_finalize)
         if (d.io_table_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
             d.io_table_out[0] = d.io_table_val[0];
@@ -897,7 +900,6 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
             // bits of a 4-D latent -- now that the verdict (formed behind the operand loads, above) says which they are
             if (post) {
                 if (es_prev >= 0) load_f32<VEC>(es_prev == 0 ? d.es_x0s[0] : es_prev == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0p);
-                if (es_anchor >= 0) load_f32<VEC>(es_anchor == 0 ? d.es_x0s[0] : es_anchor == 1 ? d.es_x0s[1] : d.es_x0s[2], i, anc);
                 load_ring();
             }
         }
@@ -1097,6 +1099,13 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
                 if (live) {
                     store_f32<VEC>(es_write == 0 ? d.es_x0s[0] : es_write == 1 ? d.es_x0s[1] : d.es_x0s[2], i, x0s);
                     // weighted squared differences (earlystop.py:52-55): w1 = 1 - mask, w2 = ring
+                    if constexpr (ES == 2 && VEC == 4) {
+                        // streaming sizes: the drift anchor (held only while the distance sits under the threshold) is fetched
+                        // HERE, after the arithmetic, not with the operands: four registers less at the kernel's peak -- the ones
+                        // that decide between 7 and 8 waves per SIMD; its latency is exposed only in iterations that hold an anchor
+                        if (es_anchor >= 0 && !(UNI && uni == 1))
+                            load_f32<VEC>(es_anchor == 0 ? d.es_x0s[0] : es_anchor == 1 ? d.es_x0s[1] : d.es_x0s[2], i, anc);
+                    }
                     if (UNI && uni == 1) {
                         // every element of the wave is known: w1 = 1 - m = 0 and the ring (inpaint pixels next to known ones)
                         // has none of them -- the wave adds exact zeros to all six sums, i.e. nothing
@@ -1212,7 +1221,7 @@ __global__ __launch_bounds__(256) void lp_step_kernel(void* a0, void* a1, const 
         }
         __syncthreads();
         const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
-        if (threadIdx.x < kEsSums) {
+        if (threadIdx.x < kEsSums && !(d.tune & LP_TUNE_ES_NO_ATOMICS)) {
             const float p0 = es_part[0][threadIdx.x], p1 = es_part[1][threadIdx.x], p2 = es_part[2][threadIdx.x],
                         p3 = es_part[3][threadIdx.x];
             const float v = ((p0 + p1) + p2) + p3;                  // the block's sum, fp32, fixed order
