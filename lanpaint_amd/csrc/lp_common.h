@@ -182,7 +182,8 @@ __device__ __forceinline__ uint32_t pack_half2(int dt, float lo, float hi) {
 // Loads of a slot past the end are redirected to the last element (no branch around a load, the value is never
 // stored); only the stores are predicated.
 struct Strided {
-    int64_t e[4];      // element index per slot, clamped to n - 1
+    uint32_t e[4];     // element index per slot (lp_step takes this layout for tensors below 2^31 elements only: four
+                       // registers of indices instead of eight -- the strided kernels sat at 78 VGPRs, 6 waves per SIMD)
     bool ok[4];        // slot inside the tensor
     // slots base + i + k s that fall into [lo, hi) (one batch row's part of one round of ATen's grid-stride loop)
     __device__ __forceinline__ Strided(int64_t i, int64_t s, int64_t base, int64_t lo, int64_t hi) {
@@ -190,12 +191,12 @@ struct Strided {
         for (int k = 0; k < 4; ++k) {
             const int64_t t = base + i + k * s;
             ok[k] = t >= lo && t < hi;
-            e[k] = ok[k] ? t : lo;
+            e[k] = static_cast<uint32_t>(ok[k] ? t : lo);
         }
     }
 };
 __device__ __forceinline__ int64_t elem_index(int64_t i, int k) { return i + k; }
-__device__ __forceinline__ int64_t elem_index(const Strided& x, int k) { return x.e[k]; }
+__device__ __forceinline__ int64_t elem_index(const Strided& x, int k) { return static_cast<int64_t>(x.e[k]); }
 __device__ __forceinline__ bool elem_ok(const Strided& x, int k) { return x.ok[k]; }
 
 template <int V>

@@ -758,8 +758,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 for (int k = 0; k < VEC; ++k) {
                     const bool bit = ((m_raw.w[k] >> (static_cast<uint32_t>(elem_index(i, k)) & 31u)) & 1u) != 0u;
                     const bool ok = elem_ok(i, k);
-                    if (__ballot(ok && !bit) == 0ull) i_x0.e[k] = st_lo;
-                    if (__ballot(ok && bit) == 0ull) i_kn.e[k] = st_lo;
+                    if (__ballot(ok && !bit) == 0ull) i_x0.e[k] = static_cast<uint32_t>(st_lo);
+                    if (__ballot(ok && bit) == 0ull) i_kn.e[k] = static_cast<uint32_t>(st_lo);
                 }
             }
         }
@@ -1431,6 +1431,7 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     // ATen's element-to-thread layout pays off when a Philox block really serves several elements of this tensor
     // (batch rows: as long as a row covers at least half a round most lanes still use two or more values of their block)
     const bool strided = VEC == 4 && rng_torch && !d.xi_post && !d.xi_pre && d.n_el > static_cast<int64_t>(d.rng_bg) &&
+                         d.n_el <= 0x7fffffffll &&
                          (d.rows == 1 || d.el_per_row >= 2 * static_cast<int64_t>(d.rng_bg)) && st_segments(d) != 0;
 #define LP_HOT(MODE_, PH_)                                                                                   \
     (strided ? (x0_half ? launch<4, MODE_, PH_, 2, 1, true>(d, stream, timer) : launch<4, MODE_, PH_, 4, 1, true>(d, stream, timer)) \
