@@ -934,8 +934,10 @@ def extra_lines(args, dev):
             "detail": res,
             "note": f"{args.workload}: LanPaint(Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX, IS_FLOW) -- no optional "
                     "keyword: graph='auto' (captured from the job's second sigma call on, after a check against eager launches), "
-                    "rng='torch' (the reference's noise stream, in-kernel), the reference's fp32 mask; packed_mask: the same "
-                    "engine with the mask bit-packed once per job (lanpaint_amd.pack_mask, what KSamplerX0Inpaint does)"}
+                    "rng='torch' (the reference's noise stream, in-kernel), the reference's fp32 mask -- which the engine, seeing the "
+                    "same binary mask tensor on the job's second sigma call, bit-packs by itself (round 4: auto_pack_mask; one host "
+                    "read per mask tensor); packed_mask: the same engine with the mask packed by the caller before the first call "
+                    "(lanpaint_amd.pack_mask, what KSamplerX0Inpaint does)"}
     except Exception as e:
         out["engine_defaults"] = {"error": repr(e)}
     # ---- the headline workload with the inner early stop armed but never firing (threshold far below any distance):

@@ -439,6 +439,8 @@ class LanPaint:
         self._hyper = _cabi.LpHyper()
         self._noise_check = None                 # (weakref(noise), version, verdict)
         self.assume_static_noise = False         # see _noise_is_zero
+        self.auto_pack_mask = os.environ.get("LANPAINT_AMD_AUTO_PACK", "1") != "0"      # see _auto_pack
+        self._mask_seen = None
         self._noise_regenerated = False
         self._iterations_run = 0                 # think iterations executed (it/s accounting)
         self.last_inner_steps = 0
@@ -457,6 +459,34 @@ class LanPaint:
     @iterations_run.setter
     def iterations_run(self, v):
         self._iterations_run = v
+
+    def _auto_pack(self, latent_mask, x):
+        """A caller that hands the engine a plain fp32 mask (the reference's interface) still gets the hard-mask kernels when
+        the mask IS binary: the second consecutive call with the same mask tensor packs it (one launch + ONE host read of
+        the "values other than 0 and 1" flag per mask tensor; a mask that turns out soft is remembered as such).  The first
+        call never packs -- a caller that builds a fresh mask tensor per call would pay the host read every time."""
+        # (not under graph=True: that engine captures on the FIRST call, with the mask as it came; packing on the second would
+        # only make a second capture -- a caller who forces graphs packs the mask himself)
+        if not self.auto_pack_mask or self.graph is True or not latent_mask.is_cuda or latent_mask.dtype != torch.float32 \
+                or not latent_mask.is_contiguous() or latent_mask.shape != x.shape or latent_mask.numel() == 0 \
+                or getattr(latent_mask, "_lp_u8", None) is not None:
+            return
+        ver = (tensor_version(latent_mask), latent_mask.data_ptr())
+        if ver[0] == -1:                 # no version counter (inference mode): a later in-place edit to soft values could not be seen
+            return
+        seen = self._mask_seen
+        if seen is None or seen[0]() is not latent_mask or seen[1] != ver:
+            self._mask_seen = (weakref.ref(latent_mask), ver, False)
+            return
+        if seen[2]:                      # known to be soft
+            return
+        try:
+            pack_mask(latent_mask, check=True)
+            latent_mask._lp_auto = True
+        except ValueError:
+            self._mask_seen = (seen[0], seen[1], True)
+        except Exception:
+            self.auto_pack_mask = False
 
     def rng_position(self, device):
         """Where the engine's own noise streams stand (checkers reproduce the draws of the next sigma call from this):
@@ -750,7 +780,15 @@ class LanPaint:
         # (KSamplerX0Inpaint's, from ComfyUI's denoise_mask) are kept current by whoever derived them
         rec = getattr(latent_mask, "_lp_bits_of", None)
         if rec is not None and not rec[2] and rec[0]() is latent_mask:
-            refresh_packed_mask(latent_mask)
+            if getattr(latent_mask, "_lp_auto", False) and tensor_version(latent_mask) != rec[1]:
+                # a mask the ENGINE packed (nobody vouched for it being binary) was rewritten: forget the copy and look again
+                for a in ("_lp_bits", "_lp_bits_of", "_lp_auto"):
+                    delattr(latent_mask, a)
+                self._auto_pack(latent_mask, x)
+            else:
+                refresh_packed_mask(latent_mask)
+        elif rec is None:
+            self._auto_pack(latent_mask, x)
         self._es_opts = self._es_options(model_options)
         if self._es_pending is not None and (self._es_opts is None or self._es_opts["trace"] is not None
                                              or self._es_pending[0] is not self._ds):

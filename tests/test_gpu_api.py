@@ -863,3 +863,47 @@ def test_noise_verdict_is_rechecked_for_tensors_without_a_version_counter():
     assert eng2._noise_is_zero(t) is False
     t.zero_()                                              # version counter moves: noticed without any flag
     assert eng2._noise_is_zero(t) is True
+
+
+def test_engine_packs_a_binary_fp32_mask_by_itself_on_second_sight():
+    """The reference's interface hands the engine a plain fp32 mask.  When the same mask tensor comes back on the next call
+    and it is binary, the engine packs it (one host read per mask tensor) and the hard-mask kernels run from then on --
+    bitwise the same results; a soft mask is left alone; a packed mask that is rewritten to soft values is unpacked again."""
+    import torch
+    from lanpaint_amd import LanPaint
+    case = gc.build_case("ve_sdxl_shape")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    args = (tt(case["y"]), tt(case["noise"]), tt(case["sigma"]))
+    times = tuple(tt(t) for t in case["times"])
+    res = {}
+    for auto in (False, True):
+        eng = LanPaint(MODELS["linear_tuple"](), 3, 15.0, 5.0, 1.0, 0.2, rng="philox", philox_seed=5, graph=False)
+        eng.auto_pack_mask = auto
+        mask, x, outs = tt(case["mask"]), tt(case["x"]), []
+        for k in range(3):
+            outs.append(eng(x, *args, mask, times, None, 0).clone())
+            assert (getattr(mask, "_lp_bits", None) is not None) == (auto and k >= 1)
+        res[auto] = (x.clone(), outs)
+    assert torch.equal(res[True][0], res[False][0]) and all(torch.equal(a, b) for a, b in zip(res[True][1], res[False][1]))
+    # a soft mask is never packed
+    eng = LanPaint(MODELS["linear_tuple"](), 2, 15.0, 5.0, 1.0, 0.2, rng="philox", philox_seed=5, graph=False)
+    soft, x = tt(np.random.default_rng(3).random(case["mask"].shape, dtype=np.float32)), tt(case["x"])
+    for _ in range(3):
+        eng(x, *args, soft, times, None, 0)
+    assert getattr(soft, "_lp_bits", None) is None and eng._mask_seen[2] is True
+    # a mask the engine packed, then rewritten in place to soft values: the copy is dropped, results follow the soft mask
+    eng = LanPaint(MODELS["linear_tuple"](), 2, 15.0, 5.0, 1.0, 0.2, rng="philox", philox_seed=5, graph=False)
+    mask, x = tt(case["mask"]), tt(case["x"])
+    eng(x, *args, mask, times, None, 0)
+    eng(x, *args, mask, times, None, 0)
+    assert getattr(mask, "_lp_bits", None) is not None
+    mask.copy_(soft)
+    x1 = tt(case["x"])
+    out1 = eng(x1, *args, mask, times, None, 0)
+    assert getattr(mask, "_lp_bits", None) is None
+    ref = LanPaint(MODELS["linear_tuple"](), 2, 15.0, 5.0, 1.0, 0.2, rng="philox", philox_seed=5, graph=False)
+    ref.auto_pack_mask = False
+    ref._philox_offset = eng._philox_offset - 2          # same launch sequence numbers as the call above
+    x2 = tt(case["x"])
+    out2 = ref(x2, *args, soft.clone(), times, None, 0)
+    assert torch.equal(out1, out2) and torch.equal(x1, x2)
