@@ -191,6 +191,31 @@ def _lerp_np(start, end, w):
     return (start + w * d).astype(np.float32) if w < 0.5 else (end - d * (np.float32(1) - w)).astype(np.float32)
 
 
+def _bf16_round(a):
+    """numpy fp32 -> nearest-even bf16, returned as fp32 (what the kernels' v_cvt_pk_bf16_f32 and torch's .to(bfloat16) do)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    return u.view(np.float32)
+
+
+class Bf16StubOracle:
+    """What StubBackbone computes when the engine hands it bf16 latents (model_dtype=torch.bfloat16), restated in numpy for the
+    oracle side of parity_check: the input rounded to bf16 (the kernel emits x_in as bf16; the final call's x is cast), the
+    two products formed in fp32 and rounded to bf16 -- with the scales as the stub holds them (a bf16 tensor on the one-launch
+    path of latency-bound latents, Python scalars above)."""
+
+    def __init__(self, flow, n_el):
+        self.inner_model = self
+        self.model_sampling = StubSampling(flow)
+        small = n_el <= 512 * 1024
+        self.s0, self.s1 = ((_bf16_round(np.float32([0.9]))[0], _bf16_round(np.float32([0.8]))[0]) if small
+                            else (np.float32(0.9), np.float32(0.8)))
+
+    def __call__(self, x, t, model_options=None, seed=None):
+        xb = _bf16_round(x)
+        return _bf16_round(xb * self.s0), _bf16_round(xb * self.s1)
+
+
 def parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow, max_sigmas=None):
     """ONE schedule pass of the engine that is about to be timed -- same object, same launch mode (graph replay / eager),
     same noise generator, same mask format -- in lockstep with the CPU oracle (oracle/lanpaint_oracle.py, the checker) fed
@@ -217,7 +242,8 @@ def parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_thi
 
     seed = int(engine.philox_seed if engine.philox_seed is not None else 0) & 0xFFFFFFFFFFFFFFFF
     draws = []
-    model = StubBackbone(flow)
+    model = StubBackbone(flow) if engine.model_dtype is None else Bf16StubOracle(flow, n_el)
+    assert engine.model_dtype in (None, torch.bfloat16), "parity_check restates the stub for fp32 and bf16 backbones"
     oracle = OracleLanPaint(model, n_think, HYPER["Friction"], float(engine.chara_lamb), float(engine.chara_beta),
                             float(engine.step_size), is_flow=flow, min_step_frac=float(engine.min_step_frac),
                             randn=lambda like: draws.pop(0))
@@ -342,7 +368,8 @@ def run_gpu(args):
 
     engine = LanPaint(StubBackbone(flow), HYPER["NSteps"], HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"],
                       HYPER["StepSize"], IS_FLOW=flow, MinStepFrac=HYPER["MinStepFrac"], rng=args.rng,
-                      philox_seed=lpd.replica_seed(args.seed, rank), graph=bool(args.graph))
+                      philox_seed=lpd.replica_seed(args.seed, rank), graph=bool(args.graph),
+                      model_dtype=torch.bfloat16 if args.model_dtype == "bf16" else None)
 
     def barrier():
         if world > 1:
@@ -460,11 +487,12 @@ def run_gpu(args):
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * tmax / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",      # the path's arithmetic and state (with --model-dtype bf16 only the backbone's
+                                                  # input / outputs are bf16 storage: config.backbone_io)
         "config": {"workload": f"{args.workload}: latent {'x'.join(map(str, shape))} per GPU, {n_sig} sigmas x "
                                f"{n_think} think iterations, {mask_desc}, stub backbone x->(0.9x,0.8x), "
                                f"{'flow' if flow else 'VE/Karras'} schedule",
-                   "rng": args.rng, "mask_format": args.mask_format, "launch": "hipGraph replay per sigma call" if args.graph else "eager launches",
+                   "rng": args.rng, "mask_format": args.mask_format, "backbone_io": args.model_dtype, "launch": "hipGraph replay per sigma call" if args.graph else "eager launches",
                    "replicas": args.gpus, "rows_per_gpu": b, "global_rows": b * args.gpus, "iterations_per_step": n_sig * n_think,
                    "latent_elements_per_gpu": n_el, "lambda": HYPER["Lambda"], "beta": HYPER["Beta"],
                    "step_size": HYPER["StepSize"]},
@@ -826,7 +854,12 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=100, every_s
                 "hbm_side_GBps": out["counter_side_GBps"],
                 "mean_launch_us": event_us, "median_launch_us": float(np.median(durs)) * 1e6,
                 "min_launch_us": float(durs.min()) * 1e6, "launches_timed": int(durs.size), "warm_burst_s": warm_s,
-                "warm_burst_launches": warmed, "committed_profile": committed_profile(prof_key)})
+                "warm_burst_launches": warmed, "committed_profile": committed_profile(prof_key),
+                "limiter_note": ("streaming sizes: the launch is co-limited by VALU issue, not by HBM alone -- SQ counters of this "
+                                 "kernel (profiles/r04_sq_*.md before, r04_after_sq_*.md after round 4's reductions): 538 -> 366 VALU "
+                                 "instructions per wave with fp32 heads (631 -> 417 with bf16 heads), SQ_INSTS_VMEM 7.4 per wave; "
+                                 "x 4 cycles x waves / 1024 SIMDs = 275 k of a 330 k-cycle launch before, 187 k after")
+                if n_el > 512 * 1024 else None})
     return out
 
 
@@ -967,6 +1000,36 @@ def extra_lines(args, dev):
                     "evaluated on the device inside every replayed launch, no host read in the loop"}
     except Exception as e:
         out["inner_early_stop_armed"] = {"error": repr(e)}
+    # ---- the headline workload behind a bf16 backbone (BASELINE configs[1] says bf16: that is the backbone's dtype): the kernels emit
+    # x_in and read both heads as bf16; checked against the oracle with the stub restated in bf16 before it is timed
+    if args.model_dtype == "f32":
+        try:
+            shape, flow, n_sig, n_think = WORKLOADS[args.workload]
+            sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
+            x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed, dev, tt)
+            mask = attach_mask_format(mask, args.mask_format)
+            sig_list = [torch.full((shape[0],), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+            times_list = [times_from_sigma(s, flow) for s in sig_list]
+            ratios = euler_ratios(sig_list, len(shape))
+            eng = LanPaint(StubBackbone(flow), n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
+                           IS_FLOW=flow, rng=args.rng, philox_seed=args.seed, graph=bool(args.graph), model_dtype=torch.bfloat16)
+            par = parity_check(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow,
+                               max_sigmas=None if int(np.prod(shape)) <= 512 * 1024 else 2)
+            for _ in range(5):
+                schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+            torch.cuda.synchronize()
+            it0, t0, reps = eng.iterations_run, time.perf_counter(), max(5, args.steps // 2)
+            for _ in range(reps):
+                schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["bf16_backbone"] = {
+                "value": (eng.iterations_run - it0) / dt if par["ok"] else None, "unit": "think-iterations/s",
+                "ms_per_step": 1e3 * dt / reps, "parity_check": {k: par[k] for k in ("mse_x", "mse_denoised_max", "ok", "sigmas_checked", "launch_modes")},
+                "note": f"{args.workload} as in the headline with model_dtype=torch.bfloat16: x_in emitted and both heads read as bf16 "
+                        "(state, arithmetic and the written-back x stay fp32); the oracle side of the check restates the stub in bf16"}
+        except Exception as e:
+            out["bf16_backbone"] = {"error": repr(e)}
     # ---- a half-precision backbone: both heads arrive as bf16 and x_in leaves as bf16 (30 B / element instead of 36);
     # the production storage widths -- BASELINE configs[1] says bf16 -- at the two bandwidth-bound shapes
     try:
@@ -1282,6 +1345,9 @@ def main():
                          "lanpaint_amd.pack_mask (what KSamplerX0Inpaint does), one byte, or the reference's fp32")
     ap.add_argument("--mask", default=None, choices=["box", "temporal", "blob"],
                     help="synthetic mask; default: 50 %% box for image latents, second half of the video inpainted for video latents")
+    ap.add_argument("--model-dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage of the latent handed to the backbone and of its two outputs (bf16: the kernels emit / read half "
+                         "width, 30 instead of 36 B per element and iteration; state and arithmetic stay fp32)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="budget of the cpu_baseline leg (split between the 1-thread and the all-threads setting)")

@@ -123,3 +123,17 @@ def test_bench_line_carries_the_parity_check():
     pc = line["parity_check"]
     assert pc["ok"] and pc["sigmas_checked"] == 30 and pc["launch_modes"] == {"graph": 30}
     assert pc["mse_x"] < 1e-9 and pc["mse_denoised_max"] < 1e-9 and line["value"] > 0
+
+
+@pytest.mark.parametrize("workload,max_sigmas", [("c2_sdxl", None), ("c5_wan", 2)])
+def test_bf16_backbone_configuration_against_the_oracle(workload, max_sigmas):
+    """BASELINE configs[1] says "bf16": the backbone's dtype.  The engine with model_dtype=torch.bfloat16 (x_in emitted as bf16,
+    both heads read as bf16 -- at the video latent through the 16-byte lane-pair accesses) against the oracle whose stub is
+    restated in bf16 (bench.Bf16StubOracle): a rounding that flips on an fp32 last-bit difference moves an element by one
+    bf16 ulp, so the bound is the BASELINE tolerance, with the measured value far below."""
+    import torch
+    job = _job(workload, "bits")
+    eng = _engine(job, rng="philox", philox_seed=6, graph=True, model_dtype=torch.bfloat16)
+    r = _check(job, eng, max_sigmas=max_sigmas)
+    assert r["ok"] and r["mse_x"] < 1e-5 and r["mse_denoised_max"] < 1e-5, r      # (measured 2e-8 / 2e-6: a few one-ulp bf16 flips
+    assert set(r["launch_modes"]) == {"graph"}                                       # at |x| ~ 15, the first sigma of the schedule)
