@@ -865,12 +865,13 @@ def test_noise_verdict_is_rechecked_for_tensors_without_a_version_counter():
     assert eng2._noise_is_zero(t) is True
 
 
-def test_engine_packs_a_binary_fp32_mask_by_itself_on_second_sight():
+def test_engine_packs_a_binary_fp32_mask_by_itself_on_second_sight(monkeypatch):
     """The reference's interface hands the engine a plain fp32 mask.  When the same mask tensor comes back on the next call
     and it is binary, the engine packs it (one host read per mask tensor) and the hard-mask kernels run from then on --
     bitwise the same results; a soft mask is left alone; a packed mask that is rewritten to soft values is unpacked again."""
     import torch
     from lanpaint_amd import LanPaint
+    monkeypatch.delenv("LANPAINT_AMD_AUTO_PACK", raising=False)
     case = gc.build_case("ve_sdxl_shape")
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
     args = (tt(case["y"]), tt(case["noise"]), tt(case["sigma"]))

@@ -59,7 +59,7 @@ def test_the_published_configuration_against_the_oracle():
     assert len(eng._graphs) == 1 and eng.iterations_run == 150
 
 
-def test_the_engine_built_with_no_optional_keyword_against_the_oracle():
+def test_the_engine_built_with_no_optional_keyword_against_the_oracle(monkeypatch):
     """`engine_defaults`: LanPaint(Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX, IS_FLOW) -- graph="auto",
     rng="torch" (the reference's own randn stream, generated in-kernel), the reference's fp32 mask -- against the oracle on
     what torch.randn itself returns from the same generator state; the generator must end every call where the reference's
@@ -67,6 +67,8 @@ def test_the_engine_built_with_no_optional_keyword_against_the_oracle():
     import torch
     import bench
     from lanpaint_amd import LanPaint
+    for var in ("LANPAINT_AMD_GRAPH", "LANPAINT_AMD_RNG", "LANPAINT_AMD_AUTO_PACK"):      # (this test is about the defaults)
+        monkeypatch.delenv(var, raising=False)
     job = _job("c2_sdxl", "f32")
     h = bench.HYPER
     eng = LanPaint(bench.StubBackbone(False), job["n_think"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], False, False)
