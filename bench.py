@@ -1066,7 +1066,7 @@ def extra_lines(args, dev):
                 x = torch.lerp(den, x, ratios[i])
         return x
 
-    for _ in range(2):
+    for _ in range(8):          # (captures for every inner-step count of the ramp, then a few steady passes: the first ones read 10-15 % low)
         node_pass()
     torch.cuda.synchronize()
     it0, t0, reps = k.PaintMethod.iterations_run, time.perf_counter(), max(20, args.steps // 8)   # (5 passes = 6 ms read +-10 %)
