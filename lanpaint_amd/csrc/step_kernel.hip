@@ -495,6 +495,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
     const float lam = d.lambda, opl = d.one_plus_lambda;
 
     RowCoef rc;
+    bool av_mixed = false;          // LP_FL_AV: the wave straddles the video / audio seam of its row
+    uint32_t av_nib = 0u;           // LP_FL_AV: this lane's indicator bits (VEC of them)
     const bool fold_coeffs = (ph & LP_PH_COEFFS) != 0;       // compile-time for PH != 0
     if (fold_coeffs) {
         // lp_coeffs folded into the replace launch: every block derives the two row scalars its own work needs
@@ -544,8 +546,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             }
         }
         if constexpr (!PER_EL) {
-            if constexpr (SMALL && PH != 0) rc = load_row_early(d.coef, row);
-            else rc = load_row(d.coef, row);
+            if constexpr (SMALL && PH != 0) {
+                rc = load_row_early(d.coef, row);
+            } else {
+                // AV packs (LP_FL_AV, see below): which of the batch row's two table rows this wave runs on is decided HERE, so that
+                // `rc` has ONE load site (a RowCoef assigned on several paths and merged ends up in scratch memory)
+                int crow = row;
+                if constexpr (PH == 0 && MODE == MODE_ROW && !ST) {
+                    if (fl & LP_FL_AV) {
+                        const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+                        const bool in_row = g0 < groups;
+                        const int64_t i0 = row_base + (in_row ? g0 : groups - 1) * VEC;
+                        const uint32_t word = static_cast<const uint32_t*>(d.av_bits)[i0 >> 5];
+                        av_nib = (word >> (static_cast<uint32_t>(i0) & 31u)) & ((1u << VEC) - 1u);
+                        const bool any_audio = __ballot(in_row && av_nib != 0u) != 0ull;
+                        const bool any_video = __ballot(in_row && av_nib != ((1u << VEC) - 1u)) != 0ull;
+                        av_mixed = any_audio && any_video;
+                        crow = 2 * row + ((any_audio && !any_video) ? 1 : 0);
+                    }
+                }
+                rc = load_row(d.coef, crow);
+            }
         }
     }
 
@@ -586,41 +607,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         // path.  The straddling wave uses the reference's per-element formulas on the two rows' fp32 fields (elem_from_row).
         // Run-time-phase row-table kernels only; the phase-specialised kernels never see the flag (lp_step routes it).
         constexpr bool AVK = PH == 0 && MODE == MODE_ROW && !ST;
-        bool av_mixed = false;
-        uint32_t av_nib = 0u;                      // this lane's indicator bits (VEC of them)
-        RowCoef rc_b = rc;                         // the audio row where the wave needs both
-        if constexpr (AVK) {
-            if (fl & LP_FL_AV) {
-                const uint32_t word = static_cast<const uint32_t*>(d.av_bits)[i >> 5];
-                av_nib = (word >> (static_cast<uint32_t>(i) & 31u)) & ((1u << VEC) - 1u);
-                const bool any_audio = __ballot(active && av_nib != 0u) != 0ull;
-                const bool any_video = __ballot(active && av_nib != ((1u << VEC) - 1u)) != 0ull;
-                if (!any_audio) {
-                    rc = load_row(d.coef, 2 * row);
-                } else if (!any_video) {
-                    rc = load_row(d.coef, 2 * row + 1);
-                } else {
-                    av_mixed = true;
-                    rc = load_row(d.coef, 2 * row);
-                    rc_b = load_row(d.coef, 2 * row + 1);
+        // What an element of a STRADDLING wave takes from its own row: read per lane from the table (one wave per batch row does
+        // this; a second RowCoef held next to `rc` and selected per lane would put both structs into scratch memory).
+        auto av_row = [&](int k) __attribute__((always_inline)) -> const float* {
+            return d.coef + static_cast<int64_t>(2 * row + static_cast<int>((av_nib >> k) & 1u)) * LP_COEF_STRIDE;
+        };
+        auto row_scale_of = [&](int k) __attribute__((always_inline)) -> float {
+            if constexpr (AVK) {
+                if (av_mixed) return av_row(k)[LP_C_SCALE];
+            }
+            return rc.scale;
+        };
+        auto row_rsigma_of = [&](int k) __attribute__((always_inline)) -> float {
+            if constexpr (AVK) {
+                if (av_mixed) return av_row(k)[LP_C_RSIGMA];
+            }
+            return rc.rsigma;
+        };
+        auto elem_of = [&](int k, float mk) __attribute__((always_inline)) -> ElemCoef {
+            // elem_from_row on the element's row; a straddling wave reads the row's fp32 fields per lane from the table (scalars
+            // merged field by field -- two ElemCoef structs built on two paths and merged would again live in scratch memory)
+            float ax = rc.ax, ay = rc.ay, dx = rc.dx, dy = rc.dy, dtx = rc.dtx, dty = rc.dty, sq = rc.sqrt_abt, oma = rc.oma,
+                  sc = rc.scale, valid = rc.valid;
+            if constexpr (AVK) {
+                if (av_mixed) {
+                    const float* c = av_row(k);
+                    ax = c[LP_C_AX]; ay = c[LP_C_AY]; dx = c[LP_C_DX]; dy = c[LP_C_DY]; dtx = c[LP_C_DTX]; dty = c[LP_C_DTY];
+                    sq = c[LP_C_SQRT_ABT]; oma = c[LP_C_OMA]; sc = c[LP_C_SCALE]; valid = c[LP_C_VALID];
                 }
             }
-        }
-        // the row an element of a straddling wave belongs to (fields selected per lane), the launch's row otherwise
-        auto row_of = [&](int k) -> RowCoef {
-            if constexpr (AVK) {
-                if (av_mixed && ((av_nib >> k) & 1u)) return rc_b;
-            }
-            return rc;
+            const float om = 1.0f - mk;
+            ElemCoef e;
+            e.a = ax * om + ay * mk;
+            e.d = dx * om + dy * mk;
+            e.dt = dtx * om + dty * mk;
+            e.sqrt_abt = sq;
+            e.oma = oma;
+            e.scale = sc;
+            e.valid = valid != 0.0f;
+            return e;
         };
 
+        // (every lambda of this body is always_inline: one that stays a call takes the arrays it captures -- xt, cv, x0s -- by address,
+        // which sends them to scratch memory; that happened to the first-iteration kernels and cost 24-42 %, found by the
+        // same-box A/B against the round-3 library, scripts/r04_ab_more.sh)
         // The verdict of iteration i - 1, formed inside launch i (folded loops): state -> totals of the accumulator slots ->
         // stop rule.  Latency-bound sizes (VEC = 1) call it BEHIND the operand loads and the Philox rounds (one memory round
         // trip instead of three); streaming sizes (VEC = 4) call it FIRST, before any operand load is issued: its twenty-odd
         // registers then never overlap the operands', the launch stays at 8 waves per SIMD, and the history loads know which
         // buffers they need (round 3: verdict behind the loads, 98 VGPRs, 4 waves per SIMD -- the video latent's 2048 blocks ran
         // in two rounds, 17.9 us against 9.5 for the plain launch).
-        auto form_verdict = [&]() {
+        auto form_verdict = [&]() __attribute__((always_inline)) {
                 const int it = d.es_index;
                 {
                     const auto u = [&](int w) { return __builtin_amdgcn_readfirstlane(static_cast<int>((w & 1) ? es_words[w >> 1].y : es_words[w >> 1].x)); };
@@ -633,6 +670,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                     es_lite.threshold_eff = __longlong_as_double(static_cast<long long>(u64(12)));
                     es_lite.abt_val = __longlong_as_double(static_cast<long long>(u64(14)));
                 }
+                int v_stopped = 0, v_cur = -1, v_anchor = -1, v_write = 0;
+                bool v_have = false;
                 if (it > 0 && es_lite.stopped == 0) {        // (block-uniform: every wave takes the barrier)
                     // The block's FIRST wave totals the accumulator slots and applies the rule; the other three only take the
                     // outcome -- stop flag and the three buffer roles -- from LDS.  (Round 3 had every wave redo the rule from
@@ -654,10 +693,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                         }
                     }
                     __syncthreads();
-                    if (threadIdx.x >= kWave) {
-                        es_lite.stopped = fold_out[0]; es_lite.cur_slot = fold_out[1];
-                        es_lite.anchor_slot = fold_out[2]; es_lite.write_slot = fold_out[3];
-                    }
+                    // (every wave, the first included, takes the outcome from LDS into plain scalars: writing it back into `es_lite`
+                    // on one path only would merge the struct across paths and send it to scratch memory)
+                    v_stopped = fold_out[0]; v_cur = fold_out[1]; v_anchor = fold_out[2]; v_write = fold_out[3];
+                    v_have = true;
                 }
                 if ((fl & LP_FL_ES_CLOSE) && it + 1 == d.es_n_steps) {
                     // last launch of the loop and no closing decision kernel (LP_FL_ES_CLOSE): unless the loop has
@@ -680,8 +719,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 } else if (es_keeper) {
                     es_store_dynamic(d.es + (it & 1), es_lite);
                 }
-                es_prev = es_lite.cur_slot; es_anchor = es_lite.anchor_slot; es_write = es_lite.write_slot;
-                es_idle = es_lite.stopped != 0;      // stopped: only re-emit x_in from the committed x_t (stores below)
+                es_prev = v_have ? v_cur : es_lite.cur_slot; es_anchor = v_have ? v_anchor : es_lite.anchor_slot;
+                es_write = v_have ? v_write : es_lite.write_slot;
+                es_idle = (v_have ? v_stopped : es_lite.stopped) != 0;      // stopped: only re-emit x_in from the committed x_t
         };
         if constexpr (ES == 2 && VEC == 4) form_verdict();
         // ---- issue every load of this launch before any arithmetic ---------------------
@@ -792,7 +832,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         constexpr bool RING_BITS_ONLY = ES != 0 && HARD && PH != 0;
         const bool ring_bits = RING_BITS_ONLY || (fl & LP_FL_ES_RING_BITS) != 0;
         uint32_t rg_raw = 0u;
-        auto load_ring = [&]() {
+        auto load_ring = [&]() __attribute__((always_inline)) {
             if (!d.es_ring) return;
             if (ring_bits) {
                 if constexpr (!ST) rg_raw = reinterpret_cast<const uint32_t*>(d.es_ring)[i >> 5];
@@ -800,7 +840,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 if constexpr (!RING_BITS_ONLY) load_f32<VEC>(d.es_ring, i, rg);
             }
         };
-        auto ring_weight = [&](int k) -> float {
+        auto ring_weight = [&](int k) __attribute__((always_inline)) -> float {
             if (!d.es_ring) return 0.0f;
             if (ring_bits) {
                 if constexpr (!ST) return static_cast<float>((rg_raw >> ((static_cast<uint32_t>(i) & 31u) + k)) & 1u);
@@ -881,7 +921,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             } else {
                 // every element index below 2^32 (any real latent): the Philox key does not depend on the element and its ten
                 // round keys are scalar -- one v_add less per round and element (lp_common.h, normal_pair_key)
-                const bool key_uniform = d.n_el <= 0xffffffffll;
+                // (streaming kernels only: at one element per lane the launch is latency-bound and the per-element key of round 3
+                // is the shorter chain -- same-box A/B against the round-3 library, scripts/r04_ab_c2.sh)
+                const bool key_uniform = !SMALL && d.n_el <= 0xffffffffll;
                 const uint32_t key0 = philox_key(seed, seq, 0);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -945,7 +987,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             if (d.replace_kind != LP_REPLACE_KNOWN) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const float r = PER_EL ? rs[k] : (av_mixed ? row_of(k).rsigma : rc.rsigma);
+                    const float r = PER_EL ? rs[k] : row_rsigma_of(k);
                     kn[k] = (d.replace_kind == LP_REPLACE_VE) ? fmaf(nv[k], r, yv[k])
                                                               : (r * (d.noise_scale * nv[k]) + (1.0f - r) * yv[k]);
                 }
@@ -957,7 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 if constexpr (PER_EL) {
                     sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
                 } else {
-                    sc = av_mixed ? row_of(k).scale : rc.scale;
+                    sc = row_scale_of(k);
                 }
                 xt[k] = flow ? xr * sc : xr / sc;
             }
@@ -965,15 +1007,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
 
         // OU(x, dt/2, C) of lanpaint.py:280 for element k (table path or the reference's own formulas)
         // (table form with the region's coefficients given: `q` is an SGPR set in a mask-uniform wave)
-        auto half_table = [&](float x, float c, float xi, const RegionCoef& q) -> float {
+        auto half_table = [&](float x, float c, float xi, const RegionCoef& q) __attribute__((always_inline)) -> float {
             return rc.valid != 0.0f ? fmaf(q.e_half, x, fmaf(q.k_half, c, q.std_half * xi)) : x;
         };
-        auto half_step = [&](float x, float c, float xi, int k) -> float {
+        auto half_step = [&](float x, float c, float xi, int k) __attribute__((always_inline)) -> float {
             const float mk = m[k];
             const bool table = HARD || (!PER_EL && !av_mixed && ((mk == 0.0f) || (mk == 1.0f)));
             if (table) {
-                // (a branch, not a select between the two coefficient sets: each side then takes its set straight from SGPRs;
-                // a v_cndmask needs one of the two in VGPRs, ten registers pinned for the whole kernel)
+                // streaming kernels: a branch, not a select between the two coefficient sets -- each side then takes its set
+                // straight from SGPRs (a v_cndmask needs one of the two in VGPRs, ten registers pinned for the whole kernel).
+                // One-element-per-lane kernels hold the row in VGPRs anyway (load_row_early) and are latency-bound: there the
+                // select is the shorter dependent chain (same-box A/B at C2: 2.09 us with selects, 2.18 with branches)
+                if constexpr (SMALL) return half_table(x, c, xi, rc.reg[mk == 1.0f ? 1 : 0]);
                 if (mk == 1.0f) return half_table(x, c, xi, rc.reg[1]);
                 return half_table(x, c, xi, rc.reg[0]);
             }
@@ -982,7 +1027,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 if constexpr (PER_EL) {
                     e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size, d.min_step_frac);
                 } else {
-                    e = elem_from_row(row_of(k), mk);
+                    e = elem_of(k, mk);
                 }
                 if (e.valid) return ou_general(x, e.dt / 2.0f, e.a, c, e.d, xi);
             }
@@ -1014,17 +1059,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) yv[k] = 0.0f;
             }
-            if (ph & LP_PH_POST_FIRST) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) cv[k] = 0.0f;
-            }
+            // (iteration 0 has no previous C: a row whose step is not positive stores C = 0, below -- assigned where the element is
+            // handled, not pre-zeroed here: an array defined on two paths and merged kept the compiler from promoting it to
+            // registers in the first-iteration kernels, which then went through scratch memory)
             if constexpr (!HARD) {
                 if (has_corr) {       // lanpaint.py:173-180: both heads pulled towards the model-space input, before the split
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         float sc;
                         if constexpr (PER_EL) sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
-                        else sc = av_mixed ? row_of(k).scale : rc.scale;
+                        else sc = row_scale_of(k);
                         const float xm = flow ? xt[k] / sc : xt[k] * sc;
                         x0[k] = xm + corr[k] * (x0[k] - xm);
                         x0b[k] = xm + corr[k] * (x0b[k] - xm);
@@ -1032,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 }
             }
             // table path of element k: two regions per row, no transcendental per element (`q`: the region's coefficients)
-            auto post_table = [&](int k, const RegionCoef& q, bool known_el) {
+            auto post_table = [&](int k, const RegionCoef& q, bool known_el) __attribute__((always_inline)) {
                 if (rc.valid != 0.0f) {
                     const float s0 = (given || !known_el) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
                     const float cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
@@ -1046,6 +1090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                     cv[k] = cn;
                 } else {
                     x0s[k] = x0[k];
+                    if (ph & LP_PH_POST_FIRST) cv[k] = 0.0f;
                 }
             };
             if (UNI && uni >= 0) {               // mask-uniform wave: the region's coefficient set stays in SGPRs
@@ -1056,21 +1101,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) post_table(k, rc.reg[1], true);
                 }
-            } else
+            } else {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float mk = m[k];
                 const bool table = HARD || (!PER_EL && !av_mixed && ((mk == 0.0f) || (mk == 1.0f)));
                 if (table) {
-                    if (mk == 1.0f) post_table(k, rc.reg[1], true);
-                    else post_table(k, rc.reg[0], false);
+                    if constexpr (SMALL) {
+                        post_table(k, rc.reg[mk == 1.0f ? 1 : 0], mk == 1.0f);
+                    } else {
+                        if (mk == 1.0f) post_table(k, rc.reg[1], true);
+                        else post_table(k, rc.reg[0], false);
+                    }
                 } else if constexpr (!HARD) {
                     ElemCoef e;
                     if constexpr (PER_EL) {
                         e = elem_from_times(abt_e[k], flow ? 0.0f : ve_e[k], mk, flow, opl, d.beta, d.step_size,
                                             d.min_step_frac);
                     } else {
-                        e = elem_from_row(row_of(k), mk);
+                        e = elem_of(k, mk);
                     }
                     const float h0 = x0[k], h1 = x0b[k];          // (the audio correction went into the heads above)
                     if (e.valid) {
@@ -1091,8 +1140,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                         cv[k] = cn;
                     } else {
                         x0s[k] = h0;
+                        if (ph & LP_PH_POST_FIRST) cv[k] = 0.0f;
                     }
                 }
+            }
             }
             if ((fl & LP_FL_WRITE_X0S) && live) store_f32<VEC>(d.x0s, i, x0s);
             if constexpr (ES) {
@@ -1123,22 +1174,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                                 es_p[4] += db * db;
                             }
                         }
-                    } else
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const float w1 = 1.0f - m[k];
-                        const float w2 = ring_weight(k);
-                        const float da = es_prev >= 0 ? x0s[k] - x0p[k] : xt[k] - xb[k];
-                        const float da2 = da * da;
-                        es_p[0] += da2 * w1;
-                        es_p[1] += w1;
-                        es_p[2] += da2 * w2;
-                        es_p[3] += w2;
-                        if (es_anchor >= 0) {
-                            const float db = x0s[k] - anc[k];
-                            const float db2 = db * db;
-                            es_p[4] += db2 * w1;
-                            es_p[5] += db2 * w2;
+                        for (int k = 0; k < VEC; ++k) {
+                            const float w1 = 1.0f - m[k];
+                            const float w2 = ring_weight(k);
+                            const float da = es_prev >= 0 ? x0s[k] - x0p[k] : xt[k] - xb[k];
+                            const float da2 = da * da;
+                            es_p[0] += da2 * w1;
+                            es_p[1] += w1;
+                            es_p[2] += da2 * w2;
+                            es_p[3] += w2;
+                            if (es_anchor >= 0) {
+                                const float db = x0s[k] - anc[k];
+                                const float db2 = db * db;
+                                es_p[4] += db2 * w1;
+                                es_p[5] += db2 * w2;
+                            }
                         }
                     }
                 }
@@ -1188,7 +1240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 if constexpr (PER_EL) {
                     sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
                 } else {
-                    sc = av_mixed ? row_of(k).scale : rc.scale;
+                    sc = row_scale_of(k);
                 }
                 xo[k] = flow ? xe[k] / sc : xe[k] * sc;
             }
