@@ -609,18 +609,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         constexpr bool AVK = PH == 0 && MODE == MODE_ROW && !ST;
         // What an element of a STRADDLING wave takes from its own row: read per lane from the table (one wave per batch row does
         // this; a second RowCoef held next to `rc` and selected per lane would put both structs into scratch memory).
+        // The table words are read as relaxed wavefront-scope ATOMIC loads -- plain global_load instructions -- because a plain C++
+        // load here gives the optimiser `x = mixed ? table[f] : rc.f`, which it rewrites into ONE load through a pointer chosen
+        // between the table and &rc.f: `rc` then has its address taken and the whole row lives in scratch memory (132 B, found in the
+        // ISA of the three run-time row kernels; atomic loads are never merged that way).
         auto av_row = [&](int k) __attribute__((always_inline)) -> const float* {
             return d.coef + static_cast<int64_t>(2 * row + static_cast<int>((av_nib >> k) & 1u)) * LP_COEF_STRIDE;
         };
+        auto av_ld = [&](const float* c, int f) __attribute__((always_inline)) -> float {
+            return __hip_atomic_load(c + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        };
         auto row_scale_of = [&](int k) __attribute__((always_inline)) -> float {
             if constexpr (AVK) {
-                if (av_mixed) return av_row(k)[LP_C_SCALE];
+                if (av_mixed) return av_ld(av_row(k), LP_C_SCALE);
             }
             return rc.scale;
         };
         auto row_rsigma_of = [&](int k) __attribute__((always_inline)) -> float {
             if constexpr (AVK) {
-                if (av_mixed) return av_row(k)[LP_C_RSIGMA];
+                if (av_mixed) return av_ld(av_row(k), LP_C_RSIGMA);
             }
             return rc.rsigma;
         };
@@ -632,8 +639,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             if constexpr (AVK) {
                 if (av_mixed) {
                     const float* c = av_row(k);
-                    ax = c[LP_C_AX]; ay = c[LP_C_AY]; dx = c[LP_C_DX]; dy = c[LP_C_DY]; dtx = c[LP_C_DTX]; dty = c[LP_C_DTY];
-                    sq = c[LP_C_SQRT_ABT]; oma = c[LP_C_OMA]; sc = c[LP_C_SCALE]; valid = c[LP_C_VALID];
+                    ax = av_ld(c, LP_C_AX); ay = av_ld(c, LP_C_AY); dx = av_ld(c, LP_C_DX); dy = av_ld(c, LP_C_DY);
+                    dtx = av_ld(c, LP_C_DTX); dty = av_ld(c, LP_C_DTY); sq = av_ld(c, LP_C_SQRT_ABT); oma = av_ld(c, LP_C_OMA);
+                    sc = av_ld(c, LP_C_SCALE); valid = av_ld(c, LP_C_VALID);
                 }
             }
             const float om = 1.0f - mk;
