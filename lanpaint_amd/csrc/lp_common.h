@@ -182,8 +182,9 @@ __device__ __forceinline__ uint32_t pack_half2(int dt, float lo, float hi) {
 // Loads of a slot past the end are redirected to the last element (no branch around a load, the value is never
 // stored); only the stores are predicated.
 struct Strided {
-    uint32_t e[4];     // element index per slot (lp_step takes this layout for tensors below 2^31 elements only: four
-                       // registers of indices instead of eight -- the strided kernels sat at 78 VGPRs, 6 waves per SIMD)
+    uint32_t e[4];     // element index per slot (lp_step takes this layout for tensors below 2^30 elements only: four
+                       // registers of indices instead of eight -- the strided kernels sat at 78 VGPRs, 6 waves per SIMD --
+                       // and BYTE offsets that fit 32 bits, see at_bytes)
     bool ok[4];        // slot inside the tensor
     // slots base + i + k s that fall into [lo, hi) (one batch row's part of one round of ATen's grid-stride loop)
     __device__ __forceinline__ Strided(int64_t i, int64_t s, int64_t base, int64_t lo, int64_t hi) {
@@ -195,6 +196,33 @@ struct Strided {
         }
     }
 };
+// Element e of a tensor at p, addressed as "pointer + 32-bit BYTE offset": p is a kernel argument (SGPR pair), so the access
+// is `global_load v, v_off, s[base]` -- one offset register per slot shared by every tensor of the launch.  Written as p[e]
+// with a 32-bit e the compiler must assume that 4 e overflows 32 bits and builds a 64-bit address PAIR per tensor and slot
+// (3-4 VALU instructions and two VGPRs each, kept alive until the stores: the last-iteration strided kernels sat at 70 VGPRs).
+template <typename T>
+__device__ __forceinline__ const T* at_bytes(const void* p, uint32_t e) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(p) + static_cast<uint32_t>(e * static_cast<uint32_t>(sizeof(T))));
+}
+template <typename T>
+__device__ __forceinline__ T* at_bytes(void* p, uint32_t e) {
+    return reinterpret_cast<T*>(static_cast<char*>(p) + static_cast<uint32_t>(e * static_cast<uint32_t>(sizeof(T))));
+}
+// The same for an access inside a predicated block (the stores of slots that may lie outside the tensor): the offset passes
+// through an empty asm, which keeps the address arithmetic IN that block -- instruction selection works block by block, and an
+// address computed once next to the loads reaches the store's block as a finished 64-bit value in a VGPR pair.
+template <typename T>
+__device__ __forceinline__ const T* at_bytes_here(const void* p, uint32_t e) {
+    uint32_t off = e * static_cast<uint32_t>(sizeof(T));
+    asm volatile("" : "+v"(off));
+    return reinterpret_cast<const T*>(static_cast<const char*>(p) + off);
+}
+template <typename T>
+__device__ __forceinline__ T* at_bytes_here(void* p, uint32_t e) {
+    uint32_t off = e * static_cast<uint32_t>(sizeof(T));
+    asm volatile("" : "+v"(off));
+    return reinterpret_cast<T*>(static_cast<char*>(p) + off);
+}
 __device__ __forceinline__ int64_t elem_index(int64_t i, int k) { return i + k; }
 __device__ __forceinline__ int64_t elem_index(const Strided& x, int k) { return static_cast<int64_t>(x.e[k]); }
 __device__ __forceinline__ bool elem_ok(const Strided& x, int k) { return x.ok[k]; }
@@ -202,13 +230,13 @@ __device__ __forceinline__ bool elem_ok(const Strided& x, int k) { return x.ok[k
 template <int V>
 __device__ __forceinline__ void load_f32(const float* __restrict__ p, const Strided& x, float (&o)[V]) {
 #pragma unroll
-    for (int k = 0; k < V; ++k) o[k] = __builtin_nontemporal_load(p + elem_index(x, k));
+    for (int k = 0; k < V; ++k) o[k] = __builtin_nontemporal_load(at_bytes_here<float>(p, x.e[k]));
 }
 template <int V>
 __device__ __forceinline__ void store_f32(float* __restrict__ p, const Strided& x, const float (&v)[V]) {
 #pragma unroll
     for (int k = 0; k < V; ++k)
-        if (elem_ok(x, k)) __builtin_nontemporal_store(v[k], p + elem_index(x, k));
+        if (elem_ok(x, k)) __builtin_nontemporal_store(v[k], at_bytes_here<float>(p, x.e[k]));
 }
 
 template <int V>
@@ -233,7 +261,7 @@ __device__ __forceinline__ void store_f32(float* __restrict__ p, int64_t i, cons
         __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p + i));
     } else {
 #pragma unroll
-        for (int k = 0; k < V; ++k) p[i + k] = v[k];
+        for (int k = 0; k < V; ++k) p[i + k] = v[k];      // (non-temporal here: no effect at the latency-bound sizes, profiles/r04_ab_nt1.log)
     }
 }
 
@@ -270,9 +298,8 @@ template <int V>
 __device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, const Strided& x, Raw<V>& r) {
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        const int64_t e = elem_index(x, k);
-        r.w[k] = (dt == DT_F32) ? __float_as_uint(static_cast<const float*>(p)[e])
-                                : static_cast<uint32_t>(static_cast<const uint16_t*>(p)[e]);
+        r.w[k] = (dt == DT_F32) ? __float_as_uint(*at_bytes_here<float>(p, x.e[k]))
+                                : static_cast<uint32_t>(*at_bytes_here<uint16_t>(p, x.e[k]));
     }
 }
 
@@ -328,9 +355,8 @@ __device__ __forceinline__ void store_any(void* __restrict__ p, int dt, const St
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         if (!elem_ok(x, k)) continue;
-        const int64_t e = elem_index(x, k);
-        if (dt == DT_F32) static_cast<float*>(p)[e] = v[k];
-        else static_cast<uint16_t*>(p)[e] = (dt == DT_BF16) ? f32_to_bf16(v[k]) : f32_to_f16(v[k]);
+        if (dt == DT_F32) *at_bytes_here<float>(p, x.e[k]) = v[k];
+        else *at_bytes_here<uint16_t>(p, x.e[k]) = (dt == DT_BF16) ? f32_to_bf16(v[k]) : f32_to_f16(v[k]);
     }
 }
 
@@ -423,10 +449,9 @@ template <int V>
 __device__ __forceinline__ void load_mask_raw(const void* __restrict__ p, uint32_t flags, const Strided& x, Raw<V>& r) {
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        const int64_t e = elem_index(x, k);
-        r.w[k] = (flags & LP_FL_MASK_BITS) ? static_cast<const uint32_t*>(p)[e >> 5]
-                 : (flags & LP_FL_MASK_U8) ? static_cast<uint32_t>(static_cast<const uint8_t*>(p)[e])
-                                           : __float_as_uint(static_cast<const float*>(p)[e]);
+        r.w[k] = (flags & LP_FL_MASK_BITS) ? *at_bytes<uint32_t>(p, x.e[k] >> 5)
+                 : (flags & LP_FL_MASK_U8) ? static_cast<uint32_t>(*at_bytes<uint8_t>(p, x.e[k]))
+                                           : __float_as_uint(*at_bytes<float>(p, x.e[k]));
     }
 }
 

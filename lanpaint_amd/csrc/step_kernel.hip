@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
     // folded decision: what its prologue loads (state fields, the first wave's slot of the previous iteration's accumulator set)
     lp_es_state es_lite;
     uint2 es_words[8];
-    double es_fv[kEsSums] = {0., 0., 0., 0., 0., 0.};
+    double es_fv[kEsSums];           // (written and read by the block's first wave only)
     if constexpr (ES) {
         es_gated = (fl & LP_FL_ES_GATED) != 0;
         if constexpr (es_fold) {
@@ -691,6 +691,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                             const double* src = es_acc_set(d, d.es_index - 1) + static_cast<size_t>(threadIdx.x) * 8;
 #pragma unroll
                             for (int k = 0; k < kEsSums; ++k) es_fv[k] = src[k];
+                        }
+                        if constexpr (VEC != 4) {
+                            // (the slot was fetched at the top of the kernel; the empty asm pins its first USE here, behind the operand
+                            // loads and the Philox rounds.  Without it the optimiser folds the double -> float conversion of
+                            // es_slot_total into the block that loads the slot, and the first wave of every block waits a whole memory
+                            // round trip for its accumulator slot before it issues a single operand load: 0.5 us per launch)
+#pragma unroll
+                            for (int k = 0; k < kEsSums; ++k) asm volatile("" : "+v"(es_fv[k]));
                         }
                         es_slot_total(es_fv, tot);
                         const bool hp = es_lite.cur_slot >= 0, ha = es_lite.anchor_slot >= 0;
@@ -1491,7 +1499,7 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     // ATen's element-to-thread layout pays off when a Philox block really serves several elements of this tensor
     // (batch rows: as long as a row covers at least half a round most lanes still use two or more values of their block)
     const bool strided = VEC == 4 && rng_torch && !d.xi_post && !d.xi_pre && d.n_el > static_cast<int64_t>(d.rng_bg) &&
-                         d.n_el <= 0x7fffffffll &&
+                         d.n_el < (1ll << 30) &&               /* 32-bit byte offsets, lp_common.h at_bytes */
                          (d.rows == 1 || d.el_per_row >= 2 * static_cast<int64_t>(d.rng_bg)) && st_segments(d) != 0;
 #define LP_HOT(MODE_, PH_)                                                                                   \
     (strided ? (x0_half ? launch<4, MODE_, PH_, 2, 1, true>(d, stream, timer) : launch<4, MODE_, PH_, 4, 1, true>(d, stream, timer)) \

@@ -105,6 +105,33 @@ def device_kernels(lib=LIB):
     return names
 
 
+def kernel_resources(lib=LIB):
+    """{mangled kernel name: its AMDGPU metadata record} from the NT_AMDGPU_METADATA notes (msgpack) of the gfx950 code objects:
+    `.vgpr_count`, `.sgpr_count`, `.private_segment_fixed_size` (scratch bytes per lane), `.vgpr_spill_count`, ... -- what
+    `hipcc -S` prints as `; ScratchSize` etc., read from the library that ships."""
+    import struct
+    import msgpack
+    out = {}
+    for image in _code_objects(lib):
+        off, size = _elf_sections(image)[".note"][:2]
+        p = off
+        while p < off + size:
+            namesz, descsz, ty = struct.unpack_from("<III", image, p)
+            p += 12 + ((namesz + 3) & ~3)
+            desc = image[p:p + descsz]
+            p += (descsz + 3) & ~3
+            if ty == 32:                                          # NT_AMDGPU_METADATA
+                for k in msgpack.unpackb(desc, raw=False).get("amdhsa.kernels", []):
+                    out[k[".name"]] = {a: b for a, b in k.items() if a != ".args"}
+    return out
+
+
+def step_kernel_args(name):
+    """(VEC, MODE, PH, X0W, RNG, ST, ES) of a mangled lp_step_kernel name, or None."""
+    m = _MANGLED.match(name)
+    return tuple(int(g) for g in m.groups()) if m else None
+
+
 def device_instantiations(lib=LIB):
     """Template argument lists of every lp_step_kernel<...> the DEVICE code of `lib` contains, in the spelling of
     product_instantiations()."""
