@@ -20,11 +20,22 @@ constexpr int kWave = 64;   // CDNA wavefront width; hard-coded per the gfx950 p
 // Box-Muller pair whose cosine branch feeds the POST half-step and whose sine branch feeds
 // the PRE half-step of the same launch.  No state is carried and the mapping is per
 // element, so the stream is independent of grid shape, vector width and block size.
+// WIDE: the round's 64-bit product as ONE v_mad_u64_u32 instead of v_mul_hi_u32 + v_mul_lo_u32 -- ten multiply instructions
+// less per element of the VALU-bound streaming kernels (round 4).  The instruction also writes a carry into an SGPR pair, so
+// the one-element-per-lane kernels (latency-bound, and at their SGPR limit in the run-time-phase forms) keep the two-multiply
+// form; the values are the same either way.
+template <bool WIDE = false>
 __device__ __forceinline__ void philox2x32_10(uint32_t& c0, uint32_t& c1, uint32_t key) {
     constexpr uint32_t M = 0xD256D193u, W = 0x9E3779B9u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi = __umulhi(M, c0), lo = M * c0;
+        uint32_t hi, lo;
+        if constexpr (WIDE) {
+            const uint64_t p = static_cast<uint64_t>(M) * c0;
+            hi = static_cast<uint32_t>(p >> 32); lo = static_cast<uint32_t>(p);
+        } else {
+            hi = __umulhi(M, c0); lo = M * c0;
+        }
         c0 = hi ^ key ^ c1;
         c1 = lo;
         key += W;
@@ -45,8 +56,9 @@ __device__ __forceinline__ float u01(uint32_t x) {
 // v_cos_f32 take their argument in revolutions, which is exactly 2*pi*u.
 // (normal_pair_key: the same pair with the block's key given -- for element indices < 2^32 the key is philox_key(seed, seq, 0),
 // wave-uniform, and the compiler keeps the round keys in SGPRs)
+template <bool WIDE>
 __device__ __forceinline__ void normal_pair_key(uint32_t c0, uint32_t c1, uint32_t key, float& z_post, float& z_pre) {
-    philox2x32_10(c0, c1, key);
+    philox2x32_10<WIDE>(c0, c1, key);
     const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c0)));
     const float t = u01(c1);
     z_post = r * __builtin_amdgcn_cosf(t);
@@ -87,14 +99,22 @@ __device__ __forceinline__ float2 box_muller_u32(uint32_t x, uint32_t y) {
     return r;
 }
 
+template <bool WIDE = false>          // (WIDE: see philox2x32_10)
 __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t subseq, uint64_t seed) {
     uint32_t c0 = static_cast<uint32_t>(ctr), c1 = static_cast<uint32_t>(ctr >> 32);
     uint32_t c2 = static_cast<uint32_t>(subseq), c3 = static_cast<uint32_t>(subseq >> 32);
     uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t hi0, lo0, hi1, lo1;
+        if constexpr (WIDE) {
+            const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0, p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+            hi0 = static_cast<uint32_t>(p0 >> 32); lo0 = static_cast<uint32_t>(p0);
+            hi1 = static_cast<uint32_t>(p1 >> 32); lo1 = static_cast<uint32_t>(p1);
+        } else {
+            hi0 = __umulhi(0xD2511F53u, c0); lo0 = 0xD2511F53u * c0;
+            hi1 = __umulhi(0xCD9E8D57u, c2); lo1 = 0xCD9E8D57u * c2;
+        }
         c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -130,7 +150,7 @@ __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64
 // idx + 3 bg of the tensor (the `Strided` lane layout).
 __device__ __forceinline__ void torch_normal4(uint32_t idx, uint64_t seed, uint64_t offset, float (&o)[4]) {
 #pragma clang fp contract(on)
-    const uint4 c = philox4x32_10(offset >> 2, idx, seed);
+    const uint4 c = philox4x32_10<true>(offset >> 2, idx, seed);
     const float2 a = box_muller_u32(c.x, c.y), b = box_muller_u32(c.z, c.w);
     o[0] = a.x * 1.0f + 0.0f; o[1] = a.y * 1.0f + 0.0f; o[2] = b.x * 1.0f + 0.0f; o[3] = b.y * 1.0f + 0.0f;
 }

@@ -945,7 +945,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 for (int k = 0; k < VEC; ++k) {
                     float za, zb;
                     const uint64_t e = static_cast<uint64_t>(elem_index(i, k));
-                    if (key_uniform) normal_pair_key(static_cast<uint32_t>(e), static_cast<uint32_t>(seq), key0, za, zb);
+                    // (one v_mad_u64_u32 per Philox round in the phase-specialised kernels; the run-time-phase ones sit at the SGPR
+                    // limit and the instruction's carry pair tips them into a private segment)
+                    if (key_uniform) normal_pair_key<PH != 0>(static_cast<uint32_t>(e), static_cast<uint32_t>(seq), key0, za, zb);
                     else normal_pair(e, seq, seed, za, zb);
                     if (!host_post) xi_a[k] = za;
                     if (!host_pre) xi_b[k] = zb;
