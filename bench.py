@@ -25,6 +25,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -522,7 +523,10 @@ def run_gpu(args):
 
 def _latest_profile_json(pattern):
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    def order(path):            # rNN_ (a round's final pass) after rNNa_, rNNb_ (its earlier passes, kept for the box-to-box spread)
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (-1, False, "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=order)
     if not files:
         return None, None
     try:
