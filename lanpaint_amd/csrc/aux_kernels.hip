@@ -235,30 +235,42 @@ int ring_dispatch(const float* mask, float* ring, int64_t planes, int height, in
 // K4b: { sum(w1 d^2), sum(w1), sum(w2 d^2), sum(w2) }, d = a-b, w1 = 1-mask, w2 = ring.
 // fp32 per-thread partials, double from the wave reduction upward, fixed order.
 // ---------------------------------------------------------------------------------
+// V = 4: sixteen bytes per lane and stream (rows of 4 k elements, 16-byte aligned tensors -- every latent); V = 1: the rest.
+// Host-stopper configurations (custom distance_fn, a batch sharded over ranks) run this once per think iteration.
+template <int V>
 __global__ __launch_bounds__(256) void lp_wmse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               const float* __restrict__ mask,
                                                               const float* __restrict__ ring, int64_t n_el,
                                                               double* __restrict__ scratch) {
     __shared__ double part[4][4];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_el;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const float dv = a[i] - b[i];
-        const float d2 = dv * dv;
-        const float w1 = 1.0f - mask[i];
-        s[0] += d2 * w1;
-        s[1] += w1;
-        if (ring) {
-            const float w2 = ring[i];
-            s[2] += d2 * w2;
-            s[3] += w2;
+    const int64_t groups = n_el / V;
+    for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < groups;
+         g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float av[V], bv[V], mv[V], rv[V];
+        load_f32<V>(a, g * V, av);
+        load_f32<V>(b, g * V, bv);
+        load_f32<V>(mask, g * V, mv);
+        if (ring) load_f32<V>(ring, g * V, rv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float dv = av[k] - bv[k];
+            const float d2 = dv * dv;
+            const float w1 = 1.0f - mv[k];
+            s[0] += d2 * w1;
+            s[1] += w1;
+            if (ring) {
+                s[2] += d2 * rv[k];
+                s[3] += rv[k];
+            }
         }
     }
+    double v[4] = {static_cast<double>(s[0]), static_cast<double>(s[1]), static_cast<double>(s[2]), static_cast<double>(s[3])};
+    wave_sum_dpp(v);                                            // fixed order; the wave's sums in its last lane
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == kWave - 1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double v = wave_sum(static_cast<double>(s[k]));
-        if (lane == 0) part[wave][k] = v;
+        for (int k = 0; k < 4; ++k) part[wave][k] = v[k];
     }
     __syncthreads();
     if (threadIdx.x < 4) {
@@ -267,24 +279,37 @@ __global__ __launch_bounds__(256) void lp_wmse_partial_kernel(const float* __res
     }
 }
 
-__global__ void lp_wmse_final_kernel(const double* __restrict__ scratch, int blocks, double* __restrict__ acc) {
-    const int k = threadIdx.x;
-    if (k >= 4) return;
-    double v = 0.0;
-    for (int bidx = 0; bidx < blocks; ++bidx) v += scratch[static_cast<int64_t>(bidx) * 4 + k];
-    acc[k] = v;
+// One wave: lane l adds the block sums l, l + 64, ... in that order, then the fixed DPP tree over the lanes (round 3 had four
+// threads walk up to 1 024 block sums one after the other).
+__global__ __launch_bounds__(64) void lp_wmse_final_kernel(const double* __restrict__ scratch, int blocks, double* __restrict__ acc) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int bidx = threadIdx.x; bidx < blocks; bidx += kWave) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += scratch[static_cast<int64_t>(bidx) * 4 + k];
+    }
+    wave_sum_dpp(v);
+    if (threadIdx.x == kWave - 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = v[k];
+    }
 }
 
 int wmse_dispatch(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el, double* acc,
                   double* scratch, int scratch_blocks, hipStream_t stream) {
     if (!a || !b || !mask || !acc || !scratch || n_el <= 0 || scratch_blocks <= 0) return LP_E_INVALID;
-    int64_t bx = (n_el + 255) / 256;
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec4 = n_el % 4 == 0 && al16(a) && al16(b) && al16(mask) && (!ring || al16(ring));
+    int64_t bx = (n_el / (vec4 ? 4 : 1) + 255) / 256;
     if (bx > scratch_blocks) bx = scratch_blocks;
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(lp_wmse_partial_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, a, b, mask, ring,
-                       n_el, scratch);
+    if (vec4)
+        hipLaunchKernelGGL(lp_wmse_partial_kernel<4>, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, a, b, mask, ring, n_el,
+                           scratch);
+    else
+        hipLaunchKernelGGL(lp_wmse_partial_kernel<1>, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, a, b, mask, ring, n_el,
+                           scratch);
     if (hipGetLastError() != hipSuccess) return LP_E_LAUNCH;
-    hipLaunchKernelGGL(lp_wmse_final_kernel, dim3(1), dim3(64), 0, stream, scratch, static_cast<int>(bx), acc);
+    hipLaunchKernelGGL(lp_wmse_final_kernel, dim3(1), dim3(kWave), 0, stream, scratch, static_cast<int>(bx), acc);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 
