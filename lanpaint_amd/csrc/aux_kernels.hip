@@ -102,16 +102,36 @@ __global__ __launch_bounds__(256) void lp_finalize_kernel(const void* a_mask, co
     // word 2 of the table: 0 voids this launch (a sigma call queued for a speculated inner-step count that turned out
     // wrong, lp_node_call): nothing of the caller's is written and the replayed generator counter does not move
     if (d.io_table && d.io_table[2] == 0ull) return;
-    if (g < groups) {
-        const int64_t i = g * VEC;
+    // Region-aware streams at streaming sizes (bit-packed mask, 16 B per lane; same rule as lp_step_kernel): a wave whose 256 mask
+    // bits are all 0 (inpaint) never reads y, one whose bits are all 1 (known) never reads the model output -- 20.1 -> 16.1 B per
+    // element in those waves.  The decision waits for the mask word, so the latency-bound sizes (BLOCK = 64) keep issuing every load
+    // at once.  (m in {0, 1}: out = model_out * 1 + 0 * 0 resp. 0 * 0 + y * 1, the value of the full expression for finite operands.)
+    constexpr bool RA = VEC == 4 && BLOCK == 256;
+    const bool in_range = g < groups;
+    if (RA || in_range) {
+        const int64_t i = (in_range ? g : groups - 1) * VEC;
         float m[VEC], mo[VEC], yv[VEC], o[VEC];
         Raw<VEC> m_raw, mo_raw, un_raw;                 // issue every load, decode afterwards (lp_common.h)
         load_mask_raw<VEC>(d.mask, d.flags, i, m_raw);
-        load_raw<VEC>(d.model_out, dt, i, mo_raw);
-        if (d.flags & LP_FL_CFG_FUSED) load_raw<VEC>(d.uncond, dt, i, un_raw);
-        load_f32<VEC>(d.y, i, yv);
         float xs[VEC];
-        if (x_dst) load_f32<VEC>(d.x_src, i, xs);
+        bool need_mo = true, need_y = true;
+        if constexpr (RA) {
+            if (x_dst) load_f32<VEC>(d.x_src, i, xs);
+            if ((d.flags & LP_FL_MASK_BITS) && !(d.flags & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP))) {
+                const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;
+                need_y = __ballot(in_range && nib != 0u) != 0ull;
+                need_mo = __ballot(in_range && nib != 0xFu) != 0ull;
+            }
+            if (!in_range) return;                      // (after the ballots: every lane of the wave takes part in them)
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) mo_raw.w[k] = 0u, yv[k] = 0.0f;
+        if (need_mo) load_raw<VEC>(d.model_out, dt, i, mo_raw);
+        if (d.flags & LP_FL_CFG_FUSED) load_raw<VEC>(d.uncond, dt, i, un_raw);
+        if (need_y) load_f32<VEC>(d.y, i, yv);
+        if constexpr (!RA) {
+            if (x_dst) load_f32<VEC>(d.x_src, i, xs);
+        }
         cvt_mask<VEC>(d.flags, i, m_raw, m);
         cvt_raw<VEC>(dt, mo_raw, mo);
         if (d.flags & LP_FL_CFG_FUSED) {
