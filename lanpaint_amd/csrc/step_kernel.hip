@@ -772,7 +772,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         }
         if (ph & LP_PH_REPLACE) {
             load_f32<VEC>(d.x, i, xv);
-            if (d.replace_kind == LP_REPLACE_KNOWN) {
+            // region-aware like the POST streams below: a wave of 256 inpaint elements (mask bits all 0) keeps its x and reads
+            // neither the noise nor the known latent -- 12 -> 4 B / element read there (streaming kernels, bit-packed mask)
+            bool need_kn = true;
+            if constexpr (HARD && VEC == 4 && !ST && (PH & LP_PH_REPLACE) != 0) {
+                if (!(fl & LP_FL_NO_REGION_SKIP)) {
+                    const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;
+                    need_kn = __ballot(nib != 0u) != 0ull;
+                }
+            }
+            if (!need_kn) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) kn[k] = 0.0f, nv[k] = 0.0f, yv[k] = 0.0f;      // (times m = 0 below)
+            } else if (d.replace_kind == LP_REPLACE_KNOWN) {
                 load_f32<VEC>(d.known, i, kn);
             } else {
                 load_f32<VEC>(d.noise, i, nv);
