@@ -156,7 +156,9 @@ def test_wmse_pair_matches_oracle(lib):
     import torch
     from lanpaint_amd.earlystop import _Metric
     rng = np.random.default_rng(3)
-    for shape in [(2, 3, 9, 11), (1, 4, 128, 128), (1, 16, 5, 6, 7)]:
+    # (594 elements: the 4-byte path; 65 536: 64 block sums; 786 432 and the video latent: more block sums than the totalling wave
+    # has lanes / than the 1 024-block cap)
+    for shape in [(2, 3, 9, 11), (1, 4, 128, 128), (1, 16, 5, 6, 7), (3, 4, 256, 256), (1, 16, 21, 60, 104)]:
         m = (rng.random(shape) > 0.5).astype(np.float32)
         a = rng.standard_normal(shape, dtype=np.float32)
         b = rng.standard_normal(shape, dtype=np.float32)
@@ -554,6 +556,57 @@ def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase, r
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert not torch.equal(res[0][0], x_t0) and torch.isfinite(res[0][0]).all()
+
+
+@pytest.mark.parametrize("kind", ["temporal", "box", "blob"])
+def test_region_aware_replace_and_finalize_change_nothing_but_the_traffic(lib, kind):
+    """Round 4: the two launches around the think loop follow the same rule at streaming sizes.  The replace launch (with the
+    coefficient table folded in, lanpaint.py:89-92): a wave of 256 inpaint elements keeps its x and reads neither noise nor known
+    latent.  lp_finalize (lanpaint.py:154,156): such a wave never reads y, a wave of known elements never reads the model
+    output.  Same launches with LP_FL_NO_REGION_SKIP: bitwise equal results, on uniform regions, mixed waves only, and a disc."""
+    import torch
+    import bench
+    from lanpaint_amd import _cabi
+    dev = torch.device("cuda", 0)
+    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
+    bench.MASK_KIND, bench.MASK_FORMAT = kind, "bits"
+    try:
+        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev,
+                                              _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS)
+    finally:
+        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    bufs, mask, coef, sig, ve, abt = keep
+    d.t_ve, d.t_abt, d.t_rsig, d.t_ve_stride, d.t_abt_stride, d.t_rsig_stride = ve.data_ptr(), abt.data_ptr(), sig.data_ptr(), 1, 1, 1
+    d.coef_out = coef.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for extra in (0, _cabi.LP_FL_NO_REGION_SKIP):
+        for k in ("x_t", "C", "x_in"):
+            bufs[k].fill_(-7.0)
+        d.flags = (d.flags & ~_cabi.LP_FL_NO_REGION_SKIP) | extra
+        _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+        torch.cuda.synchronize()
+        res.append([bufs[k].clone() for k in ("x_t", "C", "x_in")])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    m = mask.reshape(bufs["x"].shape)
+    x_want = bufs["x"] * (1 - m) + (bufs["y"] + bufs["noise"] * sig.view(-1, *([1] * (m.ndim - 1)))) * m
+    scale = torch.sqrt(1.0 + ve * ve).view(-1, *([1] * (m.ndim - 1))) if not bench.WORKLOADS["c5_wan"][1] else None
+    assert torch.isfinite(res[0][0]).all() and not (res[0][0] == -7.0).any()
+    if scale is not None:
+        assert torch.allclose(res[0][0], x_want / scale, rtol=1e-5, atol=1e-6)
+
+    out = [torch.full_like(bufs["x"], -3.0) for _ in range(2)]
+    xd = [torch.full_like(bufs["x"], -3.0) for _ in range(2)]
+    for j, extra in enumerate((0, _cabi.LP_FL_NO_REGION_SKIP)):
+        f = _cabi.LpFinalDesc()
+        f.n_el, f.flags = n_el, _cabi.LP_FL_MASK_BITS | extra
+        f.model_out, f.y, f.mask = bufs["x0"].data_ptr(), bufs["y"].data_ptr(), mask._lp_bits.data_ptr()
+        f.x_src, f.x_dst, f.out = bufs["x_t"].data_ptr(), xd[j].data_ptr(), out[j].data_ptr()
+        _cabi.check(lib.lp_finalize(ctypes.byref(f), st), "lp_finalize")
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1]) and torch.equal(xd[0], xd[1]) and torch.equal(xd[0], bufs["x_t"])
+    assert torch.equal(out[0], bufs["x0"] * (1 - m) + bufs["y"] * m)
 
 
 @pytest.mark.parametrize("half", ["bf16", "fp16"])
