@@ -48,7 +48,7 @@ __global__ void lp_sigma_times_kernel(const float* __restrict__ sigma, int rows,
                                       int schedule_len, int is_flow, float* __restrict__ times,
                                       float* __restrict__ scalars, int32_t* __restrict__ seq_out, int32_t seq,
                                       const SigmaRule rule) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= kWave) return;             // one full wave (launched as such)
     sigma_rows_and_rule(sigma, rows, schedule, schedule_len, is_flow != 0, times, scalars, seq_out, seq, rule);
 }
 

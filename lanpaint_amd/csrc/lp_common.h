@@ -637,7 +637,7 @@ __device__ __forceinline__ void sigma_to_times(float s, bool is_flow, float& ve,
     }
 }
 
-// What thread 0 of lp_sigma_times_kernel (or of the first block of an LP_PH_SIGMA replace launch) does after the rows:
+// What the first wave of lp_sigma_times_kernel (or of the first block of an LP_PH_SIGMA replace launch) does after the rows:
 // the two scalars of the inner-step rule, the rule against a speculated count, the mailbox.
 struct SigmaRule {
     int32_t n_steps, early_stop, total_steps, guess;       // guess < 0: not speculating (the word is set to 1)
@@ -648,29 +648,42 @@ struct SigmaRule {
 __host__ __device__ inline int32_t effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps,
                                                          int32_t early_stop, double min_step_frac);
 
+// Run by ONE FULL WAVE (every lane alive): the rows and the schedule entries are loaded lane-parallel -- one memory round
+// trip each instead of a scalar load + wait per entry (a 30-entry schedule: ~3 us of a thread-0 walk on the critical path of
+// every sigma call of the node path) -- while every floating-point sum keeps the sequential order of the one-thread form
+// (readlane by readlane), and the arg-min keeps torch.argmin's first-minimum rule (ties go to the lower index).  Lane 0
+// then applies the rule and posts the mailbox.
 __device__ __forceinline__ void sigma_rows_and_rule(const float* __restrict__ sigma, int rows, const float* __restrict__ schedule,
                                                     int schedule_len, bool is_flow, float* __restrict__ times,
                                                     float* __restrict__ scalars, int32_t* __restrict__ seq_out, int32_t seq,
                                                     const SigmaRule& rule) {
 #pragma clang fp contract(off)
+    const int lane = static_cast<int>(threadIdx.x) & (kWave - 1);
     float sum_sigma = 0.0f, sum_oma = 0.0f;
-    for (int r = 0; r < rows; ++r) {
-        const float s = sigma[r];
-        float ve, abt, ft;
-        sigma_to_times(s, is_flow, ve, abt, ft);
-        if (times) {
-            times[r] = ve;
-            times[rows + r] = abt;
-            times[2 * rows + r] = ft;
+    for (int r0 = 0; r0 < rows; r0 += kWave) {
+        const int r = r0 + lane;
+        float s = 0.0f, oma = 0.0f;
+        if (r < rows) {
+            s = sigma[r];
+            float ve, abt, ft;
+            sigma_to_times(s, is_flow, ve, abt, ft);
+            if (times) {
+                times[r] = ve;
+                times[rows + r] = abt;
+                times[2 * rows + r] = ft;
+            }
+            oma = 1.0f - abt;
         }
-        sum_sigma = sum_sigma + s;
-        const float oma = 1.0f - abt;
-        sum_oma = sum_oma + oma;
+        const int n = rows - r0 < kWave ? rows - r0 : kWave;
+        for (int k = 0; k < n; ++k) {                                // the one-thread order: row after row
+            sum_sigma = sum_sigma + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), k));
+            sum_oma = sum_oma + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oma), k));
+        }
     }
     const float mean_sigma = sum_sigma / static_cast<float>(rows);
     int best = 0;
     float best_d = INFINITY;
-    for (int i = 0; i < schedule_len; ++i) {                         // first minimum, like torch.argmin
+    for (int i = lane; i < schedule_len; i += kWave) {               // this lane's entries, first minimum among them
         const float diff = schedule[i] - mean_sigma;
         const float dd = fabsf(diff);
         if (dd < best_d) {
@@ -678,6 +691,16 @@ __device__ __forceinline__ void sigma_rows_and_rule(const float* __restrict__ si
             best = i;
         }
     }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {                      // first minimum over the wave (every lane ends with it)
+        const float od = __shfl_xor(best_d, off, kWave);
+        const int ob = __shfl_xor(best, off, kWave);
+        if (od < best_d || (od == best_d && ob < best)) {
+            best_d = od;
+            best = ob;
+        }
+    }
+    if (lane != 0) return;
     const float frac = sum_oma / static_cast<float>(rows);
     scalars[0] = static_cast<float>(best);
     scalars[1] = frac;

@@ -506,13 +506,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         constexpr bool fold_sigma = (PH & LP_PH_SIGMA) != 0;
         if constexpr (fold_sigma) {
             // LP_PH_SIGMA: the times of this row straight from sigma (what lp_sigma_times would have written to t_ve / t_abt /
-            // t_model; the replace sigma IS sigma); thread 0 of the first block also does that kernel's single-thread part --
+            // t_model; the replace sigma IS sigma); the first wave of the first block also does that kernel's part --
             // the rule's two scalars, the rule against the speculated count, the mailbox
             float ft;
             rs_f = d.sg_sigma[row];
             sigma_to_times(rs_f, flow, ve_f, abt_f, ft);
             tm_sig = flow ? ft : ve_f;
-            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kWave) {      // (the block's first wave, all 64 lanes alive here)
                 const SigmaRule rule{d.sg_n_steps, d.sg_early_stop, d.sg_total_steps, d.sg_guess, d.sg_min_step_frac, d.sg_valid_out};
                 sigma_rows_and_rule(d.sg_sigma, d.rows, d.sg_schedule, d.sg_schedule_len, flow, d.sg_times_out, d.sg_scalars_out,
                                     d.sg_seq_out, d.sg_seq, rule);
