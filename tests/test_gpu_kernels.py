@@ -279,6 +279,40 @@ def test_sigma_times_bit_exact_vs_reference_cpu_ops(lib, flow):
                 torch.testing.assert_close(a.cpu(), b, rtol=2.5e-7, atol=0)
 
 
+@pytest.mark.parametrize("rows,sched_len", [(1, 1), (3, 64), (64, 65), (70, 200), (130, 1000)])
+def test_sigma_times_wave_form_keeps_the_one_thread_order(lib, rows, sched_len):
+    """The sigma algebra is run by one full wave (rows and schedule entries loaded lane-parallel): more rows / entries than
+    lanes, different sigma per row, a schedule with REPEATED values around the mean.  The sums must be the sequential fp32
+    sums of the one-thread form (row after row), the index torch.argmin's first minimum."""
+    import torch
+    from lanpaint_amd import _cabi
+    rng = np.random.default_rng(rows * 1000 + sched_len)
+    sig = rng.uniform(0.05, 14.0, rows).astype(np.float32)
+    sched = np.sort(rng.uniform(0.0, 14.6, sched_len).astype(np.float32))[::-1].copy()
+    seq_mean = np.float32(0.0)
+    for v in sig:
+        seq_mean = np.float32(seq_mean + v)
+    seq_mean = np.float32(seq_mean / np.float32(rows))
+    if sched_len >= 8:               # ties: the entry nearest the mean, four times in a row, and its mirror image on the other side
+        k = int(np.argmin(np.abs(sched - seq_mean)))
+        k = min(max(k, 2), sched_len - 5)
+        sched[k:k + 4] = sched[k]
+        sched[k + 4] = np.float32(seq_mean - (sched[k] - seq_mean))
+    buf = torch.empty(3 * rows + 2, dtype=torch.float32, device="cuda")
+    sig_d, sched_d = torch.from_numpy(sig).cuda(), torch.from_numpy(sched).cuda()
+    _cabi.check(lib.lp_sigma_times(sig_d.data_ptr(), rows, sched_d.data_ptr(), sched_len, 0, buf.data_ptr(), buf[3 * rows:].data_ptr(),
+                                   _stream()))
+    got = buf.cpu().numpy()
+    abt = (np.float32(1.0) / (np.float32(1.0) + sig * sig)).astype(np.float32)
+    assert np.array_equal(got[:rows], sig) and np.array_equal(got[rows:2 * rows], abt)
+    seq_oma = np.float32(0.0)
+    for v in abt:
+        seq_oma = np.float32(seq_oma + np.float32(np.float32(1.0) - v))
+    assert np.float32(got[3 * rows + 1]) == np.float32(seq_oma / np.float32(rows))
+    dd = np.abs((sched - seq_mean).astype(np.float32))
+    assert int(got[3 * rows]) == int(np.argmin(dd))            # numpy's argmin: first minimum, like torch's
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4 * 128 * 128, 16 * 21 * 60 * 104 + 7])
 @pytest.mark.parametrize("denoise", [False, True])
 def test_pack_mask_bit_exact(lib, n, denoise):
