@@ -21,7 +21,8 @@ from lanpaint_amd import _cabi                  # noqa: E402
 PH = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
       "first": _cabi.LP_PH_POST_FIRST | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
       "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT,
-      "replace": _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT}
+      "replace": _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT,
+      "replacec": _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS}      # the engine's replace launch (table folded in)
 
 
 def main():
@@ -34,6 +35,10 @@ def main():
     half = os.environ.get("LANPAINT_AMD_BENCH_DTYPE") == "bf16"
     d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase], model_dtype=torch.bfloat16 if half else None)
     bufs = keep[0]
+    if phase == "replacec":
+        _b, _m, coef, sig, ve, abt = keep
+        d.t_ve, d.t_abt, d.t_rsig, d.t_ve_stride, d.t_abt_stride, d.t_rsig_stride = ve.data_ptr(), abt.data_ptr(), sig.data_ptr(), 1, 1, 1
+        d.coef_out = coef.data_ptr()
     rng = sys.argv[4] if len(sys.argv) > 4 else "philox"
     if rng == "torch":                          # the device generator's randn stream reproduced in-kernel
         from lanpaint_amd import LanPaint
@@ -77,7 +82,7 @@ def main():
         g2.replay()
     torch.cuda.synchronize()
     us_mul = (time.perf_counter() - t0) / (n_rep * reps) * 1e6
-    bytes_ = ({"steady": 36, "first": 32, "last": 36, "replace": 24}[phase] - (6 if half and phase != "replace" else 0)) * n_el
+    bytes_ = ({"steady": 36, "first": 32, "last": 36, "replace": 24, "replacec": 24}[phase] - (6 if half and phase != "replace" else 0)) * n_el
     env = {k: v for k, v in os.environ.items() if k.startswith("LANPAINT_AMD_TUNE")}
     print(f"{wl} {phase} n_el={n_el} us/launch={us:.3f} ({bytes_ / us / 1e3:.0f} GB/s algorithmic) "
           f"heads={'bf16' if half else 'fp32'} rng={rng} mask={bench.MASK_KIND or 'default'} region_skip={0 if os.environ.get('LANPAINT_AMD_NO_REGION_SKIP') else 1} torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
