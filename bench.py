@@ -521,12 +521,16 @@ def run_gpu(args):
         raise SystemExit(3)
 
 
+def _profile_order(path):
+    """Sort key of a profiles/ file: round number, then rNN_ (the round's final pass) AFTER rNNa_, rNNb_ (its earlier passes,
+    kept for the box-to-box spread) -- plain string order would put `r04a_` behind `r04_`."""
+    m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+    return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (-1, False, "")
+
+
 def _latest_profile_json(pattern):
     import glob
-    def order(path):            # rNN_ (a round's final pass) after rNNa_, rNNb_ (its earlier passes, kept for the box-to-box spread)
-        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
-        return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (-1, False, "")
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=order)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=_profile_order)
     if not files:
         return None, None
     try:

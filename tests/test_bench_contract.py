@@ -101,6 +101,8 @@ def test_roofline_block_is_a_bandwidth_statement():
     r2 = bench.roofline_fields(100, 1.0, 250)               # counters above the algorithmic bytes: re-reads do not earn credit
     assert r2["frac_counter"] == r2["frac_algorithmic"]
     assert bench.roofline_fields(100, 1.0, None)["frac_counter"] is None
+    names = ["r03_x.json", "r04a_x.json", "r04_x.json", "r04b_x.json", "r10_x.json", "r9_x.json", "notes.json"]
+    assert sorted(names, key=bench._profile_order) == ["notes.json", "r03_x.json", "r04a_x.json", "r04b_x.json", "r04_x.json", "r9_x.json", "r10_x.json"]
     c = bench.committed_profile("c2_sdxl")
     assert c["kernel_durations_file"].startswith("r") and c["pmc_traffic_file"].startswith("r")
     assert c["rocprofv3_mean_launch_us"] > 0 and c["pmc_traffic_bytes_per_launch"] > 0
