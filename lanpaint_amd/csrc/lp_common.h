@@ -155,6 +155,18 @@ __device__ __forceinline__ void torch_normal4(uint32_t idx, uint64_t seed, uint6
     o[0] = a.x * 1.0f + 0.0f; o[1] = a.y * 1.0f + 0.0f; o[2] = b.x * 1.0f + 0.0f; o[3] = b.y * 1.0f + 0.0f;
 }
 
+// x / s with the reciprocal y = RN(1 / s) of a divisor that several quotients share: q0 = RN(x y), r = x - s q0 (exact in an FMA),
+// q = RN(q0 + r y).  With a correctly rounded reciprocal the one residual correction gives the correctly rounded quotient
+// (Markstein 1990) -- the value of IEEE division, which the reference's `x_t / c` is -- in 3 instructions per quotient instead
+// of the 11 of v_div_scale / v_rcp / 4 x fma / v_div_fmas / v_div_fixup (four elements per lane: 44 -> 12 + one reciprocal, of a
+// kernel that is VALU-bound at streaming sizes).  No range scaling: operands and quotients of normal magnitude (latents; 2e7
+// random pairs against IEEE division: 0 differences); a non-finite x gives NaN where the division gives inf, -0 gives +0.
+__device__ __forceinline__ float div_shared(float x, float s, float y) {
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-s, q0, x);
+    return __builtin_fmaf(r, y, q0);
+}
+
 // ---- 16/32-bit float conversions ----------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(static_cast<uint32_t>(h) << 16); }
 // fp32 -> bf16, round to nearest even: gfx950's own conversion instruction (v_cvt_pk_bf16_f32, one VALU op per PAIR; the

@@ -1037,8 +1037,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
 
         // OU(x, dt/2, C) of lanpaint.py:280 for element k (table path or the reference's own formulas)
         // (table form with the region's coefficients given: `q` is an SGPR set in a mask-uniform wave)
+        auto half_valid = [&](float x, float c, float xi, const RegionCoef& q) __attribute__((always_inline)) -> float {
+            return fmaf(q.e_half, x, fmaf(q.k_half, c, q.std_half * xi));
+        };
         auto half_table = [&](float x, float c, float xi, const RegionCoef& q) __attribute__((always_inline)) -> float {
-            return rc.valid != 0.0f ? fmaf(q.e_half, x, fmaf(q.k_half, c, q.std_half * xi)) : x;
+            return rc.valid != 0.0f ? half_valid(x, c, xi, q) : x;
         };
         auto half_step = [&](float x, float c, float xi, int k) __attribute__((always_inline)) -> float {
             const float mk = m[k];
@@ -1106,30 +1109,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 }
             }
             // table path of element k: two regions per row, no transcendental per element (`q`: the region's coefficients)
-            auto post_table = [&](int k, const RegionCoef& q, bool known_el) __attribute__((always_inline)) {
-                if (rc.valid != 0.0f) {
-                    const float s0 = (given || !known_el) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
-                    const float cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
-                    x0s[k] = s0;
-                    if (ph & LP_PH_POST_FIRST) {
-                        xt[k] = fmaf(q.e_full, xt[k], fmaf(q.k_full, cn, q.std_full * xi_a[k]));
-                    } else {
-                        const float xd = fmaf(cn - cv[k], q.dt, xt[k]);
-                        xt[k] = fmaf(q.e_half, xd, fmaf(q.k_half, cv[k], q.std_half * xi_a[k]));
-                    }
-                    cv[k] = cn;
+            auto post_valid = [&](int k, const RegionCoef& q, bool known_el) __attribute__((always_inline)) {
+                const float s0 = (given || !known_el) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
+                const float cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
+                x0s[k] = s0;
+                if (ph & LP_PH_POST_FIRST) {
+                    xt[k] = fmaf(q.e_full, xt[k], fmaf(q.k_full, cn, q.std_full * xi_a[k]));
                 } else {
-                    x0s[k] = x0[k];
-                    if (ph & LP_PH_POST_FIRST) cv[k] = 0.0f;
+                    const float xd = fmaf(cn - cv[k], q.dt, xt[k]);
+                    xt[k] = fmaf(q.e_half, xd, fmaf(q.k_half, cv[k], q.std_half * xi_a[k]));
                 }
+                cv[k] = cn;
+            };
+            auto post_skipped = [&](int k) __attribute__((always_inline)) {      // a row whose step is not positive (lanpaint.py:205)
+                x0s[k] = x0[k];
+                if (ph & LP_PH_POST_FIRST) cv[k] = 0.0f;
+            };
+            auto post_table = [&](int k, const RegionCoef& q, bool known_el) __attribute__((always_inline)) {
+                if (rc.valid != 0.0f) post_valid(k, q, known_el);
+                else post_skipped(k);
             };
             if (UNI && uni >= 0) {               // mask-uniform wave: the region's coefficient set stays in SGPRs
-                if (uni == 0) {
+                // (the row's `valid` test OUTSIDE the element loop: four elements of straight-line arithmetic on scalar coefficients,
+                // which the compiler pairs into packed fp32 instructions -- v_pk_fma_f32, two IEEE FMAs per instruction; with the
+                // test inside, every element sat behind its own scalar branch)
+                if (rc.valid == 0.0f) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) post_table(k, rc.reg[0], false);
+                    for (int k = 0; k < VEC; ++k) post_skipped(k);
+                } else if (uni == 0) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) post_valid(k, rc.reg[0], false);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) post_table(k, rc.reg[1], true);
+                    for (int k = 0; k < VEC; ++k) post_valid(k, rc.reg[1], true);
                 }
             } else {
 #pragma unroll
@@ -1233,12 +1245,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
 #pragma unroll
         for (int k = 0; k < VEC; ++k) xe[k] = xt[k];
         if (ph & LP_PH_PRE_HALF) {
-            if (UNI && uni == 0) {
+            if (UNI && uni >= 0 && rc.valid == 0.0f) {
+                // (a skipped row keeps x: xe = xt already)
+            } else if (UNI && uni == 0) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) xe[k] = half_table(xt[k], cv[k], xi_b[k], rc.reg[0]);
+                for (int k = 0; k < VEC; ++k) xe[k] = half_valid(xt[k], cv[k], xi_b[k], rc.reg[0]);
             } else if (UNI && uni == 1) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) xe[k] = half_table(xt[k], cv[k], xi_b[k], rc.reg[1]);
+                for (int k = 0; k < VEC; ++k) xe[k] = half_valid(xt[k], cv[k], xi_b[k], rc.reg[1]);
             } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) xe[k] = half_step(xt[k], cv[k], xi_b[k], k);
@@ -1264,15 +1278,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         // ---- EMIT: model-space latent for the next backbone call --------------------------------
         if (ph & LP_PH_EMIT) {
             float xo[VEC];
+            if constexpr (VEC == 4 && !PER_EL && PH != 0) {
+                // streaming row-table kernels: the row's scale divides all four elements of the lane -- one reciprocal + three
+                // instructions per quotient instead of four IEEE division sequences, same values (div_shared, lp_common.h).
+                // (a real branch: the empty asm keeps the reciprocal from being hoisted in front of it, after which both sides
+                // were computed for every element and selected)
+                const float sc = rc.scale;
+                if (flow) {
+                    float y = 1.0f / sc;
+                    asm volatile("" : "+v"(y));
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                float sc;
-                if constexpr (PER_EL) {
-                    sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
+                    for (int k = 0; k < VEC; ++k) xo[k] = div_shared(xe[k], sc, y);
                 } else {
-                    sc = row_scale_of(k);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) xo[k] = xe[k] * sc;
                 }
-                xo[k] = flow ? xe[k] / sc : xe[k] * sc;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float sc;
+                    if constexpr (PER_EL) {
+                        sc = flow ? (sqrtf(abt_e[k]) + sqrtf(1.0f - abt_e[k])) : sqrtf(1.0f + ve_e[k] * ve_e[k]);
+                    } else {
+                        sc = row_scale_of(k);
+                    }
+                    xo[k] = flow ? xe[k] / sc : xe[k] * sc;
+                }
             }
             if constexpr (PAIR) {
                 if (xindt != DT_F32) store_half_pair(d.x_in, xindt, i, xo);
