@@ -319,30 +319,36 @@ def run_gpu(args):
         backend = "gloo"
     affinity0 = os.sched_getaffinity(0)
     numa = lpd.bind_to_device_numa(dev_index) if not args.no_numa_bind else None
-    lpd.init(backend, dev)                              # "nccl" IS RCCL on ROCm; no-op at world size 1
+    t_proc0 = time.perf_counter()
 
     # Per-dispatch event timing of the dominant kernel, taken FIRST in the process: the same burst repeated after
     # graph captures / other streams exist reads ~1.2 us higher at the video-latent size (11.4 vs 10.2 us) although
     # rocprofv3 shows the same 10.5-10.7 us per dispatch in both places -- event bookkeeping, not the kernel.
+    # EVERY rank takes its own (round 5; rank 0 alone used to, with the others parked in a collective): the per-rank
+    # launch duration is the first thing to look at when one rank of an 8-GPU run is slow (dist.per_rank[].steady_launch_us).
+    # All of it -- and the parity pass below -- runs BEFORE the process group exists, so no rank ever waits in a collective
+    # for another rank's local work (RCCL's watchdog is the first place an 8-GPU run can die).
     pre_busy = pre_large = pre_past = None
-    if rank == 0:
-        try:
-            if world == 1 and not args.no_large_shape:
-                # 1.2 GB per launch: nothing of it survives in the 256 MiB Infinity Cache between launches.  Every operand
-                # streamed (what SURVEY.md 8d's 36 B / element describes) and as shipped (waves whose mask bits are uniform
-                # skip the streams their region never reads), interleaved, three clocks each
-                pre_past = measure_past_l3(_cabi, dev)
-                torch.cuda.empty_cache()
-            if world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
-                pre_large = measure_hbm_bound_shape(_cabi, dev)      # the bandwidth-bound shape is the sensitive one
-            pre_busy = measure_hbm_bound_shape(_cabi, dev, workload=args.workload, launches=120)
-        except Exception as e:
-            pre_busy = {"error": repr(e)}
+    try:
+        if rank == 0 and world == 1 and not args.no_large_shape:
+            # 1.2 GB per launch: nothing of it survives in the 256 MiB Infinity Cache between launches.  Every operand
+            # streamed (what SURVEY.md 8d's 36 B / element describes) and as shipped (waves whose mask bits are uniform
+            # skip the streams their region never reads), interleaved, three clocks each
+            pre_past = measure_past_l3(_cabi, dev)
+            torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and args.workload != "c5_wan" and not args.no_large_shape:
+            pre_large = measure_hbm_bound_shape(_cabi, dev)      # the bandwidth-bound shape is the sensitive one
+        pre_busy = measure_hbm_bound_shape(_cabi, dev, workload=args.workload, launches=120)
+    except Exception as e:
+        pre_busy = {"error": repr(e)}
 
     shape, flow, n_sig, n_think = WORKLOADS[args.workload]
     sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), lpd.replica_seed(args.seed, rank), dev, tt)
+    t_init0 = time.perf_counter()
+    lpd.init(backend, dev)                              # "nccl" IS RCCL on ROCm; no-op at world size 1
+    t_init = time.perf_counter() - t_init0
     bcast, cond = {}, None
     if world > 1:      # all replicas inpaint the same image with the same mask under the same conditioning: ONE packed
         # broadcast from rank 0 at set-up -- mask, known latent, cond tensors -- and nothing afterwards
@@ -372,16 +378,24 @@ def run_gpu(args):
                       philox_seed=lpd.replica_seed(args.seed, rank), graph=bool(args.graph),
                       model_dtype=torch.bfloat16 if args.model_dtype == "bf16" else None)
 
+    waits = []
+
     def barrier():
+        """dist.barrier + device sync; remembers how long THIS rank waited in the collective (dist.per_rank[].barrier_wait_s:
+        a rank that arrives early waits for the slowest one -- the first number to look at when scaling efficiency is off)."""
         if world > 1:
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
             dist.barrier()
+            waits.append(time.perf_counter() - t_b)
         torch.cuda.synchronize()
 
     # Before anything is timed: does THIS engine, in THIS configuration, compute what the reference computes?  One schedule
-    # pass against the CPU oracle on the same draws (rank 0; bounded on the video-latent shapes, where a numpy pass over the
-    # whole schedule would take minutes).  No `value` is printed when the pass is off by more than the stated tolerance.
+    # pass against the CPU oracle on the same draws (bounded on the video-latent shapes, where a numpy pass over the whole
+    # schedule would take minutes).  No `value` is printed when the pass is off by more than the stated tolerance.  EVERY rank
+    # checks its own replica (round 5): symmetric work, nobody sits in a collective while rank 0 runs numpy for seconds.
     parity = None
-    if rank == 0 and not args.no_parity_check:
+    if not args.no_parity_check:
         n_par = args.parity_sigmas if args.parity_sigmas > 0 else (n_sig if int(np.prod(shape)) <= 512 * 1024 else 2)
         try:
             parity = parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow, max_sigmas=n_par)
@@ -397,11 +411,18 @@ def run_gpu(args):
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+    t_setup = time.perf_counter() - t_proc0
+    clocks_before = gpu_clocks(dev_index)
     barrier()
+    first_wait = waits[-1] if waits else None
     it0 = engine.iterations_run
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x_last = schedule_pass(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0             # this rank's own K steps, before it waits for the others
+    cpu_busy = time.process_time() - cpu0
     barrier()
     elapsed = time.perf_counter() - t0
     iters_local = engine.iterations_run - it0
@@ -415,6 +436,16 @@ def run_gpu(args):
         "pci_bus_id": _pci_bus_id(dev_index), "numa": numa, "pid": os.getpid(), "steps": args.steps, "iterations": int(iters_local),
         "elapsed_s": elapsed, "it_s": iters_local / elapsed, "final_checksum": float(x_last.double().sum().item()),
         "rows": int(shape[0]),
+        # diagnostics of a multi-rank run (round 5): this rank's own time for the K steps (before the closing barrier), the host
+        # CPU time it burnt over them (process_time / elapsed ~ 1: the rank is host-bound and wants its own core), how long it
+        # waited in the barrier in front of the timed region, its steady-launch duration measured alone before the group
+        # existed, the device's clocks, and its own parity verdict
+        "own_elapsed_s": own_elapsed, "own_it_s": iters_local / own_elapsed, "process_time_over_elapsed": cpu_busy / own_elapsed,
+        "t_first_barrier_wait_s": first_wait, "closing_barrier_wait_s": (waits[-1] if len(waits) > 1 else None),
+        "setup_s": t_setup, "init_process_group_s": t_init,
+        "steady_launch_us": (pre_busy or {}).get("mean_launch_us"), "clocks_mhz": {"before": clocks_before, "after": gpu_clocks(dev_index)},
+        "cpus_allowed": len(os.sched_getaffinity(0)),
+        "parity_ok": (None if parity is None else bool(parity.get("ok"))), "parity_mse_x": (None if parity is None else parity.get("mse_x")),
         # what this rank holds of the shared job after the broadcast: equal on every rank, or the broadcast did not deliver
         "shared_checksum": (float(sum(t.double().sum().item() for t in (mask, y, *(cond or {}).values()))) if world > 1 else None)})
     if dist_info is not None and rank == 0:
@@ -424,6 +455,10 @@ def run_gpu(args):
                           "shared_tensors": {k: list(v.shape) for k, v in dict({"mask": mask, "y": y}, **(cond or {})).items()},
                           "shared_checksums_equal": len({r.get("shared_checksum") for r in dist_info["per_rank"]}) == 1,
                           "global_rows": sum(r.get("rows", 0) for r in dist_info["per_rank"]),
+                          "parity_ok_all_ranks": all(r.get("parity_ok") is not False for r in dist_info["per_rank"]),
+                          "slowest_rank": max(dist_info["per_rank"], key=lambda r: r.get("own_elapsed_s") or 0.0).get("rank"),
+                          "own_it_s_spread": [min(r.get("own_it_s") or 0.0 for r in dist_info["per_rank"]),
+                                              max(r.get("own_it_s") or 0.0 for r in dist_info["per_rank"])],
                           "note": "weak scaling: every rank runs the whole workload on its own replica (seed + rank); one packed "
                                   "broadcast of mask + known latent at set-up, no collective inside the timed loop; value = "
                                   "sum of the ranks' iterations / slowest rank's time"})
@@ -479,7 +514,15 @@ def run_gpu(args):
     mask_desc = {"box": "50% box mask", "blob": "centred disc mask",
                  "temporal": f"temporal mask (second half of the video inpainted: latent frames >= "
                              f"{temporal_known_frames(shape[2]) if len(shape) == 5 else 0} after the 5-tap union)"}[kind]
-    parity_failed = parity is not None and not parity.get("ok")
+    parity_failed = (parity is not None and not parity.get("ok")) or (dist_info is not None and not dist_info.get("parity_ok_all_ranks", True))
+    ref_gpu = rccl = None
+    if world == 1 and args.extras:
+        try:
+            ref_gpu = reference_gpu_eager(args.workload, dev, iters_total / tmax)
+        except Exception as e:
+            ref_gpu = {"error": repr(e)}
+        if not args.no_rccl_selftest:
+            rccl = rccl_single_rank_selftest()
     line = {
         "metric": "langevin_think_iterations_per_sec",
         "value": None if parity_failed else iters_total / tmax,
@@ -510,7 +553,11 @@ def run_gpu(args):
         "roofline_hbm_bound_shape": large,
         "roofline_hbm_past_l3": past_l3,
         "cpu_baseline": cpu,
+        # the unmodified reference on THIS GPU (eager ATen launches) next to the product: same device, same schedule, same stub
+        "reference_gpu_eager": ref_gpu,
         "dist": dist_info,
+        # N = 1: a one-rank RCCL group in a child process pushes a job through the collectives of the N > 1 path
+        "rccl_single_rank_selftest": rccl,
     }
     line.update(extras)
     if parity_failed:
@@ -577,17 +624,52 @@ def committed_profile(workload):
                     "are the event-timer ones"}
 
 
-def roofline_fields(bytes_alg, duration_us, traffic):
-    """The bandwidth statement of one launch: algorithmic bytes / duration (`achieved`, `frac_algorithmic`) and
-    the counter-side rate -- min(algorithmic, PMC-measured) bytes / duration (`frac_counter`): a fraction of peak on
-    bytes the kernel does not move is not a bandwidth fraction."""
+def steady_bytes_per_launch(mask_np, mask_format, n_el, every_stream=False, model_dtype=None):
+    """ALGORITHMIC bytes of one steady-state launch (POST_STEADY | PRE_HALF | EMIT), two figures:
+      every_stream -- SURVEY.md 8(d)'s per-unit figure for this storage: read x_t, x0, x0_BIG, y, m, C and write x_t, C, x_in
+                      for EVERY element (36 B with fp32 streams and the reference's fp32 mask; the mask's own width as used:
+                      0.125 B bit-packed, 1 B as bytes; half-width heads / x_in with a bf16 backbone);
+      required     -- the bytes THIS job needs, from the mask actually used: an inpaint element (m = 0) reads head 0 only, a
+                      known one (m = 1) head 1 and y only (lanpaint.py:182-184 with m in {0, 1}).  It applies to the launches
+                      that act on it -- the region-aware streaming kernels (bit-packed mask, 16 B per lane: more than 512 Ki
+                      elements, not LP_FL_NO_REGION_SKIP); every other launch streams every operand and `required` equals
+                      `every_stream`.
+    `roofline.frac` is computed on `required`: a fraction of peak on bytes the kernel never has to move is not a bandwidth
+    fraction (the round-4 C5 line printed 1.09 that way)."""
+    half = model_dtype is not None
+    head, xin = (2.0, 2.0) if half else (4.0, 4.0)
+    m_b = {"bits": 0.125, "u8": 1.0}.get(mask_format, 4.0)
+    every = 8.0 + 8.0 + xin + 2 * head + 4.0 + m_b            # x_t, C in; x_t, C out; x_in out; two heads; y; mask
+    region_aware = mask_format == "bits" and n_el > 512 * 1024 and not every_stream
+    required = every
+    known_frac = None
+    if mask_np is not None:
+        known_frac = float(np.count_nonzero(np.asarray(mask_np) > 0.5)) / float(np.asarray(mask_np).size)
+        if region_aware:
+            required = 8.0 + 8.0 + xin + m_b + (1.0 - known_frac) * head + known_frac * (head + 4.0)
+    return {"every_stream": every * n_el, "required": required * n_el, "bytes_per_element_every_stream": every,
+            "bytes_per_element_required": required, "known_fraction": known_frac, "region_aware_launch": region_aware}
+
+
+def roofline_fields(bytes_alg, duration_us, traffic, bytes_every_stream=None):
+    """The bandwidth statement of one launch.  `bytes_alg`: the algorithmic bytes the launch has to move
+    (steady_bytes_per_launch's `required`); `achieved` / `frac` = that / duration -- at most the rate the bytes really moved
+    at, so a fraction of peak.  `frac_every_stream`: the same duration against SURVEY.md 8(d)'s every-operand figure (can
+    exceed what HBM delivers when the kernel skips streams; quoted for comparison with earlier rounds, never as `frac`).
+    `frac_counter`: min(algorithmic, PMC-measured) bytes / duration."""
     achieved = bytes_alg / (duration_us * 1e-6) / 1e9
     moved = min(bytes_alg, traffic) if traffic else None
     counter = (moved / (duration_us * 1e-6) / 1e9) if moved else None
+    every = (bytes_every_stream / (duration_us * 1e-6) / 1e9) if bytes_every_stream else None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "frac_algorithmic": achieved / HBM_PEAK_GBPS, "frac_counter": (counter / HBM_PEAK_GBPS) if counter else None,
+            "frac_every_stream": (every / HBM_PEAK_GBPS) if every else None, "every_stream_GBps": every,
+            "every_stream_bytes_per_launch": bytes_every_stream,
             "counter_side_GBps": counter, "frac_counter_vs_6290": (counter / 6290.0) if counter else None,
-            "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg, "duration_used_us": duration_us}
+            "traffic": traffic,
+            "traffic_source": "committed_constant: profiles/r*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                              "of the same launch on another box), not a live counter of this run" if traffic else None,
+            "algorithmic_bytes_per_launch": bytes_alg, "duration_used_us": duration_us}
 
 
 def steady_kernel_name(workload, rng, mask_format):
@@ -644,7 +726,8 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
         lib.lp_timer_destroy(t)
     durs = np.asarray(durs)
     n_el = x0.numel()
-    bytes_per_launch = BYTES_PER_EL_STEADY * n_el
+    nbytes = steady_bytes_per_launch(make_mask(tuple(x0.shape), MASK_KIND), args.mask_format, n_el)
+    bytes_per_launch = nbytes["required"]
     burst_us = graph_burst_us_per_launch(_cabi, args.workload, x0.device)
     # The timed region replays hipGraphs, inside which per-dispatch events cannot be recorded, and the eager
     # replay above leaves the GPU idle between dispatches (host-paced), which stretches each dispatch (7.8 us vs
@@ -652,8 +735,15 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
     # rocprofv3 -- is the same event pair per dispatch with the launches back to back: that one is `achieved`.
     if not busy or "error" in busy:
         busy = measure_hbm_bound_shape(_cabi, x0.device, workload=args.workload, launches=120)
-    out = roofline_fields(bytes_per_launch, busy["mean_launch_us"], pmc_traffic(args.workload))
+    out = roofline_fields(bytes_per_launch, busy["mean_launch_us"], pmc_traffic(args.workload), nbytes["every_stream"])
+    prof = committed_profile(args.workload)
+    rp_us = prof.get("rocprofv3_mean_launch_us")
     out.update({
+        "bytes_model": nbytes,
+        # the same bytes over the rocprofv3 --kernel-trace mean per dispatch committed under profiles/ (another box, under
+        # the profiler), printed beside the live figure so that nobody has to recompute it
+        "frac_rocprofv3": (bytes_per_launch / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if rp_us else None,
+        "frac_every_stream_rocprofv3": (nbytes["every_stream"] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if rp_us else None,
         "regime": busy.get("regime"),
         "note": "latency-bound shape: 2.4 MB per launch is cache resident, the dispatch is launch latency "
                 "(see roofline_hbm_bound_shape / roofline_hbm_past_l3 for the bandwidth-bound regime)"
@@ -665,10 +755,10 @@ def measure_roofline(engine, _cabi, x0, y, noise, mask, sig_list, times_list, ra
         "kernel": steady_kernel_name(args.workload, "philox", args.mask_format),
         "kernel_rng": "philox (the roofline launches are the Philox2x32 variant of the step kernel whatever --rng the "
                       "timed region ran with)",
-        "storage": "fp32 x_t, C, x0, x0_BIG, y, x_in; mask 1 bit / element",
+        "storage": "fp32 x_t, C, x0, x0_BIG, y, x_in; mask: " + {"bits": "1 bit", "u8": "1 byte"}.get(args.mask_format, "4 bytes (fp32)") + " / element",
         "mean_launch_us": busy["mean_launch_us"], "median_launch_us": busy["median_launch_us"],
         "min_launch_us": busy["min_launch_us"], "launches_timed": busy["launches_timed"], "warm_burst_s": busy.get("warm_burst_s"),
-        "committed_profile": committed_profile(args.workload),
+        "committed_profile": prof,
         "timer": "hipExtLaunchKernelGGL start/stop events per dispatch (kernel begin->end) on the launch stream, THIS run; "
                  "mean over back-to-back launches of the steady kernel on buffers of this workload's shape after a warm burst "
                  "of the same launch"})
@@ -847,15 +937,16 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=100, every_s
     st = torch.cuda.current_stream(dev).cuda_stream
     warmed = warm_burst(lib, d, st, dev, warm_s)
     durs = timed_burst(_cabi, lib, d, st, dev, launches)
-    bytes_per_el = BYTES_PER_EL_STEADY if model_dtype is None else BYTES_PER_EL_STEADY - 6     # bf16 x0, x0_BIG in, x_in out
-    bytes_per_launch = bytes_per_el * n_el
     shape = WORKLOADS[workload][0]
+    nbytes = steady_bytes_per_launch(make_mask(shape, MASK_KIND), MASK_FORMAT, n_el, every_stream=every_stream,
+                                     model_dtype=model_dtype)
+    bytes_per_launch = nbytes["required"]
     del keep
     prof_key = workload + ("_every_stream" if every_stream else "") + ("_bf16" if model_dtype is not None else "")
     event_us = float(durs.mean()) * 1e6
     working_set, regime = shape_regime(n_el)
-    out = roofline_fields(bytes_per_launch, event_us, pmc_traffic(prof_key))
-    out.update({"workload": f"{workload}: latent {'x'.join(map(str, shape))}, steady-state lp_step back to back"
+    out = roofline_fields(bytes_per_launch, event_us, pmc_traffic(prof_key), nbytes["every_stream"])
+    out.update({"bytes_model": nbytes, "workload": f"{workload}: latent {'x'.join(map(str, shape))}, steady-state lp_step back to back"
                             + (", every operand streamed (LP_FL_NO_REGION_SKIP)" if every_stream else "")
                             + (", bf16 heads in / bf16 x_in out" if model_dtype is not None else ""),
                 "regime": regime, "working_set_bytes": working_set, "frac_vs_6290": out["achieved"] / 6290.0,
@@ -890,7 +981,8 @@ def measure_past_l3(_cabi, dev, workload="x_wan_b16", launches=100, warm_s=0.3, 
     for key in ("every_stream", "region_aware"):
         r, m = res[key], res[key]["last"]
         ev, gb = float(np.mean(r["event_mean_us"])), float(np.mean(r["graph_burst_us"]))
-        blk = roofline_fields(m["algorithmic_bytes_per_launch"], ev, m["traffic"])
+        blk = roofline_fields(m["algorithmic_bytes_per_launch"], ev, m["traffic"], m["every_stream_bytes_per_launch"])
+        blk["bytes_model"] = m["bytes_model"]
         blk.update({"event_mean_us_per_round": r["event_mean_us"], "graph_burst_us_per_round": r["graph_burst_us"],
                     "event_mean_us": ev, "graph_burst_us_per_launch": gb,
                     "rocprofv3_mean_launch_us": m["committed_profile"]["rocprofv3_mean_launch_us"],
@@ -902,9 +994,9 @@ def measure_past_l3(_cabi, dev, workload="x_wan_b16", launches=100, warm_s=0.3, 
             out.update(blk)
             out["mean_launch_us"] = ev
         else:
-            blk["note"] = ("same launch with the wave-uniform stream skipping on (the default): fewer bytes than the algorithmic "
-                           "36 B / element have to move, so `frac_algorithmic` can exceed what HBM delivers; `frac_counter` "
-                           "(PMC bytes / duration) is the bandwidth fraction")
+            blk["note"] = ("same launch with the wave-uniform stream skipping on (the default): `frac` is on the bytes this mask "
+                           "requires (bytes_model.required), `frac_every_stream` on the every-operand figure the launch no longer "
+                           "has to move, `frac_counter` on the PMC bytes")
             out["region_aware_streams"] = blk
     out["interleaved"] = f"{rounds} rounds of [every-stream events, every-stream graph burst, region-aware events, region-aware graph burst]"
     return out
@@ -1254,6 +1346,111 @@ def cpu_baseline(workload, budget_s):
     return out
 
 
+def reference_gpu_eager(workload, dev, product_it_s, budget_s=20.0, passes=5):
+    """The UNMODIFIED reference engine (oracle/_ref) driven over the same schedule ON THIS GPU -- the same eager ATen
+    launches (~164 per think iteration, its own torch.randn_like draws, one host sync per iteration) a ComfyUI user of the
+    reference gets on this device -- so that the line carries product vs reference on the SAME device next to product vs
+    CPU.  Same stub backbone object type, same inputs, fp32; one pass discarded, median of `passes`, each bracketed by
+    torch.cuda.synchronize(); outside the timed region of the headline.  Bounded like cpu_baseline: when the passes would
+    not fit `budget_s` the sample is the first sigma calls of the schedule, and says so."""
+    from oracle import ref_engine
+    ref_cls = ref_engine.load_reference()
+    if ref_cls is None:
+        return {"error": "oracle/_ref is not staged in this checkout (built from /root/reference by __graft_entry__.build())"}
+    import warnings
+    warnings.filterwarnings("ignore", message="In CUDA autocast")
+    warnings.filterwarnings("ignore", message=".*autocast.*")
+    shape, flow, n_sig, n_think = WORKLOADS[workload]
+    sig_np = flow_sigmas(n_sig) if flow else karras_sigmas(n_sig)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), 0, dev, tt)
+    sig_list = [torch.full((shape[0],), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+    times_list = [times_from_sigma(s, flow) for s in sig_list]
+    ratios = euler_ratios(sig_list, len(shape))
+    eng = ref_cls(StubBackbone(flow), n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
+                  IS_FLUX=False, IS_FLOW=flow, MinStepFrac=HYPER["MinStepFrac"])
+
+    def one_pass(n_s):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        xl = schedule_pass(eng, x0, y, noise, mask, sig_list[:n_s], times_list[:n_s], ratios[:max(0, n_s - 1)], n_think)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, xl
+
+    state = torch.cuda.get_rng_state(dev)
+    try:
+        torch.manual_seed(0)
+        per_sigma, _ = one_pass(1)
+        per_sigma = min(per_sigma, one_pass(1)[0])
+        n_s = n_sig if (passes + 1) * n_sig * per_sigma <= budget_s else max(1, int(budget_s / ((passes + 1) * per_sigma)))
+        one_pass(n_s)                                         # discarded
+        vals, xl = [], None
+        for _ in range(passes):
+            dt, xl = one_pass(n_s)
+            vals.append(n_s * n_think / dt)
+        finite = bool(torch.isfinite(xl).all())
+    finally:
+        torch.cuda.set_rng_state(state, dev)
+    med = float(np.median(vals))
+    m = ref_engine.manifest() or {}
+    return {"value": med, "unit": "think-iterations/s", "min_it_s": min(vals), "max_it_s": max(vals), "passes": len(vals),
+            "sigma_calls_per_pass": n_s, "ms_per_sigma_call": 1e3 * n_think / med, "finite": finite,
+            "device": torch.cuda.get_device_name(dev), "dtype": "f32", "launch": "eager ATen launches (the reference has no other mode)",
+            "product_over_reference_same_gpu": (product_it_s / med) if (product_it_s and med > 0) else None,
+            "reference_source_sha256": {k: v.get("source_sha256") for k, v in m.get("modules", {}).items()},
+            "sample": f"{'whole passes' if n_s == n_sig else f'the first {n_s} sigma calls'} of the {workload} schedule ({n_sig} sigmas x "
+                      f"{n_think}), stub backbone, the UNMODIFIED reference engine (oracle/_ref) on {dev}; one pass discarded, "
+                      f"median of {len(vals)}"}
+
+
+def gpu_clocks(dev_index):
+    """Current shader / memory clock of the device (MHz) as the driver reports them in sysfs (pp_dpm_sclk / pp_dpm_mclk: the
+    line marked '*'), best effort; None where the files are not readable."""
+    bdf = _pci_bus_id(dev_index)
+    out = {}
+    for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        try:
+            for ln in open(f"/sys/bus/pci/devices/{bdf}/{name}"):
+                if ln.rstrip().endswith("*"):
+                    out[key] = int(re.search(r"(\d+)\s*Mhz", ln, flags=re.I).group(1))
+        except Exception:
+            pass
+    if not out:
+        try:
+            out["sclk_mhz"] = int(torch.cuda.clock_rate(dev_index))
+        except Exception:
+            pass
+    return out or None
+
+
+def rccl_single_rank_selftest(timeout_s=150):
+    """First contact with RCCL at N = 1: a CHILD process brings up a ONE-rank "nccl" process group on this
+    GPU and pushes a job through the very functions the N > 1 path uses -- lanpaint_amd.distributed.broadcast_job
+    (broadcast_object_list + ONE packed uint8 device broadcast), reduce_throughput (two fp64 device all-reduces) and
+    gather_rank_reports (all_gather_object) -- and checks the tensors come back byte-identical.  In a child with a time limit so
+    that a library fault can never cost the headline line."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run([sys.executable, "-c",
+                            "import sys, json; sys.path.insert(0, %r); from lanpaint_amd import distributed as d; "
+                            "print(json.dumps(d.single_rank_selftest()))" % ROOT],
+                           env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"ok": False, "error": f"child exited {p.returncode}", "stderr_tail": p.stderr[-600:]}
+        out = json.loads(lines[-1])
+        out["wall_s"] = time.perf_counter() - t0
+        return out
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "error": f"no answer within {timeout_s} s"}
+    except Exception as e:
+        return {"ok": False, "error": repr(e)}
+
+
 _LINE_FD = None
 
 
@@ -1367,6 +1564,8 @@ def main():
                     help="with --dist-backend nccl on a box with fewer GPUs than ranks: carry the ranks over gloo instead of "
                          "exiting with an error (a rehearsal of the multi-rank path, not a scaling measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rccl-selftest", action="store_true",
+                    help="N = 1: skip the one-rank RCCL group that exercises the collectives of the N > 1 path in a child process")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the schedule pass against the CPU oracle that precedes the timed region")
     ap.add_argument("--parity-sigmas", type=int, default=0,

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 17
+#define LP_ABI_VERSION 18
 
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
@@ -557,17 +557,31 @@ int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, in
  * (torch.inference_mode), where the reference recomputes the mask on every call anyway (nodes.py:277-283).             */
 int lp_pack_mask_latent(const float* mask, int64_t n_el, uint32_t flags, void* bits, float* latent_out, void* stream);
 
+/* ATen's nearest-exact source-index rules (F.interpolate(mode="nearest-exact"): nodes.py:78,88,110,125-127,1079,1278-1287).
+ * "Bit-exact mask index math" means the rule of the kernel torch runs on the device the REFERENCE holds the mask on -- the
+ * reference resamples before `.to(device)` (nodes.py:159-160), i.e. on the CPU tensor ComfyUI hands it -- and ATen has three
+ * (every (in, out) <= 512 checked against torch 2.10 on the CPU: tests/test_oracle_properties.py); scale = float(in)/float(out):
+ *   SCALAR           min(int(floorf((i + 0.5f) * scale)), in-1): torch's GPU kernels; CPU 2-D kernel when out_h + out_w <= 128;
+ *                    CPU channels-last kernels with > 3 channels
+ *   CPU_GENERIC_FMA  s = max(fmaf(scale, i + 0.5f, -0.5f), 0); min(int(floorf(float(double(s) + 0.5))), in-1): the CPU's
+ *                    TensorIterator kernel (1-D, 3-D, 2-D with out_h + out_w > 128) as its AVX2 / AVX512 builds contract it
+ *   CPU_GENERIC      the same with product and subtraction rounded separately (a CPU without FMA: ATEN_CPU_CAPABILITY=default)
+ * The three agree on every down-sampling pair (pixel mask -> latent grid); up-sampling they differ on ties (2 -> 41, i = 20). */
+#define LP_NN_ATEN_SCALAR          0
+#define LP_NN_ATEN_CPU_GENERIC_FMA 1
+#define LP_NN_ATEN_CPU_GENERIC     2
+#define LP_RESHAPE_BINARIZE        1      /* lp_reshape_mask flags bit 0: also apply 1 - (v > 0.5) (nodes.py:281-283) */
+#define LP_RESHAPE_RULE_SHIFT      8      /* lp_reshape_mask flags bits 8..9: one of LP_NN_ATEN_*                      */
+
 /* K5  mask preparation (nodes.py:59-133); index math bit-for-bit with torch's nearest-exact.
  * dst[b][c][f][h][w] = max over the temporal window (video: 5 taps, -inf pad;
- * else 1 tap) of src[f_src(f+k)][h_src(h)][w_src(w)], with
- * idx_src(i) = min(int(floorf((i + 0.5f) * (float(in) / float(out)))), in-1)  (ATen's fp32 form of
- * F.interpolate nearest-exact, reproduced op for op),
+ * else 1 tap) of src[f_src(f+k)][h_src(h)][w_src(w)], with idx_src(i) by the LP_NN_ATEN_* rule in `flags`
+ * (0 = the scalar rule: every caller of ABI <= 17 passed 0 or 1 here),
  * with dst batch b reading src batch b % src_b and dst channel c reading src
- * channel c % src_c (the reference's repeat + slice).  `binarize`: 0 = copy value,
- * 1 = also apply 1 - (v > 0.5) (nodes.py:281-283).                              */
+ * channel c % src_c (the reference's repeat + slice).  `flags`: LP_RESHAPE_BINARIZE | (rule << LP_RESHAPE_RULE_SHIFT). */
 int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
                     float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
-                    int32_t temporal_taps, int32_t binarize, void* stream);
+                    int32_t temporal_taps, int32_t flags, void* stream);
 
 /* Post-decode mask blend (pixel space, once per job):
  *   m = conv2d(max_pool2d(mask, k, stride 1, pad k/2), gaussian_kernel_2d(k), pad k/2)
@@ -587,6 +601,8 @@ typedef struct lp_blend_desc {
     const float* image2;
     float*       out;                         /* [batch, height, width, channels]               */
     float*       smooth_out;                  /* optional [batch, height, width] smoothed mask  */
+    int32_t nn_rule;                          /* LP_NN_ATEN_* rule of the mask resample (ABI 18) */
+    int32_t reserved0;
 } lp_blend_desc;
 int lp_mask_blend(const lp_blend_desc* desc, void* stream);
 

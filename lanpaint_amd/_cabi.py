@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -37,6 +37,8 @@ def mask_bits_bytes(n_el: int) -> int:
     return ((int(n_el) + 63) // 64) * 8
 LP_REPLACE_KNOWN, LP_REPLACE_VE, LP_REPLACE_FLOW = 0, 1, 2
 LP_RNG_PHILOX, LP_RNG_TORCH = 0, 1
+LP_NN_ATEN_SCALAR, LP_NN_ATEN_CPU_GENERIC_FMA, LP_NN_ATEN_CPU_GENERIC = 0, 1, 2     # nearest-exact source-index rules
+LP_RESHAPE_BINARIZE, LP_RESHAPE_RULE_SHIFT = 1, 8
 
 
 class LpHyper(C.Structure):
@@ -128,7 +130,7 @@ class LpBlendDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
                 ("k", C.c_int32), ("mask_batch", C.c_int32), ("mask_h", C.c_int32), ("mask_w", C.c_int32),
                 ("mask", C.c_void_p), ("image1", C.c_void_p), ("image2", C.c_void_p), ("out", C.c_void_p),
-                ("smooth_out", C.c_void_p)]
+                ("smooth_out", C.c_void_p), ("nn_rule", C.c_int32), ("reserved0", C.c_int32)]
 
 
 EXPORTS = {

@@ -12,7 +12,7 @@ import ctypes
 
 import torch
 
-from . import _cabi
+from . import _cabi, interp_rule
 
 
 def gaussian_kernel_2d(kernel_size):
@@ -30,7 +30,7 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
 
 
-def _launch(mask, image1, image2, k, want_smooth=False):
+def _launch(mask, image1, image2, k, want_smooth=False, nn_rule=0):
     if not image1.is_cuda:
         raise RuntimeError("lanpaint_amd.blend runs on a HIP device only; no CPU fallback")
     if not isinstance(k, int) or k < 1 or k > 51 or k % 2 == 0:
@@ -45,6 +45,7 @@ def _launch(mask, image1, image2, k, want_smooth=False):
     d = _cabi.LpBlendDesc()
     d.batch, d.height, d.width, d.channels, d.k = b, h, w, c, k
     d.mask_batch, d.mask_h, d.mask_w = m.shape[0], m.shape[1], m.shape[2]
+    d.nn_rule = int(nn_rule)
     d.mask, d.image1, d.image2, d.out = m.data_ptr(), i1.data_ptr(), i2.data_ptr(), out.data_ptr()
     d.smooth_out = smooth.data_ptr() if smooth is not None else None
     with torch.cuda.device(dev):
@@ -82,7 +83,10 @@ def merge_video_with_mask(orig, inpainted, mask, blend_overlap):
         raise ValueError("the mask has fewer frames than the image")
     else:
         m = m[:count]
-    return _launch(m, orig, inpainted, blend_overlap)
+    # the reference resamples a lower-resolution mask with F.interpolate on the MASK's device (nodes.py:1078-1081: a 2-D call on
+    # [F, 1, h, w]): the kernel follows the index rule of the torch kernel that call would have run
+    rule = interp_rule.rule_for(mask, m.unsqueeze(1), tuple(orig.shape[1:3]))
+    return _launch(m, orig, inpainted, blend_overlap, nn_rule=rule)
 
 
 class MaskBlend:

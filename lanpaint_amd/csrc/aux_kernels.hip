@@ -334,22 +334,16 @@ int wmse_dispatch(const float* a, const float* b, const float* mask, const float
 }
 
 // ---------------------------------------------------------------------------------
-// K5: reshape_mask (nodes.py:59-133) as an output-indexed gather.  All index math is
-// fp32 exactly as ATen's nearest-exact (UpSample.h): scale = float(in)/float(out);
-// src(i) = min(int(floorf((i + 0.5f) * scale)), in-1).  The fp32 rounding IS the reference behaviour
-// (the exact-rational index differs, e.g. in=14,out=201,i=100), so it is reproduced op for op.
+// K5: reshape_mask (nodes.py:59-133) as an output-indexed gather.  The source index is ATen's nearest-exact rule of the
+// kernel the reference's device would run (lp_common.h::nearest_exact_index: three fp32 forms; `flags` bits 8..9 choose) --
+// the fp32 rounding IS the reference behaviour (the exact-rational index differs, e.g. in=14,out=201,i=100), so each form
+// is reproduced op for op.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ int nearest_exact(int i, int in_size, int out_size) {
-#pragma clang fp contract(off)
-    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
-    const float pos = (static_cast<float>(i) + 0.5f) * scale;
-    const int s = static_cast<int>(floorf(pos));
-    return s < in_size - 1 ? s : in_size - 1;
-}
-
 __global__ __launch_bounds__(256) void lp_reshape_mask_kernel(const float* __restrict__ src, int sb, int sc, int sf,
                                                               int sh, int sw, float* __restrict__ dst, int db, int dc,
-                                                              int df, int dh, int dw, int taps, int binarize) {
+                                                              int df, int dh, int dw, int taps, int flags) {
+    const int binarize = flags & LP_RESHAPE_BINARIZE;
+    const int rule = (flags >> LP_RESHAPE_RULE_SHIFT) & 3;
     const int64_t total = static_cast<int64_t>(db) * dc * df * dh * dw;
     const int half = taps / 2;
     for (int64_t o = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; o < total;
@@ -360,13 +354,13 @@ __global__ __launch_bounds__(256) void lp_reshape_mask_kernel(const float* __res
         const int f = static_cast<int>(t % df); t /= df;
         const int c = static_cast<int>(t % dc); t /= dc;
         const int b = static_cast<int>(t);
-        const int ws = nearest_exact(w, sw, dw), hs = nearest_exact(h, sh, dh);
+        const int ws = nearest_exact_index(w, sw, dw, rule), hs = nearest_exact_index(h, sh, dh, rule);
         const int64_t plane = (static_cast<int64_t>(b % sb) * sc + (c % sc)) * sf;
         float v = -INFINITY;
         for (int k = -half; k <= half; ++k) {           // max_pool3d (5,1,1), pad (2,0,0) with -inf
             const int ff = f + k;
             if (ff < 0 || ff >= df) continue;
-            const int fs = nearest_exact(ff, sf, df);
+            const int fs = nearest_exact_index(ff, sf, df, rule);
             const float s = src[((plane + fs) * sh + hs) * sw + ws];
             v = (s > v || s != s) ? s : v;              // NaN propagates like torch's max_pool
         }
@@ -376,16 +370,19 @@ __global__ __launch_bounds__(256) void lp_reshape_mask_kernel(const float* __res
 }
 
 int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int sw, float* dst, int db, int dc, int df,
-                          int dh, int dw, int taps, int binarize, hipStream_t stream) {
+                          int dh, int dw, int taps, int flags, hipStream_t stream) {
     if (!src || !dst || sb <= 0 || sc <= 0 || sf <= 0 || sh <= 0 || sw <= 0 || db <= 0 || dc <= 0 || df <= 0 ||
         dh <= 0 || dw <= 0)
         return LP_E_INVALID;
     if (taps < 1 || (taps % 2) == 0) return LP_E_INVALID;
+    if (flags < 0 || (flags & ~(LP_RESHAPE_BINARIZE | (3 << LP_RESHAPE_RULE_SHIFT))) != 0 ||
+        ((flags >> LP_RESHAPE_RULE_SHIFT) & 3) > LP_NN_ATEN_CPU_GENERIC)
+        return LP_E_INVALID;
     const int64_t total = static_cast<int64_t>(db) * dc * df * dh * dw;
     int64_t bx = (total + 255) / 256;
     if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(lp_reshape_mask_kernel, dim3(static_cast<unsigned>(bx)), dim3(256), 0, stream, src, sb, sc, sf,
-                       sh, sw, dst, db, dc, df, dh, dw, taps, binarize);
+                       sh, sw, dst, db, dc, df, dh, dw, taps, flags);
     return hipGetLastError() == hipSuccess ? LP_OK : LP_E_LAUNCH;
 }
 

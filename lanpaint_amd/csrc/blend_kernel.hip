@@ -12,15 +12,6 @@
 
 namespace lp {
 
-// ATen's nearest-exact source index, fp32 op for op (see lp_reshape_mask_kernel)
-__device__ __forceinline__ int blend_nearest(int i, int in_size, int out_size) {
-#pragma clang fp contract(off)
-    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
-    const float pos = (static_cast<float>(i) + 0.5f) * scale;
-    const int s = static_cast<int>(floorf(pos));
-    return s < in_size - 1 ? s : in_size - 1;
-}
-
 template <int TH, int TW>
 __global__ __launch_bounds__(256) void lp_mask_blend_kernel(const lp_blend_desc d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -50,8 +41,8 @@ __global__ __launch_bounds__(256) void lp_mask_blend_kernel(const lp_blend_desc 
         const int y = y0 - 2 * R + ay, x = x0 - 2 * R + ax;
         float v = -INFINITY;                                   // max_pool2d pads with -inf
         if (y >= 0 && y < H && x >= 0 && x < W) {
-            const int sy = resample ? blend_nearest(y, d.mask_h, H) : y;
-            const int sx = resample ? blend_nearest(x, d.mask_w, W) : x;
+            const int sy = resample ? nearest_exact_index(y, d.mask_h, H, d.nn_rule) : y;
+            const int sx = resample ? nearest_exact_index(x, d.mask_w, W, d.nn_rule) : x;
             v = mplane[static_cast<int64_t>(sy) * d.mask_w + sx];
         }
         A[idx] = v;
@@ -125,6 +116,7 @@ int blend_dispatch(const lp_blend_desc* dp, hipStream_t stream) {
     if (d.k < 1 || d.k > 51 || (d.k % 2) == 0) return LP_E_INVALID;
     if (d.mask_batch != 1 && d.mask_batch != d.batch) return LP_E_INVALID;
     if (d.mask_h <= 0 || d.mask_w <= 0) return LP_E_INVALID;
+    if (d.nn_rule < LP_NN_ATEN_SCALAR || d.nn_rule > LP_NN_ATEN_CPU_GENERIC) return LP_E_INVALID;
     if (!d.out && !d.smooth_out) return LP_E_INVALID;
     if (d.out && (!d.image1 || !d.image2)) return LP_E_INVALID;
     if (d.batch > 65535 || (d.height + 7) / 8 > 65535) return LP_E_UNSUPPORTED;

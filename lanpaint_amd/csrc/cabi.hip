@@ -31,7 +31,7 @@ int torch_normal_dispatch(float* out, int64_t n, uint64_t seed, uint64_t offset,
 int pack_mask_dispatch(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, float* latent_out,
                        hipStream_t stream);
 int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int sw, float* dst, int db, int dc, int df,
-                          int dh, int dw, int taps, int binarize, hipStream_t stream);
+                          int dh, int dw, int taps, int flags, hipStream_t stream);
 }  // namespace lp
 
 static inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
@@ -301,9 +301,9 @@ int lp_pack_mask_latent(const float* mask, int64_t n_el, uint32_t flags, void* b
 
 int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
                     float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
-                    int32_t temporal_taps, int32_t binarize, void* stream) {
+                    int32_t temporal_taps, int32_t flags, void* stream) {
     return lp::reshape_mask_dispatch(src, src_b, src_c, src_f, src_h, src_w, dst, batch, channels, dst_f, dst_h, dst_w,
-                                     temporal_taps, binarize, as_stream(stream));
+                                     temporal_taps, flags, as_stream(stream));
 }
 
 }  // extern "C"

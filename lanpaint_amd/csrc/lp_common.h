@@ -14,6 +14,34 @@ namespace lp {
 
 constexpr int kWave = 64;   // CDNA wavefront width; hard-coded per the gfx950 programming guide
 
+// ---- nearest-exact source index (nodes.py:78,88,110,125-127; 1079, 1278-1287: every F.interpolate(mode="nearest-exact")) ----
+// "bit-exact for mask index math" needs the rule of the kernel torch runs ON THE DEVICE THE REFERENCE HOLDS THE MASK ON, and ATen
+// has more than one (measured against torch 2.10 over every (in, out) <= 512, tests/test_oracle_properties.py):
+//   LP_NN_ATEN_SCALAR           min(int(floorf((i + 0.5f) * scale)), in - 1), all fp32 -- nearest_neighbor_exact_compute_source_index:
+//                               torch's GPU kernels; on the CPU the 2-D kernel with out_h + out_w <= 128 and the
+//                               channels-last kernels with more than 3 channels (cpu_upsample_nearest*);
+//   LP_NN_ATEN_CPU_GENERIC_FMA  the CPU's TensorIterator kernel (upsample_generic_Nd_kernel_impl / HelperInterpNearestExact: 1-D,
+//                               3-D, 2-D with out_h + out_w > 128): src = max(scale * (i + 0.5f) - 0.5f, 0) with the multiply-subtract
+//                               CONTRACTED to one fma (the AVX2 / AVX512 builds of that file), then floorf(float(double(src) + 0.5));
+//   LP_NN_ATEN_CPU_GENERIC      the same kernel as a CPU without FMA runs it (ATEN_CPU_CAPABILITY=default): product and
+//                               subtraction rounded separately.
+// scale = float(in) / float(out) in all three.  They agree on every DOWN-sampling pair (a pixel mask brought to a latent
+// grid); up-sampling they differ on ties -- e.g. 2 -> 41 at i = 20: the scalar rule reads source 0, the generic one source 1.
+__device__ __forceinline__ int nearest_exact_index(int i, int in_size, int out_size, int rule) {
+#pragma clang fp contract(off)
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
+    const float at = static_cast<float>(i) + 0.5f;
+    int s;
+    if (rule == LP_NN_ATEN_SCALAR) {
+        s = static_cast<int>(floorf(at * scale));
+    } else {
+        float src = (rule == LP_NN_ATEN_CPU_GENERIC_FMA) ? __builtin_fmaf(scale, at, -0.5f) : (scale * at - 0.5f);
+        src = src < 0.0f ? 0.0f : src;
+        s = static_cast<int>(floorf(static_cast<float>(static_cast<double>(src) + 0.5)));
+    }
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
 // ---- Philox2x32-10 (Salmon et al. 2011, Random123) ---------------------------------
 // Counter-based, ONE block per latent element: counter = (element index, launch sequence
 // number), key = seed folded with the high words.  The two 32-bit outputs make one

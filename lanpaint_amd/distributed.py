@@ -25,10 +25,28 @@ def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
-    """Initialise the default process group from the environment (no-op for world size 1)."""
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None, single_rank_group: bool = False) -> Tuple[int, int]:
+    """Initialise the default process group from the environment.  World size 1 is a no-op unless `single_rank_group`: then
+    a ONE-rank group is brought up on a free local port, so that the collectives below really go through the library
+    (RCCL for "nccl") instead of their no-group shortcuts -- `single_rank_selftest`, the GPU tests."""
     rank, world, local_rank = env_world()
-    if world <= 1:
+    if world <= 1 and not single_rank_group:
+        return 0, 1
+    if world <= 1 and not dist.is_initialized():
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            device = device or torch.device("cuda", torch.cuda.current_device())
+            torch.cuda.set_device(device)
+            kw["device_id"] = device
+        import datetime
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                timeout=datetime.timedelta(seconds=120), **kw)
         return 0, 1
     if not dist.is_initialized():
         if backend is None:
@@ -89,7 +107,8 @@ def broadcast_job(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0,
     single packed byte buffer (xGMI is per-link bound: one large transfer, not many small ones).
     Non-src ranks may pass None.  Returns {name: tensor} on `device` on every rank.  `stats` (optional dict) receives
     {"bytes": size of the packed buffer, "ms": wall time of the one data collective on this rank, "backend"}."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():         # no process group: nothing to share with.  (A group of ONE rank does go through the
+        # collectives -- a one-rank RCCL group is how the code path is exercised on a one-GPU box.)
         return {k: (t.to(device) if device is not None else t) for k, t in (tensors or {}).items()}
     rank = dist.get_rank(group)
     header = [_pack_header(tensors) if rank == src else None]
@@ -127,7 +146,7 @@ def broadcast_job(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0,
 
 def reduce_throughput(elapsed_s: float, units: int, device: Optional[torch.device] = None, group=None) -> Tuple[float, int]:
     """(max elapsed over ranks, total units over ranks): whole-job throughput = units / elapsed."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return float(elapsed_s), int(units)
     dev = device if (device is not None and dist.get_backend(group) == "nccl") else (
         torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
@@ -149,9 +168,9 @@ def collective_library_version() -> Optional[str]:
 
 def gather_rank_reports(report: dict, group=None) -> Optional[dict]:
     """Every rank contributes one small dict; rank 0 gets the evidence block of a multi-rank run:
-    {backend, world_size, ranks_reporting, device_per_rank, rccl_version, per_rank_it_s, per_rank}.  None at world
-    size 1 (no process group).  One object all-gather, outside any timed region."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    {backend, world_size, ranks_reporting, device_per_rank, rccl_version, per_rank_it_s, per_rank}.  None without a
+    process group.  One object all-gather, outside any timed region."""
+    if not dist.is_initialized():
         return None
     world = dist.get_world_size(group)
     reports = [None] * world
@@ -169,6 +188,58 @@ def gather_rank_reports(report: dict, group=None) -> Optional[dict]:
 def all_reduce_stop_sums(acc: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the early-stop partial sums {sum(w d^2), sum(w)} x {inpaint, ring} over the ranks that
     share one (sharded) batch, in place; identity when no process group is up."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc
+
+
+def single_rank_selftest(backend: Optional[str] = None, device_index: int = 0) -> dict:
+    """ONE rank, the real library: bring up a one-rank process group ("nccl" = RCCL when a GPU is there) and push a job of
+    SDXL-job size through every collective the N > 1 path issues -- broadcast_job (broadcast_object_list for the layout + ONE
+    packed uint8 device broadcast), reduce_throughput (fp64 device all-reduces MAX / SUM), all_reduce_stop_sums,
+    gather_rank_reports (all_gather_object) -- and compare what comes back with what went in, byte for byte.  Returns a
+    JSON-able record; destroys the group it created."""
+    import time
+    use_cuda = torch.cuda.is_available()
+    backend = backend or ("nccl" if use_cuda else "gloo")
+    dev = torch.device("cuda", device_index) if (use_cuda and backend == "nccl") else torch.device("cpu")
+    rec = {"backend": backend, "world_size": 1, "device": str(dev), "ok": False}
+    created = not dist.is_initialized()
+    t0 = time.perf_counter()
+    try:
+        init(backend, dev if dev.type == "cuda" else None, single_rank_group=True)
+        rec["init_s"] = time.perf_counter() - t0
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        job = {"mask": (torch.rand((1, 4, 128, 128), generator=g) > 0.5).float(),            # 256 KiB fp32
+               "y": torch.randn((1, 4, 128, 128), generator=g),
+               "cond": torch.randn((1, 77, 2048), generator=g).to(torch.bfloat16),           # SDXL text states
+               "pooled": torch.randn((1, 2816), generator=g).to(torch.bfloat16),
+               "odd": torch.arange(7, dtype=torch.uint8)}                                    # (keeps the 16-byte padding honest)
+        job = {k: v.to(dev) for k, v in job.items()}
+        stats: dict = {}
+        got = broadcast_job(job, src=0, device=dev, stats=stats)
+        same = all(got[k].dtype == v.dtype and got[k].shape == v.shape and
+                   torch.equal(got[k].contiguous().view(torch.uint8), v.contiguous().view(torch.uint8)) for k, v in job.items())
+        t_max, n_sum = reduce_throughput(1.25, 150, dev if dev.type == "cuda" else None)
+        acc = torch.arange(8, dtype=torch.float64, device=dev)
+        acc2 = all_reduce_stop_sums(acc.clone())
+        rep = gather_rank_reports({"rank": 0, "device": str(dev), "it_s": 1.0})
+        rec.update({"broadcast_bytes": stats.get("bytes"), "broadcast_ms": stats.get("ms"), "tensors_byte_identical": bool(same),
+                    "reduce_throughput_ok": bool(t_max == 1.25 and n_sum == 150), "all_reduce_identity_ok": bool(torch.equal(acc, acc2)),
+                    "reports_gathered": None if rep is None else rep.get("ranks_reporting"),
+                    "rccl_version": collective_library_version() if backend == "nccl" else None,
+                    "collectives": ["broadcast_object_list", "broadcast(uint8 pack)", "all_reduce(f64 MAX)", "all_reduce(f64 SUM)",
+                                    "all_reduce(f64 x8 SUM)", "all_gather_object"]})
+        rec["ok"] = bool(same and rec["reduce_throughput_ok"] and rec["all_reduce_identity_ok"] and rec["reports_gathered"] == 1
+                         and stats.get("backend") == backend)
+    except Exception as e:                                     # the record says what failed; the caller decides what that means
+        rec["error"] = repr(e)
+    finally:
+        if created and dist.is_initialized():
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    rec["total_s"] = time.perf_counter() - t0
+    return rec

@@ -26,7 +26,7 @@ from contextlib import contextmanager
 
 import torch
 
-from . import _cabi
+from . import _cabi, interp_rule
 from .blend import MaskBlend, gaussian_kernel_2d, merge_video_with_mask  # noqa: F401
 from .lanpaint import LanPaint, pack_mask, raw_stream, refresh_packed_mask, tensor_version
 from .types import FusedCFGHeads
@@ -80,27 +80,33 @@ def _hip_device(t, device=None):
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def _resample(src5, out_b, out_c, out_f, out_h, out_w, taps):
-    """One lp_reshape_mask launch: src5 is [B', C', F, H, W] fp32 on the device."""
+def _resample(src5, out_b, out_c, out_f, out_h, out_w, taps, rule=0):
+    """One lp_reshape_mask launch: src5 is [B', C', F, H, W] fp32 on the device; `rule`: the LP_NN_ATEN_* source-index rule
+    (interp_rule.rule_for: the one torch's kernel follows on the device the reference would have resampled on)."""
     lib = _cabi.load()
     sb, sc, sf, sh, sw = src5.shape
     dst = torch.empty((out_b, out_c, out_f, out_h, out_w), dtype=torch.float32, device=src5.device)
     with torch.cuda.device(src5.device):
         _cabi.check(lib.lp_reshape_mask(src5.data_ptr(), sb, sc, sf, sh, sw, dst.data_ptr(), out_b, out_c, out_f, out_h,
-                                        out_w, taps, 0, torch.cuda.current_stream(src5.device).cuda_stream),
+                                        out_w, taps, int(rule) << _cabi.LP_RESHAPE_RULE_SHIFT,
+                                        torch.cuda.current_stream(src5.device).cuda_stream),
                     "lp_reshape_mask")
     return dst
 
 
 def reshape_mask(input_mask, output_shape, video_inpainting=False, device=None):
     """nodes.py:59-133.  Nearest-exact resample to the latent grid, 5-wide temporal union for
-    video, channel / batch broadcast -- computed by one HIP launch with ATen's own fp32 index formula
-    src = min(int(floorf((i + 0.5f) * (float(in) / float(out)))), in-1)  (== F.interpolate nearest-exact).
+    video, channel / batch broadcast -- computed by one HIP launch.  The source index follows the rule of the torch kernel
+    the REFERENCE would have run for this mask: it resamples on the mask's own device before `.to(device)` (nodes.py:159-160),
+    so a host-resident mask (ComfyUI's) gets ATen's CPU rules, a device-resident one the GPU kernels' rule
+    (interp_rule.rule_for; all three forms are fp32 expressions reproduced op for op, e.g. the scalar one
+    src = min(int(floorf((i + 0.5f) * (float(in) / float(out)))), in-1)).  Bit-equal to F.interpolate on that device.
     Returns a float mask of `output_shape` on the HIP device the work ran on."""
     output_shape = tuple(int(s) for s in output_shape)
     dev = _hip_device(input_mask, device)
     m = input_mask.to(device=dev, dtype=torch.float32)
     nd_out = len(output_shape)
+    rule = None                      # of the reference's FIRST interpolate call where it makes two (the second is an identity)
 
     # ---- bring the mask to [B', C', (F), H, W] exactly as the reference's unsqueeze rules do
     if video_inpainting:                                                    # :64-73
@@ -111,8 +117,10 @@ def reshape_mask(input_mask, output_shape, video_inpainting=False, device=None):
         elif m.ndim == 2:
             m = m[None, None, None]
     elif m.ndim == 1 and nd_out == 4:                                      # :74-83 audio [F] -> tokens
+        rule = interp_rule.rule_for(input_mask, m.reshape(1, 1, -1), (output_shape[-1],))       # a 1-D interpolate call
         m = m.reshape(1, 1, 1, m.shape[0])          # rows of the (ch, T) layout all read the same 1-D mask
     elif m.ndim == 4 and nd_out == 4 and m.shape[1] == 1 and m.shape[3] == 1:   # :84-89 audio [1,1,F,1]
+        rule = interp_rule.rule_for(input_mask, m, (output_shape[-1], 1))                       # 2-D call, size (T, 1)
         m = m.permute(0, 1, 3, 2)
     elif m.ndim == 2:                                                       # :90-91
         m = m[None, None]
@@ -124,28 +132,33 @@ def reshape_mask(input_mask, output_shape, video_inpainting=False, device=None):
     if video_inpainting:                                                    # :100-122
         if m.ndim != 5:
             raise ValueError(f"video mask must resolve to 5 dims, got shape {tuple(m.shape)}")
+        rule = interp_rule.rule_for(input_mask, m, output_shape[2:])
         m = m.contiguous()
         c_out = output_shape[1] if m.shape[1] < output_shape[1] else m.shape[1]
-        return _resample(m, output_shape[0], c_out, output_shape[2], output_shape[3], output_shape[4], 5)
+        return _resample(m, output_shape[0], c_out, output_shape[2], output_shape[3], output_shape[4], 5, rule)
 
     if nd_out == 5 and m.ndim == 4:
         # ComfyUI < 0.6.0 (:124-125): the 4-D mask is resampled on (H, W) only and then hits
         # `repeat((1, C, 1, 1, 1))` on a 4-D tensor, which PREPENDS a dim.  Resample with the
         # kernel, reproduce the repeat/slice quirk with views.
         b4, c4, _, _ = m.shape
-        r = _resample(m.contiguous()[:, :, None], b4, c4, 1, output_shape[-2], output_shape[-1], 1)[:, :, 0]
+        rule = interp_rule.rule_for(input_mask, m, output_shape[-2:])
+        r = _resample(m.contiguous()[:, :, None], b4, c4, 1, output_shape[-2], output_shape[-1], 1, rule)[:, :, 0]
         if r.shape[1] < output_shape[1]:
             r = r.repeat((1, output_shape[1], 1, 1, 1))[:, :output_shape[1]]
         return _repeat_to_batch_size(r, output_shape[0])
     if m.ndim != nd_out:
         raise ValueError(f"mask of shape {tuple(input_mask.shape)} does not fit latent shape {output_shape}")
     if nd_out == 4:
+        if rule is None:
+            rule = interp_rule.rule_for(input_mask, m, output_shape[2:])
         src5 = m.contiguous()[:, :, None]
         c_out = output_shape[1] if m.shape[1] < output_shape[1] else m.shape[1]
-        return _resample(src5, output_shape[0], c_out, 1, output_shape[2], output_shape[3], 1)[:, :, 0]
+        return _resample(src5, output_shape[0], c_out, 1, output_shape[2], output_shape[3], 1, rule)[:, :, 0]
     if nd_out == 5:
+        rule = interp_rule.rule_for(input_mask, m, output_shape[2:])
         c_out = output_shape[1] if m.shape[1] < output_shape[1] else m.shape[1]
-        return _resample(m.contiguous(), output_shape[0], c_out, output_shape[2], output_shape[3], output_shape[4], 1)
+        return _resample(m.contiguous(), output_shape[0], c_out, output_shape[2], output_shape[3], output_shape[4], 1, rule)
     raise ValueError(f"unsupported latent rank {nd_out}")
 
 
@@ -839,7 +852,8 @@ def _snap_mask_nearest_exact(mask_hw, out_h, out_w):
         return mask_hw
     dev = _hip_device(mask_hw)
     src = mask_hw.to(device=dev, dtype=torch.float32).contiguous()
-    return _resample(src.reshape(1, 1, 1, *src.shape), 1, 1, 1, out_h, out_w, 1)[0, 0, 0].to(mask_hw.device)
+    rule = interp_rule.rule_for(mask_hw, src.reshape(1, 1, *src.shape), (out_h, out_w))      # nodes.py:1278-1287: 2-D call on the mask's device
+    return _resample(src.reshape(1, 1, 1, *src.shape), 1, 1, 1, out_h, out_w, 1, rule)[0, 0, 0].to(mask_hw.device)
 
 
 class LanPaint_ImageEncode:
@@ -924,7 +938,8 @@ class LanPaint_ImageDecode:
         if mask is None:
             return (img,)
         dev = _hip_device(image)
-        merged = merge_video_with_mask(image.to(dev), img.to(dev), mask.to(dev), blend_overlap)
+        # (the mask is handed over where it lives: its device decides which of torch's index rules the reference's resample followed)
+        merged = merge_video_with_mask(image.to(dev), img.to(dev), mask, blend_overlap)
         return (merged.to(image.device),)
 
 

@@ -178,25 +178,58 @@ def binarize_and_invert(denoise_mask):
 # ----------------------------------------------------------------------------
 # a17: mask preparation -- index math bit-for-bit with torch's nearest-exact
 # ----------------------------------------------------------------------------
-def nearest_exact_src_index(out_size: int, in_size: int) -> np.ndarray:
+def nearest_exact_src_index(out_size: int, in_size: int, rule: str = "scalar") -> np.ndarray:
     """Source index chosen by F.interpolate(mode="nearest-exact") for each output index
-    (nodes.py:110-114,124-127 call sites).  ATen evaluates it in FLOAT32 on every backend:
-        scale = float(in) / float(out);  src = min(int(floorf((i + 0.5f) * scale)), in - 1)
-    (aten/src/ATen/native/UpSample.h nearest_neighbor_exact_compute_source_index / nearest_exact_idx).
-    The fp32 rounding is part of the reference's behaviour: the exact-rational index
-    ((2i+1)*in)//(2*out) differs where (i+0.5)*in/out is an integer that fp32 lands just below
-    (e.g. in=14, out=201, i=100 -> 6, not 7), so the float form is restated, op for op."""
+    (nodes.py:78,88,110-114,124-127 call sites).  ATen evaluates it in FLOAT32, in one of three forms depending on the kernel
+    the call dispatches to (scale = float(in) / float(out) in all of them):
+      "scalar"       src = min(int(floorf((i + 0.5f) * scale)), in - 1)
+                     (aten/src/ATen/native/UpSample.h nearest_neighbor_exact_compute_source_index / nearest_exact_idx:
+                     torch's GPU kernels; CPU: the 2-D kernel when out_h + out_w <= 128, channels-last with > 3 channels)
+      "generic_fma"  s = max(fma(scale, i + 0.5f, -0.5f), 0);  src = min(int(floorf(float(double(s) + 0.5))), in - 1)
+                     (aten/src/ATen/native/cpu/UpSampleKernel.cpp HelperInterpNearestExact -- the CPU's TensorIterator kernel:
+                     1-D, 3-D, 2-D with out_h + out_w > 128 -- as its AVX2 / AVX512 builds contract the multiply-subtract)
+      "generic"      the same with product and subtraction rounded separately (ATEN_CPU_CAPABILITY=default).
+    The fp32 rounding is part of the reference's behaviour: the exact-rational index ((2i+1)*in)//(2*out) differs where
+    (i+0.5)*in/out is an integer that fp32 lands just below (e.g. in=14, out=201, i=100 -> 6, not 7, by the scalar rule), and
+    the three forms differ from each other on such ties when UP-sampling (2 -> 41 at i = 20: scalar 0, generic_fma 1);
+    on every down-sampling pair they agree.  Each is restated op for op."""
     scale = np.float32(in_size) / np.float32(out_size)
-    pos = (np.arange(out_size, dtype=np.float32) + np.float32(0.5)) * scale
-    return np.minimum(np.floor(pos).astype(np.int64), in_size - 1)
+    at = np.arange(out_size, dtype=np.float32) + np.float32(0.5)
+    if rule == "scalar":
+        return np.minimum(np.floor(at * scale).astype(np.int64), in_size - 1)
+    if rule == "generic_fma":       # one rounding: the product of two fp32 values is exact in double, and so is the - 0.5
+        src = (at.astype(np.float64) * np.float64(scale) - 0.5).astype(np.float32)
+    elif rule == "generic":
+        src = at * scale - np.float32(0.5)
+    else:
+        raise ValueError(rule)
+    src = np.where(src < 0, np.float32(0), src)
+    q = (src.astype(np.float64) + 0.5).astype(np.float32)
+    return np.minimum(np.floor(q).astype(np.int64), in_size - 1)
 
 
-def _interp_nearest_exact(a: np.ndarray, sizes: Sequence[int]) -> np.ndarray:
-    """Nearest-exact resample of the trailing len(sizes) axes of `a`."""
+def aten_nearest_exact_rule(mask_on: str, spatial_dims: int, out_sizes: Sequence[int], channels: int = 1,
+                            channels_last: bool = False, cpu_fma: bool = True) -> str:
+    """Which of the three forms one F.interpolate(mode="nearest-exact") call follows -- ATen's dispatch restated
+    (upsample_nearest_exact{1,2,3}d_kernel_impl, _use_vectorized_kernel_cond_2d): mask_on "gpu" -> scalar; "cpu":
+    channels-last with more than 3 channels -> scalar; 2-D with out_h + out_w <= 128 -> scalar; else the TensorIterator
+    kernel, contracted unless `cpu_fma` is False."""
+    if mask_on == "gpu":
+        return "scalar"
+    if channels_last and channels > 3 and spatial_dims in (2, 3):
+        return "scalar"
+    if spatial_dims == 2 and int(out_sizes[-2]) + int(out_sizes[-1]) <= 128:
+        return "scalar"
+    return "generic_fma" if cpu_fma else "generic"
+
+
+def _interp_nearest_exact(a: np.ndarray, sizes: Sequence[int], mask_on: str = "gpu", cpu_fma: bool = True) -> np.ndarray:
+    """Nearest-exact resample of the trailing len(sizes) axes of `a` ([N, C, *spatial]) as torch does it on `mask_on`."""
     nd = len(sizes)
+    rule = aten_nearest_exact_rule(mask_on, nd, sizes, a.shape[1] if a.ndim >= 2 else 1, False, cpu_fma)
     for k, out_size in enumerate(sizes):
         axis = a.ndim - nd + k
-        a = np.take(a, nearest_exact_src_index(int(out_size), a.shape[axis]), axis=axis)
+        a = np.take(a, nearest_exact_src_index(int(out_size), a.shape[axis], rule), axis=axis)
     return a
 
 
@@ -212,8 +245,10 @@ def _repeat_to_batch_size(a: np.ndarray, batch: int) -> np.ndarray:
 
 
 def reshape_mask(input_mask, output_shape: Sequence[int], video_inpainting: bool = False,
-                 comfy_060_or_newer: bool = True) -> np.ndarray:
-    """nodes.py:59-133.  numpy float32 in / out; output has `output_shape`."""
+                 comfy_060_or_newer: bool = True, mask_on: str = "gpu", cpu_fma: bool = True) -> np.ndarray:
+    """nodes.py:59-133.  numpy float32 in / out; output has `output_shape`.  `mask_on`: the device the reference holds the
+    mask on when it resamples ("cpu": ComfyUI's host tensors, nodes.py:159-160 resamples before `.to(device)`; "gpu"): torch's
+    kernels there decide the index rule (nearest_exact_src_index)."""
     m = np.asarray(input_mask, dtype=np.float32)
     output_shape = tuple(int(s) for s in output_shape)
     dims = len(output_shape) - 2
@@ -226,11 +261,11 @@ def reshape_mask(input_mask, output_shape: Sequence[int], video_inpainting: bool
             m = m[None, None, None]
     elif m.ndim == 1 and len(output_shape) == 4:                # :74-83 audio [F]
         t = output_shape[-1]
-        m = _interp_nearest_exact(m[None, None], (t,))
+        m = _interp_nearest_exact(m[None, None], (t,), mask_on, cpu_fma)
         m = np.broadcast_to(m[:, :, None, :], (1, 1, output_shape[-2], t))
     elif m.ndim == 4 and len(output_shape) == 4 and m.shape[1] == 1 and m.shape[3] == 1:   # :84-89
         t = output_shape[-1]
-        m = _interp_nearest_exact(m, (t, 1))
+        m = _interp_nearest_exact(m, (t, 1), mask_on, cpu_fma)
         m = np.broadcast_to(np.transpose(m, (0, 1, 3, 2)), (1, 1, output_shape[-2], t))
     elif m.ndim == 2:                                           # :90-91
         m = m[None, None]
@@ -241,7 +276,7 @@ def reshape_mask(input_mask, output_shape: Sequence[int], video_inpainting: bool
     if video_inpainting:                                        # :100-122
         tf = output_shape[2]
         th, tw = output_shape[-2:]
-        m = _interp_nearest_exact(m, (tf, th, tw))
+        m = _interp_nearest_exact(m, (tf, th, tw), mask_on, cpu_fma)
         # max_pool3d kernel (5,1,1) stride 1 pad (2,0,0): -inf padding
         f = m.shape[2]
         padded = np.full(m.shape[:2] + (f + 4,) + m.shape[3:], -np.inf, dtype=np.float32)
@@ -255,7 +290,7 @@ def reshape_mask(input_mask, output_shape: Sequence[int], video_inpainting: bool
         m = _repeat_to_batch_size(m, output_shape[0])
     else:                                                       # :123-130
         sizes = output_shape[2:] if comfy_060_or_newer else output_shape[-2:]
-        m = _interp_nearest_exact(m, sizes)
+        m = _interp_nearest_exact(m, sizes, mask_on, cpu_fma)
         if m.shape[1] < output_shape[1]:
             m = np.tile(m, (1, output_shape[1]) + (1,) * dims)[:, :output_shape[1]]
         m = _repeat_to_batch_size(m, output_shape[0])
@@ -630,8 +665,10 @@ def mask_blend(image1: np.ndarray, image2: np.ndarray, mask: np.ndarray, blend_o
     return (image1 * (1 - m) + image2 * m).astype(np.float32)
 
 
-def merge_video_with_mask(orig: np.ndarray, inpainted: np.ndarray, mask: np.ndarray, blend_overlap: int) -> np.ndarray:
-    """nodes.py:1060-1088."""
+def merge_video_with_mask(orig: np.ndarray, inpainted: np.ndarray, mask: np.ndarray, blend_overlap: int,
+                          mask_on: str = "gpu", cpu_fma: bool = True) -> np.ndarray:
+    """nodes.py:1060-1088.  `mask_on`: the device the reference holds the mask on (decides torch's nearest-exact index rule
+    when a lower-resolution mask is resampled: nearest_exact_src_index)."""
     m = np.asarray(mask, dtype=np.float32)
     if m.ndim == 4:
         m = m[:, 0]
@@ -646,7 +683,7 @@ def merge_video_with_mask(orig: np.ndarray, inpainted: np.ndarray, mask: np.ndar
     else:
         m = m[:count]
     if tuple(m.shape[1:]) != tuple(orig.shape[1:3]):
-        m = _interp_nearest_exact(m, orig.shape[1:3])
+        m = _interp_nearest_exact(m[:, None], orig.shape[1:3], mask_on, cpu_fma)[:, 0]      # nodes.py:1078-1081
     sm = smooth_mask(np.ascontiguousarray(m), blend_overlap)[..., None]
     return (orig * (1 - sm) + inpainted * sm).astype(np.float32)
 

@@ -115,3 +115,22 @@ def test_self_started_ranks_fail_fast_and_loudly_without_a_gpu():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "stopping the other ranks" in p.stderr or "Error" in p.stderr or "error" in p.stderr
+
+
+@pytest.mark.timeout(180)
+def test_single_rank_group_goes_through_the_collectives():
+    """A ONE-rank process group is not a shortcut (round 5): broadcast_job, reduce_throughput, all_reduce_stop_sums and
+    gather_rank_reports issue their collectives whenever a group exists, so a one-GPU box can exercise the code path the
+    8-GPU run takes.  Here over gloo, in a child process (the GPU twin runs RCCL: tests/test_gpu_rccl_single_rank.py)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-c",
+                        "import sys, json; sys.path.insert(0, %r); from lanpaint_amd import distributed as d; "
+                        "print(json.dumps(d.single_rank_selftest(backend='gloo')))" % ROOT],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=150)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["ok"] and rec["backend"] == "gloo" and rec["tensors_byte_identical"] and rec["reports_gathered"] == 1, rec
+    assert rec["broadcast_bytes"] > 2 * 256 * 1024 + 77 * 2048 * 2 and rec["rccl_version"] is None
+    assert len(rec["collectives"]) == 6

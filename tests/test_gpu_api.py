@@ -908,3 +908,82 @@ def test_engine_packs_a_binary_fp32_mask_by_itself_on_second_sight(monkeypatch):
     x2 = tt(case["x"])
     out2 = ref(x2, *args, soft.clone(), times, None, 0)
     assert torch.equal(out1, out2) and torch.equal(x1, x2)
+
+
+# ---- mask index math against the reference's arbiter, torch on the CPU -------------------------------
+RULES = {0: "scalar", 1: "generic_fma", 2: "generic"}
+
+
+def test_reshape_mask_kernel_equals_its_python_twin_for_every_index_rule(hip_lib):
+    """lp_reshape_mask's three source-index forms (include/lanpaint_hip.h LP_NN_ATEN_*) against the oracle's numpy twins
+    (which the CPU suite pins to torch-CPU over every (in, out) <= 512), through the C ABI: down- and up-sampling pairs,
+    every tie pair where the forms differ, on each of the three axes."""
+    import torch
+    from lanpaint_amd import _cabi
+    from oracle import lanpaint_oracle as orc
+    pairs = [(a, b) for a in (1, 2, 3, 4, 6, 7, 14, 54, 124, 259) for b in (1, 2, 5, 37, 41, 47, 83, 97, 123, 141, 201, 260, 519)]
+    pairs += [(a, b) for a in range(1, 260) for b in range(a + 1, 520)
+              if not np.array_equal(orc.nearest_exact_src_index(b, a, "scalar"), orc.nearest_exact_src_index(b, a, "generic_fma"))][:120]
+    st = torch.cuda.current_stream().cuda_stream
+    for rule, name in RULES.items():
+        for axis in range(3):
+            for a, b in pairs:
+                src_shape, dst_shape = [1, 1, 1], [1, 1, 1]
+                src_shape[axis], dst_shape[axis] = a, b
+                src = torch.arange(a, dtype=torch.float32, device=DEV).reshape(1, 1, *src_shape).contiguous()
+                dst = torch.empty((1, 1, *dst_shape), dtype=torch.float32, device=DEV)
+                _cabi.check(hip_lib.lp_reshape_mask(src.data_ptr(), 1, 1, *src_shape, dst.data_ptr(), 1, 1, *dst_shape, 1,
+                                                    rule << _cabi.LP_RESHAPE_RULE_SHIFT, st))
+                want = orc.nearest_exact_src_index(b, a, name)
+                assert np.array_equal(dst.reshape(-1).cpu().numpy().astype(np.int64), want), (name, axis, a, b)
+    # an unknown rule is refused, not silently mapped
+    src, dst = torch.zeros(4, device=DEV), torch.zeros(4, device=DEV)
+    assert hip_lib.lp_reshape_mask(src.data_ptr(), 1, 1, 1, 1, 4, dst.data_ptr(), 1, 1, 1, 1, 4, 1, 3 << 8, st) == _cabi.LP_E_INVALID
+
+
+def test_reshape_mask_of_a_host_mask_equals_torch_cpu_interpolate_when_upsampling():
+    """The reference resamples on the mask's own device BEFORE `.to(device)` (nodes.py:159-160): for ComfyUI's host tensors
+    that is torch's CPU kernels, whose index rule differs from the GPU kernels' on up-sampling ties.  lanpaint_amd.reshape_mask
+    of a HOST mask must equal the reference's torch pipeline run on the host, bit for bit -- audio [F] -> tokens (1-D call),
+    [1, 1, F, 1] (2-D call), low-resolution image masks (2-D, both dispatch regimes), a low-resolution video mask (3-D) --
+    and of a DEVICE mask torch's GPU kernels."""
+    import torch
+    from lanpaint_amd.nodes import reshape_mask
+    interp = torch.nn.functional.interpolate
+    g = torch.Generator().manual_seed(3)
+    for f, t in [(2, 41), (2, 47), (4, 82), (6, 123), (54, 259), (14, 201), (100, 40), (7, 300), (2, 141)]:
+        a = torch.rand(f, generator=g)
+        want = interp(a[None, None], size=(t,), mode="nearest-exact").expand(1, 1, 3, t)
+        assert torch.equal(reshape_mask(a, (1, 2, 3, t)).cpu(), want.repeat(1, 2, 1, 1)), ("[F]", f, t)
+        a4 = a.reshape(1, 1, f, 1)
+        want = interp(a4, size=(t, 1), mode="nearest-exact").permute(0, 1, 3, 2).expand(1, 1, 3, t)
+        assert torch.equal(reshape_mask(a4, (1, 2, 3, t)).cpu(), want.repeat(1, 2, 1, 1)), ("[1,1,F,1]", f, t)
+        # the same masks held on the device: torch's GPU kernels are the reference there
+        want = interp(a.to(DEV)[None, None], size=(t,), mode="nearest-exact").expand(1, 1, 3, t)
+        assert torch.equal(reshape_mask(a.to(DEV), (1, 1, 3, t)), want), ("[F] on the device", f, t)
+    for (h, w), (th, tw) in [((2, 2), (41, 47)), ((2, 6), (141, 123)), ((4, 2), (82, 83)), ((54, 14), (259, 201)), ((2, 2), (64, 64)),
+                             ((2, 2), (128, 128)), ((6, 4), (123, 94))]:
+        m = torch.rand(h, w, generator=g)
+        want = interp(m[None, None], size=(th, tw), mode="nearest-exact")
+        assert torch.equal(reshape_mask(m, (1, 1, th, tw)).cpu(), want), ((h, w), (th, tw))
+        want = interp(m.to(DEV)[None, None], size=(th, tw), mode="nearest-exact")
+        assert torch.equal(reshape_mask(m.to(DEV), (1, 1, th, tw)), want), ("device", (h, w), (th, tw))
+    for (f, h, w), (tf, th, tw) in [((2, 2, 2), (41, 47, 83)), ((4, 6, 2), (82, 123, 41)), ((3, 5, 7), (21, 60, 104))]:
+        m = torch.rand(f, h, w, generator=g)
+        want = interp(m[None, None], size=(tf, th, tw), mode="nearest-exact")
+        want = torch.nn.functional.max_pool3d(want, kernel_size=(5, 1, 1), stride=(1, 1, 1), padding=(2, 0, 0))
+        assert torch.equal(reshape_mask(m, (1, 1, tf, th, tw), video_inpainting=True).cpu(), want), ((f, h, w), (tf, th, tw))
+
+
+def test_merge_video_with_a_low_resolution_host_mask_follows_torch_cpu_index_rule():
+    """nodes.py:1078-1081 resamples a lower-resolution mask on the mask's device before the blend: with k = 1 (no dilation, no
+    blur) the merge is a per-pixel select, so every pixel shows which mask element it read."""
+    import torch
+    from lanpaint_amd import blend
+    g = torch.Generator().manual_seed(5)
+    for (h, w), (H, W) in [((2, 2), (41, 141)), ((4, 6), (82, 123)), ((2, 2), (47, 47))]:
+        mask = (torch.rand(1, h, w, generator=g) > 0.5).float()
+        orig, inp = torch.zeros(1, H, W, 3), torch.ones(1, H, W, 3)
+        want = torch.nn.functional.interpolate(mask.unsqueeze(1), size=(H, W), mode="nearest-exact")[:, 0]
+        got = blend.merge_video_with_mask(orig.to(DEV), inp.to(DEV), mask, 1).cpu()
+        assert torch.equal(got[..., 0], want), ((h, w), (H, W))

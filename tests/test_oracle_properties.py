@@ -7,76 +7,129 @@ from hypothesis import given, settings, strategies as st
 from oracle import lanpaint_oracle as orc
 
 
-@settings(max_examples=300, deadline=None)
-@given(st.integers(1, 400), st.integers(1, 400))
-def test_nearest_exact_index_equals_torch(n_in, n_out):
-    """The oracle restates ATen's formula (fp32 scale, fp32 product), which torch's GPU kernels follow exactly
-    (checked on the MI355X for 8288 (in,out) pairs, all three ranks).  torch's CPU kernels deviate from their
-    own formula at a few indices where (i + 0.5) * scale lands one ulp below an integer k (they return k):
-    39 of 8288 pairs on the 1-D/3-D paths, 26 on the 2-D path, e.g. (in=2, out=47, i=23).  Anything else is a bug."""
-    src = torch.arange(n_in, dtype=torch.float32).reshape(1, 1, n_in)
-    want = torch.nn.functional.interpolate(src, size=(n_out,), mode="nearest-exact").reshape(-1).numpy().astype(np.int64)
-    got = orc.nearest_exact_src_index(n_out, n_in)
-    scale = np.float32(n_in) / np.float32(n_out)
-    for i in np.nonzero(got != want)[0]:
-        p = (np.float32(i) + np.float32(0.5)) * scale
-        k = np.float32(np.round(p))
-        assert p == np.nextafter(k, np.float32(-np.inf)) and want[i] == min(int(k), n_in - 1), (n_in, n_out, int(i))
+RULE_NAME = {0: "scalar", 1: "generic_fma", 2: "generic"}       # include/lanpaint_hip.h LP_NN_ATEN_*
 
 
-def test_nearest_exact_known_cpu_kernel_deviation_is_the_only_one():
-    """Exhaustive over a grid that contains the known deviating pairs."""
-    dev = 0
-    for n_in in (1, 2, 3, 4, 6, 7, 14, 54):
-        for n_out in range(1, 260):
-            src = torch.arange(n_in, dtype=torch.float32).reshape(1, 1, 1, n_in)
-            want = torch.nn.functional.interpolate(src, size=(1, n_out), mode="nearest-exact").reshape(-1).numpy().astype(np.int64)
-            got = orc.nearest_exact_src_index(n_out, n_in)
-            bad = np.nonzero(got != want)[0]
-            dev += len(bad)
-            scale = np.float32(n_in) / np.float32(n_out)
-            for i in bad:
-                p = (np.float32(i) + np.float32(0.5)) * scale
-                assert p == np.nextafter(np.float32(np.round(p)), np.float32(-np.inf))
-    assert dev < 40
-    assert orc.nearest_exact_src_index(201, 14)[100] == 6        # exact-rational math would say 7
+def _cpu_fma():
+    """Does this torch build's CPU TensorIterator kernel contract its multiply-subtract on this host?  (2 -> 41, output 20)"""
+    probe = torch.nn.functional.interpolate(torch.tensor([[[0.0, 1.0]]]), size=(41,), mode="nearest-exact")
+    return float(probe[0, 0, 20]) == 1.0
 
 
-def test_nearest_exact_cpu_kernels_agree_wherever_a_mask_is_brought_to_a_latent_grid():
-    """Which device's rule is "the reference"?  reshape_mask (nodes.py:59-133) runs torch's interpolate on whatever
-    device ComfyUI holds the mask on.  The formula restated here (ATen's nearest_exact_idx, followed exactly by
-    torch's GPU kernels and by lp_reshape_mask) and torch's CPU 2-D / 3-D kernels -- the ones a CPU-resident mask
-    goes through -- can only differ when UPSAMPLING from an even size <= 14 (one index per pair, where the exact
-    position is an integer).  A pixel mask is always DOWNSAMPLED to the latent grid (x8 in space, 81 -> 21 frames):
-    there the two agree on every pair, so the GPU path gives the masks the reference gives on either device."""
+def _torch_cpu_index(n_in, n_out, nd, axis=0, other_out=3, channels=1, channels_last=False):
+    """The source index torch's CPU kernel picks along one axis of an nd-dimensional nearest-exact call."""
     interp = torch.nn.functional.interpolate
+    shp, view, size = [1, channels] + [2] * nd, [1, 1] + [1] * nd, [other_out] * nd
+    shp[2 + axis], view[2 + axis], size[axis] = n_in, n_in, n_out
+    x = torch.arange(n_in, dtype=torch.float32).view(view).expand(shp).contiguous()
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
+    y = interp(x, size=tuple(size), mode="nearest-exact")
+    idx = [0, 0] + [0] * nd
+    idx[2 + axis] = slice(None)
+    return y[tuple(idx)].numpy().astype(np.int64)
 
-    def cpu2d(a, b):
-        src = torch.arange(a, dtype=torch.float32).reshape(1, 1, a, 1).expand(1, 1, a, 3).contiguous()
-        return interp(src, size=(b, 3), mode="nearest-exact")[0, 0, :, 0].numpy().astype(np.int64)
 
-    def cpu3d(a, b):
-        src = torch.arange(a, dtype=torch.float32).reshape(1, 1, a, 1, 1).expand(1, 1, a, 2, 2).contiguous()
-        return interp(src, size=(b, 2, 2), mode="nearest-exact")[0, 0, :, 0, 0].numpy().astype(np.int64)
+def test_nearest_exact_index_equals_torch_cpu_on_every_pair():
+    """torch-CPU `nearest-exact` is what the reference runs (nodes.py:110-127, 159-160: reshape_mask before
+    `.to(device)`), so it is the arbiter of "bit-exact mask index math" -- in BOTH directions.  The oracle's three index forms +
+    ATen's dispatch (aten_nearest_exact_rule) against torch on the CPU, exhaustively: 1-D every (in <= 256, out <= 512) pair;
+    2-D in both regimes of _use_vectorized_kernel_cond_2d (out_h + out_w <= 128: scalar rule; above: TensorIterator kernel);
+    3-D on each axis.  0 mismatching pairs (round 4's single fp32 form: 94 mismatching up-sampling pairs up to 512)."""
+    fma = _cpu_fma()
+    bad = []
+    for n_in in range(1, 257):                                          # 1-D: the audio [F] -> tokens path (nodes.py:78-82)
+        for n_out in range(1, 513):
+            rule = orc.aten_nearest_exact_rule("cpu", 1, (n_out,), cpu_fma=fma)
+            if not np.array_equal(orc.nearest_exact_src_index(n_out, n_in, rule), _torch_cpu_index(n_in, n_out, 1)):
+                bad.append((1, n_in, n_out))
+    assert not bad, bad[:10]
+    for n_in in list(range(1, 80)) + [124, 128, 259]:                   # 2-D: image masks; (T, 1) audio masks (nodes.py:88)
+        for n_out in range(1, 300):
+            for other in (1, 3, 128 - n_out, 129 - n_out, 200):         # both sides of the out_h + out_w = 128 boundary
+                if other < 1:
+                    continue
+                rule = orc.aten_nearest_exact_rule("cpu", 2, (n_out, other), cpu_fma=fma)
+                assert rule == ("scalar" if n_out + other <= 128 else ("generic_fma" if fma else "generic"))
+                if not np.array_equal(orc.nearest_exact_src_index(n_out, n_in, rule), _torch_cpu_index(n_in, n_out, 2, 0, other)):
+                    bad.append((2, n_in, n_out, other))
+    assert not bad, bad[:10]
+    for axis in range(3):                                               # 3-D: the video path (nodes.py:110-114)
+        for n_in in list(range(1, 40)) + [81, 121]:
+            for n_out in range(1, 200, 1 if n_in < 16 else 3):
+                rule = orc.aten_nearest_exact_rule("cpu", 3, (n_out, 3, 3), cpu_fma=fma)
+                if not np.array_equal(orc.nearest_exact_src_index(n_out, n_in, rule), _torch_cpu_index(n_in, n_out, 3, axis)):
+                    bad.append((3, axis, n_in, n_out))
+    assert not bad, bad[:10]
+    # channels-last inputs with more than 3 channels go to the scalar-rule kernels whatever the output size
+    for nd, cl_c, want in ((2, 4, "scalar"), (2, 3, None), (3, 8, "scalar"), (3, 1, None)):
+        rule = orc.aten_nearest_exact_rule("cpu", nd, (141, 3) if nd == 2 else (41, 3, 3), cl_c, True, fma)
+        assert want is None or rule == want
+        n_in, n_out = (2, 141) if nd == 2 else (2, 41)
+        assert np.array_equal(orc.nearest_exact_src_index(n_out, n_in, rule), _torch_cpu_index(n_in, n_out, nd, 0, 3, cl_c, True))
+    assert orc.nearest_exact_src_index(201, 14)[100] == 6               # exact-rational math would say 7
+    assert orc.nearest_exact_src_index(41, 2, "scalar")[20] == 0 and orc.nearest_exact_src_index(41, 2, "generic_fma")[20] == 1
+    assert orc.nearest_exact_src_index(41, 2, "generic")[20] == 0
 
-    # every downsampling pair up to 96, and the pixel sizes of real workflows down to any latent size
-    pairs = [(a, b) for a in range(1, 97) for b in range(1, a + 1)]
-    pairs += [(a, b) for a in (81, 121, 124, 480, 512, 720, 832, 864, 1024, 2048) for b in range(1, a // 4 + 1, 3)]
-    for a, b in pairs:
-        want = orc.nearest_exact_src_index(b, a)
-        assert np.array_equal(cpu2d(a, b), want) and np.array_equal(cpu3d(a, b), want), (a, b)
-    # upsampling: the deviation exists, and only from small even sizes
-    dev = set()
-    for a in range(1, 40):
-        for b in range(a + 1, 200):
-            want = orc.nearest_exact_src_index(b, a)
-            for got in (cpu2d(a, b), cpu3d(a, b)):
-                bad = np.nonzero(got != want)[0]
-                assert len(bad) <= 1
-                if len(bad):
-                    dev.add(a)
-                    assert (int(bad[0]) + 0.5) * a / b == float(got[bad[0]])    # torch-CPU returns the exact integer position
-    assert dev and dev <= {2, 4, 6, 8, 10, 12, 14}
+
+def test_the_three_index_rules_agree_wherever_a_mask_is_brought_down_to_a_latent_grid():
+    """Every DOWN-sampling pair up to 512 (pixel mask -> latent grid: x8 in space, 81 -> 21 frames): the three forms give
+    the same indices, so the production masks were already the reference's on either device; up-sampling they differ on
+    94 (scalar vs contracted) of the 130 816 pairs."""
+    differ_up = 0
+    for n_in in range(1, 513):
+        for n_out in range(1, 513):
+            a = orc.nearest_exact_src_index(n_out, n_in, "scalar")
+            b = orc.nearest_exact_src_index(n_out, n_in, "generic_fma")
+            if n_out <= n_in:
+                assert np.array_equal(a, b) and np.array_equal(a, orc.nearest_exact_src_index(n_out, n_in, "generic")), (n_in, n_out)
+            elif not np.array_equal(a, b):
+                differ_up += 1
+    assert differ_up == 94
+
+
+def test_product_rule_dispatch_is_the_oracles_and_torchs():
+    """lanpaint_amd.interp_rule (what the HIP launch is told) == the oracle's restatement of ATen's dispatch == torch on the CPU,
+    on the tensors the reference's call sites build (host masks; a CUDA mask always takes the GPU kernels' scalar rule)."""
+    from lanpaint_amd import interp_rule as ir
+    fma = _cpu_fma()
+    assert RULE_NAME[ir.cpu_generic_rule()] == ("generic_fma" if fma else "generic")
+    host = torch.zeros(3)
+    cases = [(torch.zeros(1, 1, 7), (41,)), (torch.zeros(1, 1, 7, 1), (41, 1)), (torch.zeros(1, 1, 7, 1), (200, 1)),
+             (torch.zeros(2, 1, 30, 30), (64, 64)), (torch.zeros(2, 1, 30, 30), (128, 128)), (torch.zeros(1, 1, 5, 9, 9), (21, 60, 104)),
+             (torch.zeros(1, 8, 6, 6).contiguous(memory_format=torch.channels_last), (100, 100)),
+             (torch.zeros(1, 3, 6, 6).contiguous(memory_format=torch.channels_last), (100, 100))]
+    for view, size in cases:
+        nd = len(size)
+        cl = nd in (2, 3) and view.shape[1] > 3 and view.is_contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
+        want = orc.aten_nearest_exact_rule("cpu", nd, size, view.shape[1], cl, fma)
+        assert RULE_NAME[ir.rule_for(host, view, size)] == want, (tuple(view.shape), size)
+        n_in = view.shape[2]
+        src = torch.arange(n_in, dtype=torch.float32).view([1, 1, n_in] + [1] * (nd - 1)).expand(view.shape).contiguous()
+        if cl:
+            src = src.contiguous(memory_format=torch.channels_last)
+        got = torch.nn.functional.interpolate(src, size=size, mode="nearest-exact")
+        idx = got[(0, 0, slice(None)) + (0,) * (nd - 1)].numpy().astype(np.int64)
+        assert np.array_equal(idx, orc.nearest_exact_src_index(size[0], n_in, want)), (tuple(view.shape), size)
+    assert ir.aten_rule(True, 1, (41,)) == 0 and ir.aten_rule(True, 3, (21, 60, 104)) == 0
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 40), st.integers(1, 300), st.integers(1, 6), st.integers(0, 2 ** 31 - 1))
+def test_reshape_mask_audio_upsampling_equals_torch_cpu_pipeline(f, t, ch, seed):
+    """The reference's audio paths -- [F] -> tokens (1-D call) and [1, 1, F, 1] (2-D call, size (T, 1)) -- UP-sample; on a host
+    mask the oracle must give what torch's CPU kernels give (nodes.py:74-89, 123-130)."""
+    rng = np.random.default_rng(seed)
+    m = rng.random(f).astype(np.float32)
+    fma = _cpu_fma()
+    interp = torch.nn.functional.interpolate
+    want = interp(torch.from_numpy(m)[None, None], size=(t,), mode="nearest-exact").expand(1, 1, ch, t)
+    want = interp(want, size=(ch, t), mode="nearest-exact")
+    assert np.array_equal(orc.reshape_mask(m, (1, 1, ch, t), mask_on="cpu", cpu_fma=fma), want.numpy())
+    m4 = torch.from_numpy(m).reshape(1, 1, f, 1)
+    want = interp(m4, size=(t, 1), mode="nearest-exact").permute(0, 1, 3, 2).expand(1, 1, ch, t)
+    want = interp(want, size=(ch, t), mode="nearest-exact")
+    assert np.array_equal(orc.reshape_mask(m4.numpy(), (1, 1, ch, t), mask_on="cpu", cpu_fma=fma), want.numpy())
 
 
 @settings(max_examples=40, deadline=None)
