@@ -552,7 +552,7 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
  * input value is neither 0 nor 1 (soft mask: the packed form would not be equivalent).             */
 int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream);
 /* Same launch, which also writes the fp32 latent_mask (1 = known; nodes.py:281-283 with LP_FL_MASK_DENOISE) to `latent_out`
- * (n_el floats; may alias `mask` when flags == 0).  One launch re-derives BOTH forms of a mask whose tensor may have been
+ * (n_el floats; may be the same buffer as `mask` when flags == 0 -- the kernel declares neither pointer restrict).  One launch re-derives BOTH forms of a mask whose tensor may have been
  * rewritten in place -- what KSamplerX0Inpaint does on every sigma call for tensors that carry no version counter
  * (torch.inference_mode), where the reference recomputes the mask on every call anyway (nodes.py:277-283).             */
 int lp_pack_mask_latent(const float* mask, int64_t n_el, uint32_t flags, void* bits, float* latent_out, void* stream);

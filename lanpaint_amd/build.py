@@ -54,7 +54,11 @@ def _compile(out, extra, verbose):
     # LP_RNG_TORCH to reproduce torch.randn bit for bit (csrc/lp_common.h); it also makes the arithmetic of every
     # kernel independent of what the optimiser happens to fuse.
     # -amdgpu-kernarg-preload-count: leading scalar / pointer kernel arguments arrive in SGPRs (csrc/step_kernel.hip)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared",
+    # -fhip-fp32-correctly-rounded-divide-sqrt, -fno-fast-math: hipcc's defaults, spelled out because parity rests on them --
+    # `/` and sqrtf are IEEE-rounded, and lp_common.h::div_shared equals IEEE division only while its reciprocal `1.0f / c` is
+    # correctly rounded (tests/test_gpu_kernels.py::test_shared_divisor_emit_equals_ieee_division)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fno-fast-math",
+           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared",
            "-mllvm", "-amdgpu-kernarg-preload-count=14",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     cmd += extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]

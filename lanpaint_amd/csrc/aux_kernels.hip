@@ -389,9 +389,11 @@ int reshape_mask_dispatch(const float* src, int sb, int sc, int sf, int sh, int 
 // ---------------------------------------------------------------------------------
 // bit-packed mask: one wave64 ballot turns 64 consecutive elements into one 64-bit word
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lp_pack_mask_kernel(const float* __restrict__ mask, int64_t n_el, uint32_t flags,
+// (`mask` and `latent_out` carry no __restrict__: the header allows them to be ONE buffer when flags == 0 -- an in-place
+// refresh of a mask that is its own fp32 form; every element is read and written by the same lane)
+__global__ __launch_bounds__(256) void lp_pack_mask_kernel(const float* mask, int64_t n_el, uint32_t flags,
                                                            unsigned long long* __restrict__ bits,
-                                                           int32_t* __restrict__ nonbinary, float* __restrict__ latent_out) {
+                                                           int32_t* __restrict__ nonbinary, float* latent_out) {
     const int64_t words = (n_el + 63) / 64;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;

@@ -119,7 +119,9 @@ def refresh_packed_mask(packed: torch.Tensor, source: torch.Tensor = None) -> bo
     """Bring the bit-packed copy attached to `packed` (pack_mask's return value) up to date with the tensor it was made from
     (`source`, default: the recorded one), IN PLACE -- same bits buffer, same fp32 latent mask tensor, so captured graphs and
     the engine's identity checks keep matching.  A source with a version counter is re-packed only when the counter moved;
-    an inference tensor (no counter) every time.  One launch (lp_pack_mask_latent).  Returns True when it re-packed."""
+    an inference tensor (no counter) every time.  One launch (lp_pack_mask_latent).  Returns True when it re-packed.
+    A packed mask must STAY binary: the denoise form thresholds at 0.5 by definition (nodes.py:281-283); for a mask packed from
+    its own fp32 tensor a rewrite to soft values is reported by the NEXT call (ValueError), see below."""
     rec = getattr(packed, "_lp_bits_of", None)
     bits = getattr(packed, "_lp_bits", None)
     if rec is None or bits is None:
@@ -138,7 +140,17 @@ def refresh_packed_mask(packed: torch.Tensor, source: torch.Tensor = None) -> bo
     with torch.cuda.device(src.device):
         stream = raw_stream(src.device)
         if same:
-            _cabi.check(lib.lp_pack_mask(s32.data_ptr(), s32.numel(), 0, bits.data_ptr(), None, stream), "lp_pack_mask")
+            # The caller vouched for a BINARY mask when packing it; a rewrite to soft values would be binarised at 0.5 without
+            # a word.  The re-pack raises the kernel's "values other than 0 and 1" flag straight into pinned host memory (no
+            # device -> host copy, no sync); what the PREVIOUS re-pack left there is looked at now.
+            soft = getattr(packed, "_lp_soft_flag", None)
+            if soft is None:
+                soft = packed._lp_soft_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            elif int(soft[0]) != 0:
+                soft[0] = 0
+                raise ValueError("pack_mask: the packed mask was rewritten in place to values other than 0 and 1; soft masks cannot "
+                                 "be bit-packed (hand the engine the plain fp32 mask instead)")
+            _cabi.check(lib.lp_pack_mask(s32.data_ptr(), s32.numel(), 0, bits.data_ptr(), soft.data_ptr(), stream), "lp_pack_mask")
         else:
             _cabi.check(lib.lp_pack_mask_latent(s32.data_ptr(), s32.numel(), _cabi.LP_FL_MASK_DENOISE if denoise else 0,
                                                 bits.data_ptr(), packed.data_ptr(), stream), "lp_pack_mask_latent")
@@ -147,41 +159,53 @@ def refresh_packed_mask(packed: torch.Tensor, source: torch.Tensor = None) -> bo
 
 
 def pack_indicator(indicator: torch.Tensor, shape) -> tuple:
-    """(bits, audio share) of an AV pack's stream indicator (lanpaint.py:68-73: 1 = audio element), or None when it is not a
-    0/1 tensor broadcastable to the latent -- then the reference-shaped per-element path runs.  Cached on the tensor (weak
-    identity + version; an inference tensor is re-packed on every call like a mask), one host read when first packed."""
+    """(bits, audio share, rows share equally?) of an AV pack's stream indicator (lanpaint.py:68-73: 1 = audio element), or None
+    when it is not a 0/1 tensor broadcastable to the latent -- then the reference-shaped per-element path runs.  Cached on the
+    tensor (weak identity + version), one host read when first packed.  An inference tensor has no version counter: a binary
+    one is re-packed IN PLACE on every call with the "values other than 0 and 1" flag checked (one small host read per sigma
+    call: a rewrite to soft values must not be binarised silently), a soft one is looked at again on every call.
+    The third item: the device-side stopper takes its `abt` mean from the two time rows of every batch row and ONE audio share
+    (lp_step_desc.av_frac); that equals the reference's mean over the blended abt tensor (earlystop.py:104-110) only when every
+    batch row holds the same share of audio elements -- True for pack layouts (the indicator is a broadcast [1, ...] tensor)."""
     if not indicator.is_cuda:
         return None
     ver = tensor_version(indicator)
     rec = getattr(indicator, "_lp_av", None)
-    if rec is not None and rec[2] == tuple(shape) and rec[3] == ver and ver != -1:
-        return (rec[0], rec[1]) if rec[0] is not None else None
+    if rec is not None and (rec[2] != tuple(shape) or (rec[0] is not None and rec[0].device != indicator.device)):
+        rec = None
+    if rec is not None and rec[3] == ver and ver != -1:
+        return (rec[0], rec[1], rec[4]) if rec[0] is not None else None
     try:
         full = _as_f32c(indicator if tuple(indicator.shape) == tuple(shape) else indicator.expand(shape))
     except RuntimeError:
         return None
     n = full.numel()
-    bits = rec[0] if (rec is not None and rec[2] == tuple(shape) and rec[0].device == full.device) else \
+    bits = rec[0] if (rec is not None and rec[0] is not None) else \
         torch.empty(_cabi.mask_bits_bytes(n), dtype=torch.uint8, device=full.device)
-    if rec is not None and rec[2] == tuple(shape) and ver == -1 and rec[0] is not None:
-        # no version counter: re-derive the bits in place on every call (no host read; the share of audio elements is a per-job
-        # constant of the pack layout and keeps its first value)
-        with torch.cuda.device(full.device):
-            _cabi.check(_cabi.load().lp_pack_mask(full.data_ptr(), n, 0, bits.data_ptr(), None, raw_stream(full.device)), "lp_pack_mask")
-        return bits, rec[1]
     flag = torch.zeros(1, dtype=torch.int32, device=full.device)
     with torch.cuda.device(full.device):
         _cabi.check(_cabi.load().lp_pack_mask(full.data_ptr(), n, 0, bits.data_ptr(), flag.data_ptr(), raw_stream(full.device)),
                     "lp_pack_mask")
-    frac = float(full.sum(dtype=torch.float64).item()) / n          # (the one host read; also waits for the flag)
-    if int(flag.item()):
-        indicator._lp_av = (None, 0.0, tuple(shape), ver)
-        return None
+    if rec is not None and rec[0] is not None and ver == -1:
+        # no version counter, packed before: bits re-derived in place above (captured launches bake their address); the audio
+        # share is a per-job constant of the pack layout and keeps its first value; only the flag is read
+        if int(flag.item()):
+            try:
+                indicator._lp_av = (None, 0.0, tuple(shape), ver, False)
+            except Exception:
+                pass
+            return None
+        return bits, rec[1], rec[4]
+    rows = int(shape[0]) if len(shape) else 1
+    per_row = full.reshape(rows, -1).sum(dim=1, dtype=torch.float64).cpu()        # (the one host read; also waits for the flag)
+    frac = float(per_row.sum()) / n
+    soft = bool(int(flag.item()))
+    rows_equal = bool((per_row == per_row[0]).all())
     try:
-        indicator._lp_av = (bits, frac, tuple(shape), ver)
+        indicator._lp_av = (None, 0.0, tuple(shape), ver, False) if soft else (bits, frac, tuple(shape), ver, rows_equal)
     except Exception:
         pass
-    return bits, frac
+    return None if soft else (bits, frac, rows_equal)
 
 
 def aten_randn_policy(numel: int, multi_processor_count: int, max_threads_per_multi_processor: int):
@@ -459,6 +483,14 @@ class LanPaint:
     @iterations_run.setter
     def iterations_run(self, v):
         self._iterations_run = v
+
+    def _indicator_pack(self, indicator, shape):
+        """pack_indicator once per sigma call (eligibility check, graph key and prologue all ask; an inference tensor would be
+        re-packed -- a launch and a host read -- each time)."""
+        c = getattr(self, "_av_pack", None)
+        if c is None or c[0] is not indicator or c[1] != tuple(shape):
+            c = self._av_pack = (indicator, tuple(shape), pack_indicator(indicator, shape))
+        return c[2]
 
     def _auto_pack(self, latent_mask, x):
         """A caller that hands the engine a plain fp32 mask (the reference's interface) still gets the hard-mask kernels when
@@ -799,6 +831,7 @@ class LanPaint:
         self.audio_indicator = audio_indicator
         self.current_times_audio = current_times_audio
         self.audio_correction = audio_correction
+        self._av_pack = None                     # (indicator, shape, pack_indicator's answer) of THIS call, see _indicator_pack
         self._noise_regenerated = self._noise_is_zero(noise)
         if self._noise_regenerated:              # lanpaint.py:51-52: the first draw of the call
             self.noise = self.rng(noise) if callable(self.rng) else torch.randn_like(noise)
@@ -1026,7 +1059,7 @@ class LanPaint:
             if (self.audio_indicator is None or self.current_times_audio is None or self._es_opts is not None
                     or any(t.numel() not in (1, rows) for t in self.current_times_audio)
                     or os.environ.get("LANPAINT_AMD_AV_TABLE", "1") == "0"
-                    or pack_indicator(self.audio_indicator, x.shape) is None):
+                    or self._indicator_pack(self.audio_indicator, x.shape) is None):
                 return False
         if self._es_opts is not None and (not self._es_opts["device"] or self.rng not in ("torch", "philox")):
             return False         # a custom distance_fn / a sharded batch keeps the stopper on the host; a gated loop
@@ -1111,7 +1144,10 @@ class LanPaint:
                tuple(int(t.numel()) for t in current_times), id(model_options), seed, self.rng, self._hyper_key(),
                self.model_dtype, None if self._es_opts is None else (self._es_opts["threshold"], self._es_opts["patience_eff"],
                                                                       self._es_opts["trace"] is not None),
-               None if self.audio_indicator is None else (id(self.audio_indicator), self.audio_correction is not None))
+               # (AV: the captured launches bake the address of the indicator's bit-packed copy -- that address, not the tensor's
+               # id(), which another tensor of the same shape can recycle)
+               None if self.audio_indicator is None else (self._indicator_pack(self.audio_indicator, x.shape)[0].data_ptr(),
+                                                          self.audio_correction is not None))
         cap = self._graphs.get(key)
         if cap is not None and cap.model_options is not model_options:
             del self._graphs[key]        # another dict at a recycled id(): the captured backbone calls used the old one
@@ -1421,8 +1457,11 @@ class LanPaint:
             row_sized = all(t.numel() in (1, rows) for t in (VE_Sigma, abt, sigma, Flow_t, VE_a, abt_a, Flow_a))
             host_side = self._overridden("langevin_dynamics") or self._overridden("score_model") or \
                 self._overridden("prepare_step_size") or (self._es_opts is not None and not self._es_opts["device"])
-            packed = pack_indicator(ai, shape) if (row_sized and not host_side and
-                                                   os.environ.get("LANPAINT_AMD_AV_TABLE", "1") != "0") else None
+            packed = self._indicator_pack(ai, shape) if (row_sized and not host_side and
+                                                         os.environ.get("LANPAINT_AMD_AV_TABLE", "1") != "0") else None
+            if packed is not None and self._es_opts is not None and not packed[2]:
+                packed = None        # rows with different audio shares: the device-side stopper's one `av_frac` would not give the
+                                     # reference's threshold (mean of the blended abt) -> reference-shaped path, host stopper
             if packed is not None:
                 # a 0/1 indicator and per-row times: the blend picks, per element, one of two per-row time sets exactly
                 # (x * 1 + y * 0 = x), so the kernels take the sets from a two-row table and the indicator as bits -- no

@@ -987,3 +987,24 @@ def test_merge_video_with_a_low_resolution_host_mask_follows_torch_cpu_index_rul
         want = torch.nn.functional.interpolate(mask.unsqueeze(1), size=(H, W), mode="nearest-exact")[:, 0]
         got = blend.merge_video_with_mask(orig.to(DEV), inp.to(DEV), mask, 1).cpu()
         assert torch.equal(got[..., 0], want), ((h, w), (H, W))
+
+
+def test_packed_mask_rewritten_to_soft_values_is_reported_not_binarised():
+    """refresh_packed_mask re-packs a caller-packed mask after an in-place rewrite; values other than 0 and 1 used
+    to be binarised at 0.5 in the bits AND in the fp32 copy without a word.  The re-pack now raises the kernel's flag into
+    pinned host memory and the next call reports it."""
+    import torch
+    from lanpaint_amd import pack_mask
+    from lanpaint_amd.lanpaint import refresh_packed_mask
+    m = (torch.rand((1, 4, 16, 16), device=DEV) > 0.5).float()
+    pack_mask(m)
+    m.copy_((torch.rand_like(m) > 0.3).float())                       # a binary rewrite: followed silently
+    assert refresh_packed_mask(m) is True
+    torch.cuda.synchronize()
+    assert refresh_packed_mask(m) is False                            # nothing moved since
+    m.mul_(0.25)                                                      # now soft
+    assert refresh_packed_mask(m) is True
+    torch.cuda.synchronize()
+    m.add_(0.0)                                                       # (moves the version counter: the next look re-packs)
+    with pytest.raises(ValueError, match="values other than 0 and 1"):
+        refresh_packed_mask(m)

@@ -154,3 +154,82 @@ def test_av_pack_replays_as_a_graph_bitwise_equal_to_eager_launches():
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("graph", [None, False])
+def test_soft_indicator_under_inference_mode_over_several_sigma_calls(graph):
+    """a non-0/1 indicator is cached as "soft"; under torch.inference_mode() -- how ComfyUI runs nodes --
+    tensors carry no version counter, so the cache cannot tell whether the tensor was rewritten and the next look used to
+    dereference the missing bit buffer (AttributeError inside the first sigma call: the eligibility check and the prologue
+    both ask).  Three sigma calls with the same soft indicator tensor, default launch mode and eager: the reference-shaped
+    per-element path every time, results equal to the oracle's."""
+    import torch
+    from lanpaint_amd import LanPaint
+    shape, n_steps = (1, 2, 96), 2
+    c = _case(shape, 60, seed=2)
+    c["ai"] = (c["ai"] * 0.5).astype(np.float32)
+    c["corr"] = ((1.0 - c["ai"]) + np.float32(0.7) * c["ai"]).astype(np.float32)
+    rng = np.random.default_rng(12)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(3 * (2 * n_steps - 1))]
+    it_o = iter(draws)
+    o = orc.OracleLanPaint(MODELS["linear_tuple"](flow=True), n_steps, 15.0, 5.0, 1.0, 0.2, is_flow=True, randn=lambda like: next(it_o))
+    x_o, want = c["x"].copy(), []
+    for _ in range(3):
+        want.append(o(x_o, c["y"], c["noise"], c["sigma"], c["mask"], c["times_v"], None, 0, current_times_audio=c["times_a"],
+                      audio_indicator=c["ai"], audio_correction=c["corr"]).copy())
+    with torch.inference_mode():
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+        it = iter([tt(d) for d in draws])
+        kw = {} if graph is None else {"graph": graph}
+        eng = LanPaint(MODELS["linear_tuple"](flow=True), n_steps, 15.0, 5.0, 1.0, 0.2, IS_FLOW=True, rng=lambda like: next(it), **kw)
+        x, ai, corr = tt(c["x"]), tt(c["ai"]), tt(c["corr"])
+        y, noise, mask, sigma = tt(c["y"]), tt(c["noise"]), tt(c["mask"]), tt(c["sigma"])
+        tv, ta = tuple(tt(t) for t in c["times_v"]), tuple(tt(t) for t in c["times_a"])
+        for k in range(3):
+            out = eng(x, y, noise, sigma, mask, tv, None, 0, current_times_audio=ta, audio_indicator=ai, audio_correction=corr)
+            assert eng._desc.flags & (1 << 8) and not (eng._desc.flags & (1 << 17))     # per-element path, not the table
+            assert_close(out.cpu().numpy(), want[k], f"sigma call {k}: out", rel=3e-5)
+        assert_close(x.cpu().numpy(), x_o, "x after three calls", rel=3e-5)
+
+
+def test_binary_indicator_rewritten_to_soft_values_under_inference_mode_is_noticed():
+    """A 0/1 indicator packed once and then rewritten IN PLACE to soft values while no version counter exists: the in-place
+    re-pack of every call reads the "values other than 0 and 1" flag, so the call falls back to the per-element path instead of
+    running on bits that binarise the new values at 0.5."""
+    import torch
+    from lanpaint_amd.lanpaint import pack_indicator
+    with torch.inference_mode():
+        ai = torch.zeros((1, 2, 128), device=DEV)
+        ai[..., 64:] = 1.0
+        first = pack_indicator(ai, ai.shape)
+        assert first is not None and first[1] == 0.5 and first[2] is True
+        again = pack_indicator(ai, ai.shape)
+        assert again is not None and again[0] is first[0]                 # same bit buffer, re-derived in place
+        ai.mul_(0.5)
+        assert pack_indicator(ai, ai.shape) is None
+        ai.fill_(1.0)
+        back = pack_indicator(ai, ai.shape)                                # and a later binary rewrite is taken up again
+        assert back is not None and back[1] == 1.0
+
+
+def test_rows_with_different_audio_shares_keep_the_host_stopper():
+    """the device-side stopper weights every row's (video, audio) abt pair by ONE audio share; the reference's
+    threshold is the mean of the blended abt tensor, i.e. per-row shares.  An indicator whose rows differ in their share
+    therefore takes the reference-shaped path with the host-side stopper, and matches the oracle's stopper."""
+    shape, n_steps = (2, 1, 512), 6
+    c = _case(shape, 300, seed=6, rows_differ=True)
+    c["ai"][1, :, 100:] = 1.0                                              # row 1 holds more audio elements than row 0
+    c["corr"] = ((1.0 - c["ai"]) + np.float32(0.7) * c["ai"]).astype(np.float32)
+    rng = np.random.default_rng(13)
+    draws = [rng.standard_normal(shape, dtype=np.float32) for _ in range(2 * n_steps - 1)]
+    mo_o = {"lanpaint_semantic_stop": {"threshold": 5.0, "patience": 2}}
+    mo_e = {"lanpaint_semantic_stop": {"threshold": 5.0, "patience": 2}, "lanpaint_semantic_trace": []}
+    x_o, out_o, o = _run_oracle(c, n_steps, draws, mo_o)
+    x_e, out_e, eng = _run_engine(c, n_steps, draws, mo_e)
+    assert not (eng._desc.flags & (1 << 17))                               # not the two-row table with its single share
+    assert eng.iterations_run == o.iterations_run
+    assert_close(x_e, x_o, "rows with different audio shares: x", rel=3e-5)
+    assert_close(out_e, out_o, "rows with different audio shares: out", rel=3e-5)
+    # without a stopper the table path is still taken for such an indicator (the share only enters the stop threshold)
+    _, _, eng2 = _run_engine(c, 2, draws[:3])
+    assert eng2._desc.flags & (1 << 17)

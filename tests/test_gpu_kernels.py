@@ -756,3 +756,40 @@ def test_self_closing_gated_loop_through_the_c_abi(lib, stops, n):
     assert lib.lp_step(ctypes.byref(d), st) == _cabi.LP_E_INVALID
     d.flags = base | _cabi.LP_FL_ES_GATED                                        # GATED without ES
     assert lib.lp_step(ctypes.byref(d), st) == _cabi.LP_E_INVALID
+
+
+@pytest.mark.parametrize("phase", ["steady", "last"])
+def test_shared_divisor_emit_equals_ieee_division(lib, phase):
+    """ADVICE r04: the flow-model emit `x_t / c` of the 16-byte-per-lane kernels goes through lp_common.h::div_shared (one
+    reciprocal per lane + one residual correction per element), which equals IEEE division only while `1.0f / c` is correctly
+    rounded -- a property of the build flags (pinned in lanpaint_amd/build.py: -fhip-fp32-correctly-rounded-divide-sqrt,
+    -fno-fast-math).  The one-element-per-lane kernels still divide.  Same launch, both vector widths forced through the tune
+    switches: bitwise equal x_t, C and model-space x_in on the video latent (2 M quotients per launch, flow scale c)."""
+    import torch
+    import bench
+    from lanpaint_amd import _cabi
+    dev = torch.device("cuda", 0)
+    ph = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
+          "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT}[phase]
+    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
+    bench.MASK_KIND, bench.MASK_FORMAT = "temporal", "bits"
+    try:
+        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph)
+    finally:
+        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    bufs = keep[0]
+    bufs["x_t"].mul_(37.5)                      # quotients over a few binades
+    st = torch.cuda.current_stream().cuda_stream
+    x_t0, c0 = bufs["x_t"].clone(), bufs["C"].clone()
+    res = []
+    for tune in (_cabi.LP_TUNE_VEC4, _cabi.LP_TUNE_VEC1):
+        bufs["x_t"].copy_(x_t0)
+        bufs["C"].copy_(c0)
+        bufs["x_in"].zero_()
+        d.tune, d.rng_offset = tune, 5
+        _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+        torch.cuda.synchronize()
+        res.append([bufs[k].clone() for k in ("x_t", "C", "x_in")])
+    for name, a, b in zip(("x_t", "C", "x_in"), *res):
+        assert torch.equal(a, b), name
+    assert torch.isfinite(res[0][2]).all() and not torch.equal(res[0][2], torch.zeros_like(res[0][2]))
