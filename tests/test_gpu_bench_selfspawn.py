@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _cmd(backend, gpus=2, extra=()):
     return [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dist-backend", backend, "--steps", "3",
-            "--warmup", "1", "--repeats", "1", "--prewarm-seconds", "0.05", "--cpu-seconds", "1.0", "--no-large-shape", *extra]
+            "--warmup", "1", "--repeats", "1", "--prewarm-seconds", "0.05", "--cpu-seconds", "1.0", "--no-large-shape",
+            "--parity-sigmas", "4", *extra]            # (every rank checks its own replica: keep the numpy passes short here)
 
 
 def _env():
@@ -48,7 +49,14 @@ def _check(line, backend):
     assert d["broadcast_bytes"] >= 2 * 4 * line["config"]["latent_elements_per_gpu"] and d["broadcast_ms"] > 0
     # whole-job value = all ranks' iterations / slowest rank's clock
     assert abs(line["value"] - sum(r["iterations"] for r in per) / max(r["elapsed_s"] for r in per)) / line["value"] < 0.05
-    assert line["cpu_baseline"]["value"] > 0 and line["roofline"]["frac"] > 0     # rank 0 still reports both at N > 1
+    assert line["cpu_baseline"]["value"] > 0 and 0 < line["roofline"]["frac"] <= 1     # rank 0 still reports both at N > 1
+    # round 5: every rank checked its own replica against the oracle and reports what explains a slow rank
+    assert d["parity_ok_all_ranks"] and all(r["parity_ok"] is True and r["parity_mse_x"] < 1e-9 for r in per)
+    for r in per:
+        assert r["own_elapsed_s"] <= r["elapsed_s"] and r["own_it_s"] > 0 and 0 < r["process_time_over_elapsed"] < 4
+        assert r["t_first_barrier_wait_s"] >= 0 and r["steady_launch_us"] > 0 and r["cpus_allowed"] >= 1
+        assert r["setup_s"] > 0 and r["init_process_group_s"] >= 0
+    assert d["slowest_rank"] in (0, 1) and d["own_it_s_spread"][0] <= d["own_it_s_spread"][1]
     return d
 
 
@@ -86,7 +94,8 @@ def test_bench_two_ranks_under_torch_distributed_run():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3",
-           "--warmup", "1", "--repeats", "0", "--prewarm-seconds", "0.05", "--no-cpu-baseline", "--no-large-shape"]
+           "--warmup", "1", "--repeats", "0", "--prewarm-seconds", "0.05", "--no-cpu-baseline", "--no-large-shape",
+           "--parity-sigmas", "3"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -108,7 +117,8 @@ def test_bench_eight_ranks_rehearse_the_multi_gpu_configurations_baseline_names(
     import torch
     backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
     line = _run(backend, gpus=8, timeout=1400,
-                extra=("--workload", workload, "--steps", "2", "--repeats", "0", "--no-cpu-baseline", "--extras", "0"))
+                extra=("--workload", workload, "--steps", "2", "--repeats", "0", "--no-cpu-baseline", "--extras", "0",
+                       "--parity-sigmas", "2"))
     d = line["dist"]
     assert line["n_gpus"] == 8 and d["world_size"] == d["ranks_reporting"] == 8 and line["collective"] == ("rccl" if backend == "nccl" else "gloo")
     assert line["config"]["rows_per_gpu"] == rows and line["config"]["global_rows"] == 8 * rows == d["global_rows"]
@@ -121,4 +131,5 @@ def test_bench_eight_ranks_rehearse_the_multi_gpu_configurations_baseline_names(
     assert set(shared) >= {"mask", "y", "cond"} and (workload != "c3_sdxl_b4" or (shared["cond"] == [1, 77, 2048] and shared["pooled"] == [1, 2816]))
     n_el = line["config"]["latent_elements_per_gpu"]
     assert d["broadcast_bytes"] >= 2 * 4 * n_el + 2 * 77 * 2048
-    assert line["parity_check"]["ok"] and line["value"] > 0
+    assert line["parity_check"]["ok"] and line["value"] > 0 and d["parity_ok_all_ranks"]
+    assert all(r["parity_ok"] is True and r["steady_launch_us"] > 0 and r["t_first_barrier_wait_s"] >= 0 for r in per)
