@@ -85,6 +85,12 @@ extern "C" {
 #define LP_R_CXT          9   /* A - 1/(1-abt)                                   */
 #define LP_C_TMODEL      32   /* the time the backbone is called with inside the loop (flow_t or VE sigma,
                                  lanpaint.py:165,170): lets a replayed hipGraph hand `table[:, 32]` to the model */
+#define LP_C_RSCALE      33   /* RN(1 / scale), formed in double and rounded once (= the IEEE fp32 quotient 1.0f / scale: a
+                                 double has 2 * 24 + 2 <= 53 bits, so the second rounding is innocuous).  The streaming kernels'
+                                 flow-model emit x_t / scale divides four elements per lane by this row scalar: with the
+                                 correctly rounded reciprocal one residual correction per element gives the IEEE quotient
+                                 (lp_common.h::div_shared) -- the reciprocal itself, 11 VALU instructions per lane, now comes
+                                 from the table (round 5).                                                             */
 
 typedef struct lp_hyper {
     float    lambda;          /* LanPaint_Lambda   (lanpaint.py:11)             */

@@ -20,7 +20,7 @@ LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, 
 LP_COEF_STRIDE = 36
 (LP_C_SCALE, LP_C_SQRT_ABT, LP_C_OMA, LP_C_ABT, LP_C_RSIGMA, LP_C_DTX, LP_C_DTY, LP_C_AX, LP_C_AY, LP_C_DX, LP_C_DY,
  LP_C_VALID) = range(12)
-LP_C_REGION0, LP_C_REGION1, LP_C_TMODEL = 12, 22, 32
+LP_C_REGION0, LP_C_REGION1, LP_C_TMODEL, LP_C_RSCALE = 12, 22, 32, 33
 (LP_R_E_FULL, LP_R_K_FULL, LP_R_STD_FULL, LP_R_E_HALF, LP_R_K_HALF, LP_R_STD_HALF, LP_R_DT, LP_R_A, LP_R_CX0,
  LP_R_CXT) = range(10)
 

@@ -93,6 +93,39 @@ __device__ __forceinline__ void normal_pair_key(uint32_t c0, uint32_t c1, uint32
     z_pre = r * __builtin_amdgcn_sinf(t);
 }
 
+// The same pairs for the FOUR elements of a streaming lane, the float arithmetic around the transcendentals written on
+// 2-vectors so that it issues as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per instruction, the same
+// values as normal_pair_key element by element -- u01's fma, the -2 ln 2 scaling, r * cos, r * sin: 20 VALU instructions
+// become 10 per lane of a launch that is VALU-bound at streaming sizes; round 5).  v_cvt / v_log / v_sqrt / v_sin / v_cos
+// have no packed form.
+template <bool WIDE>
+__device__ __forceinline__ void normal_pairs4_key(const uint32_t (&elem)[4], uint32_t seq, uint32_t key, float (&z_post)[4],
+                                                  float (&z_pre)[4]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    uint32_t c0[4], c1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c0[k] = elem[k]; c1[k] = seq;
+        philox2x32_10<WIDE>(c0[k], c1[k], key);
+    }
+    const f32x2 scale = {2.3283064365386963e-10f, 2.3283064365386963e-10f}, half = {1.1641532182693481e-10f, 1.1641532182693481e-10f};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        f32x2 u = {static_cast<float>(c0[2 * p]), static_cast<float>(c0[2 * p + 1])};
+        f32x2 t = {static_cast<float>(c1[2 * p]), static_cast<float>(c1[2 * p + 1])};
+        u = __builtin_elementwise_fma(u, scale, half);                     // u01, both elements
+        t = __builtin_elementwise_fma(t, scale, half);
+        f32x2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+        lg = lg * -1.3862943611198906f;
+        const f32x2 r = {__builtin_amdgcn_sqrtf(lg.x), __builtin_amdgcn_sqrtf(lg.y)};
+        const f32x2 cs = {__builtin_amdgcn_cosf(t.x), __builtin_amdgcn_cosf(t.y)};
+        const f32x2 sn = {__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
+        const f32x2 zc = r * cs, zs = r * sn;
+        z_post[2 * p] = zc.x; z_post[2 * p + 1] = zc.y;
+        z_pre[2 * p] = zs.x; z_pre[2 * p + 1] = zs.y;
+    }
+}
+
 __device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_t seed, float& z_post, float& z_pre) {
     uint32_t c0 = static_cast<uint32_t>(elem), c1 = static_cast<uint32_t>(seq);
     philox2x32_10(c0, c1, philox_key(seed, seq, elem));
@@ -590,6 +623,7 @@ __device__ inline void coeffs_lane(const lp_hyper& h, float abt_f, float ve_f, f
         c[LP_C_DY] = sqrtf(2.0f);
         c[LP_C_VALID] = valid ? 1.0f : 0.0f;
         c[LP_C_TMODEL] = tm_f;
+        c[LP_C_RSCALE] = static_cast<float>(1.0 / static_cast<double>(c[LP_C_SCALE]));      // = 1.0f / scale, see the header
     }
     const double oma_d = static_cast<double>(oma);
     float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);

@@ -37,6 +37,7 @@ struct RegionCoef {
 struct RowCoef {
     float scale, sqrt_abt, oma, abt, rsigma, dtx, dty, ax, ay, dx, dy, valid;
     RegionCoef reg[2];
+    float rscale;          // RN(1 / scale) (LP_C_RSCALE; load_row only: the one-element-per-lane kernels divide)
 };
 
 __device__ __forceinline__ RowCoef load_row(const float* __restrict__ coef, int row) {
@@ -45,6 +46,7 @@ __device__ __forceinline__ RowCoef load_row(const float* __restrict__ coef, int 
     r.scale = c[LP_C_SCALE]; r.sqrt_abt = c[LP_C_SQRT_ABT]; r.oma = c[LP_C_OMA]; r.abt = c[LP_C_ABT];
     r.rsigma = c[LP_C_RSIGMA]; r.dtx = c[LP_C_DTX]; r.dty = c[LP_C_DTY]; r.ax = c[LP_C_AX]; r.ay = c[LP_C_AY];
     r.dx = c[LP_C_DX]; r.dy = c[LP_C_DY]; r.valid = c[LP_C_VALID];
+    r.rscale = c[LP_C_RSCALE];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const float* q = c + (g ? LP_C_REGION1 : LP_C_REGION0);
@@ -73,6 +75,7 @@ __device__ __forceinline__ RowCoef load_row_early(const float* coef, int row) {
     r.scale = w[LP_C_SCALE]; r.sqrt_abt = w[LP_C_SQRT_ABT]; r.oma = w[LP_C_OMA]; r.abt = w[LP_C_ABT];
     r.rsigma = w[LP_C_RSIGMA]; r.dtx = w[LP_C_DTX]; r.dty = w[LP_C_DTY]; r.ax = w[LP_C_AX]; r.ay = w[LP_C_AY];
     r.dx = w[LP_C_DX]; r.dy = w[LP_C_DY]; r.valid = w[LP_C_VALID];
+    r.rscale = 0.0f;       // (slot 33 lies past the eight quads fetched here; nothing at one element per lane reads it)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const float* q = w + (g ? LP_C_REGION1 : LP_C_REGION0);
@@ -488,7 +491,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
     const uint32_t ph = PH ? PH : d.phases;          // compile-time for the hot combinations
     const bool flow = fl & LP_FL_FLOW;
     const bool post = ph & kPost;
-    const bool given = fl & LP_FL_X0S_GIVEN;
+    // The phase-specialised kernels (PH != 0: the launches a think loop repeats) never see the two rare forms -- x0s handed in
+    // (LP_FL_X0S_GIVEN: the public langevin_dynamics) and host-supplied noise (xi_post / xi_pre: recorded streams, explicit
+    // torch.randn_like draws) -- lp_step routes those to the run-time-phase kernels (launch_phase), so the four selects on
+    // `given` and the eight between in-kernel and host noise leave the hot code (round 5: 12 VALU instructions per lane of
+    // a launch that is VALU-bound at streaming sizes)
+    // (Philox kernels without early stop only: the early-stop kernels sit at their register limits -- the changed schedule sent one of
+    // them to scratch memory -- and the torch-stream kernels, whose two Philox4x32 blocks per lane the scheduler then interleaves
+    // further, went from 52-64 to 65-74 VGPRs, i.e. below 8 waves per SIMD)
+    constexpr bool HOT = PH != 0 && ES == 0 && RNG == 0;
+    const bool given = HOT ? false : (fl & LP_FL_X0S_GIVEN) != 0;
     const int x0dt = X0W == 4 ? static_cast<int>(DT_F32) : x0_dtype(fl), xindt = xin_dtype(fl);
     const int64_t groups = ST ? static_cast<int64_t>(d.rng_bg) : d.el_per_row / VEC;
     const int64_t row_base = static_cast<int64_t>(row) * d.el_per_row;
@@ -762,6 +774,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         // all 1 takes its region's coefficients from SGPRs -- no mask decode, no per-element selects -- through the very
         // expressions of the per-element path (same operations on the same values: bit-identical results).
         constexpr bool UNI = HARD && VEC == 4 && !ST && (PH & (kPost | LP_PH_PRE_HALF)) != 0 && (PH & LP_PH_REPLACE) == 0;
+        constexpr bool MIXSEL = UNI && ES == 0;       // mixed waves of these kernels: both regions computed, results selected (below)
         int uni = -1;                                // 0: every element inpaint, 1: every element known, -1: mixed
         bool need_x0 = true, need_known = true;
         bool lane_x0 = true, lane_known = true;
@@ -843,7 +856,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         // ---- from here on the descriptor proper is needed (the first wait for the argument segment) ----
         if constexpr (SMALL) load_mask_raw<VEC>(d.mask, mfl, i, m_raw);
         const bool has_corr = d.corr_el != nullptr && !given;
-        const bool host_post = d.xi_post != nullptr, host_pre = d.xi_pre != nullptr;
+        const bool host_post = HOT ? false : d.xi_post != nullptr, host_pre = HOT ? false : d.xi_pre != nullptr;
         const bool need_rng = (post && !host_post) || ((ph & LP_PH_PRE_HALF) && !host_pre);
         if (post) {
             if (!given && need_known && lane_known) load_f32<VEC>(d.y, i_kn, yv);
@@ -953,6 +966,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 // is the shorter chain -- same-box A/B against the round-3 library, scripts/r04_ab_c2.sh)
                 const bool key_uniform = !SMALL && d.n_el <= 0xffffffffll;
                 const uint32_t key0 = philox_key(seed, seq, 0);
+                if constexpr (VEC == 4 && HOT) {
+                    if (key_uniform) {
+                        // the lane's four Philox blocks, then Box-Muller on 2-vectors (packed fp32, lp_common.h::normal_pairs4_key)
+                        uint32_t e4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) e4[k] = static_cast<uint32_t>(elem_index(i, k));
+                        normal_pairs4_key<true>(e4, static_cast<uint32_t>(seq), key0, xi_a, xi_b);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) normal_pair(static_cast<uint64_t>(elem_index(i, k)), seq, seed, xi_a[k], xi_b[k]);
+                    }
+                } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float za, zb;
@@ -963,6 +988,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                     else normal_pair(e, seq, seed, za, zb);
                     if (!host_post) xi_a[k] = za;
                     if (!host_pre) xi_b[k] = zb;
+                }
                 }
             }
         }
@@ -1109,16 +1135,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 }
             }
             // table path of element k: two regions per row, no transcendental per element (`q`: the region's coefficients)
-            auto post_valid = [&](int k, const RegionCoef& q, bool known_el) __attribute__((always_inline)) {
-                const float s0 = (given || !known_el) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
-                const float cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
-                x0s[k] = s0;
+            // (post_vals: the three results of element k in region `q` -- x0s, the new C, the new x_t -- as VALUES, so that a mixed wave
+            // can form both regions' and select; post_valid: the same stored)
+            auto post_vals = [&](int k, const RegionCoef& q, bool known_el, float& s0, float& cn, float& xn) __attribute__((always_inline)) {
+                s0 = (given || !known_el) ? x0[k] : fmaf(-lam, x0b[k], opl * yv[k]);
+                cn = fmaf(q.cx0, s0, q.cxt * xt[k]);
                 if (ph & LP_PH_POST_FIRST) {
-                    xt[k] = fmaf(q.e_full, xt[k], fmaf(q.k_full, cn, q.std_full * xi_a[k]));
+                    xn = fmaf(q.e_full, xt[k], fmaf(q.k_full, cn, q.std_full * xi_a[k]));
                 } else {
                     const float xd = fmaf(cn - cv[k], q.dt, xt[k]);
-                    xt[k] = fmaf(q.e_half, xd, fmaf(q.k_half, cv[k], q.std_half * xi_a[k]));
+                    xn = fmaf(q.e_half, xd, fmaf(q.k_half, cv[k], q.std_half * xi_a[k]));
                 }
+            };
+            auto post_valid = [&](int k, const RegionCoef& q, bool known_el) __attribute__((always_inline)) {
+                float s0, cn, xn;
+                post_vals(k, q, known_el, s0, cn, xn);
+                x0s[k] = s0;
+                xt[k] = xn;
                 cv[k] = cn;
             };
             auto post_skipped = [&](int k) __attribute__((always_inline)) {      // a row whose step is not positive (lanpaint.py:205)
@@ -1142,6 +1175,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 } else {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) post_valid(k, rc.reg[1], true);
+                }
+            } else if (MIXSEL && rc.valid != 0.0f) {
+                // A MIXED wave of a hard mask at 16 bytes per lane (mask edges; a spatial mask on a video latent is mixed waves
+                // only): both regions' arithmetic for every element, on the two scalar coefficient sets -- straight-line code the
+                // compiler pairs into packed fp32 like the uniform waves' -- and one select per result, instead of a branch per
+                // element whose two sides a mixed wave walks one after the other anyway (round 5).  Same expressions on the same
+                // values for the side an element takes: bit-identical; what the other side computes -- possibly from a stream the
+                // lane did not load -- is discarded.
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const bool kn = m[k] == 1.0f;
+                    float s0a, cna, xna, s0b, cnb, xnb;
+                    post_vals(k, rc.reg[0], false, s0a, cna, xna);
+                    post_vals(k, rc.reg[1], true, s0b, cnb, xnb);
+                    x0s[k] = kn ? s0b : s0a;
+                    xt[k] = kn ? xnb : xna;
+                    cv[k] = kn ? cnb : cna;
                 }
             } else {
 #pragma unroll
@@ -1253,6 +1303,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             } else if (UNI && uni == 1) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) xe[k] = half_valid(xt[k], cv[k], xi_b[k], rc.reg[1]);
+            } else if (MIXSEL && rc.valid != 0.0f) {       // mixed wave: both regions' half-step, selected (see POST above)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float ha = half_valid(xt[k], cv[k], xi_b[k], rc.reg[0]), hb = half_valid(xt[k], cv[k], xi_b[k], rc.reg[1]);
+                    xe[k] = m[k] == 1.0f ? hb : ha;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) xe[k] = half_step(xt[k], cv[k], xi_b[k], k);
@@ -1281,12 +1337,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             if constexpr (VEC == 4 && !PER_EL && PH != 0) {
                 // streaming row-table kernels: the row's scale divides all four elements of the lane -- one reciprocal + three
                 // instructions per quotient instead of four IEEE division sequences, same values (div_shared, lp_common.h).
-                // (a real branch: the empty asm keeps the reciprocal from being hoisted in front of it, after which both sides
-                // were computed for every element and selected)
                 const float sc = rc.scale;
                 if (flow) {
-                    float y = 1.0f / sc;
-                    asm volatile("" : "+v"(y));
+                    // (round 5: the correctly rounded reciprocal of the row's scale comes from the coefficient table, LP_C_RSCALE --
+                    // the IEEE sequence for 1.0f / sc was 11 instructions per lane)
+                    // (the early-stop launches sit at their SGPR limit -- one more live scalar sent the torch-stream one to scratch
+                    // memory -- and keep forming the reciprocal themselves; the empty asm keeps it behind the branch)
+                    float y;
+                    if constexpr (ES != 0 || (RNG == 1 && !ST)) {     // (likewise the non-strided torch-stream kernels: one of them at 101 SGPRs)
+                        y = 1.0f / sc;
+                        asm volatile("" : "+v"(y));
+                    } else {
+                        y = rc.rscale;
+                    }
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) xo[k] = div_shared(xe[k], sc, y);
                 } else {
@@ -1511,6 +1574,9 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     const bool hard = (d.flags & LP_FL_MASK_BITS) && d.corr_el == nullptr;
     if (d.flags & LP_FL_AV)             // two time sets per row (AV packs): the run-time row-table kernels know the flag
         return (d.flags & LP_FL_ES) ? launch<VEC, MODE_ROW, 0, 0, 2, false, 1>(d, stream, timer) : launch<VEC, MODE_ROW, 0>(d, stream, timer);
+    // x0s handed in (the public langevin_dynamics) and host-supplied noise (recorded streams, explicit torch.randn_like draws)
+    // only exist in the run-time-phase kernels (round 5: their selects left the phase-specialised ones)
+    const bool rare = (d.flags & LP_FL_X0S_GIVEN) || d.xi_post || d.xi_pre;
     const bool x0_half = x0_dtype(d.flags) != DT_F32;
     // half-width heads of a streaming launch go 16 bytes per lane pair (lp_common.h): 16-byte aligned streams, rows of 8 k
     // elements; anything else takes the run-time kernel with its 8-byte accesses
@@ -1520,7 +1586,7 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     if (d.flags & LP_FL_ES) {                                // inner early stop evaluated on the device
         // the two launches a loop repeats, specialised like the plain hot kernels (bit-packed mask, fp32 heads): the
         // run-time phase kernel spends 1.0 us of shader clock before its first operand load, these 0.6
-        if (hard && !x0_half && !d.xi_post && !d.xi_pre && (!d.es_ring || (d.flags & LP_FL_ES_RING_BITS))) {
+        if (hard && !x0_half && !rare && (!d.es_ring || (d.flags & LP_FL_ES_RING_BITS))) {
             const bool rt = d.rng_kind == LP_RNG_TORCH;
             if (d.phases == (S | P | E))
                 return rt ? launch<VEC, MODE_HARD, S | P | E, 4, 1, false, 1>(d, stream, timer)
@@ -1550,7 +1616,7 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     (strided ? (x0_half ? launch<4, MODE_, PH_, 2, 1, true>(d, stream, timer) : launch<4, MODE_, PH_, 4, 1, true>(d, stream, timer)) \
      : x0_half ? (rng_torch ? launch<VEC, MODE_, PH_, 2, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 2, 0>(d, stream, timer)) \
                : (rng_torch ? launch<VEC, MODE_, PH_, 4, 1>(d, stream, timer) : launch<VEC, MODE_, PH_, 4, 0>(d, stream, timer)))
-    if (!pair_ok) return hard ? launch<VEC, MODE_HARD, 0>(d, stream, timer) : launch<VEC, MODE_ROW, 0>(d, stream, timer);
+    if (!pair_ok || rare) return hard ? launch<VEC, MODE_HARD, 0>(d, stream, timer) : launch<VEC, MODE_ROW, 0>(d, stream, timer);
     if (hard) {
         switch (d.phases) {
             case S | P | E: return LP_HOT(MODE_HARD, S | P | E);   // steady state
