@@ -535,6 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             rs_f = d.t_rsig ? d.t_rsig[static_cast<int64_t>(row) * d.t_rsig_stride] : 0.0f;
         }
         rc.scale = row_scale(flow, abt_f, ve_f);
+        rc.rscale = 1.0f / rc.scale;        // (what the table's LP_C_RSCALE holds: the emit of this launch divides by it, see EMIT)
         rc.rsigma = rs_f;
         if (blockIdx.x == 0 && threadIdx.x < 4) {
             lp_hyper h;
@@ -910,6 +911,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             }
         }
 
+        // Streaming kernels: the device-side generator state of a replayed graph, read HERE -- behind the operand loads, ahead of
+        // the first store of the kernel.  Ahead of every store the compiler can prove the words unclobbered and reads them with a
+        // SCALAR load (its own counter); round 4 read them inside the noise block, behind the I/O-table store below: a VECTOR
+        // load, whose `s_waitcnt vmcnt(0)` made the Philox rounds wait for every operand load issued before it -- in a replayed
+        // graph (the engine's launches; the micro-benchmarks pass no state pointer) the noise was generated AFTER the memory
+        // latency instead of under it (rocprofv3, C5 steady: 9.05 us in the bench's replays against 8.57 in the micro-benchmark).
+        if constexpr (!SMALL) {
+            if (need_rng && d.rng_offset_ptr) {
+                rng_w0 = d.rng_offset_ptr[0];
+                rng_w1 = d.rng_offset_ptr[1];
+                rng_have = true;
+            }
+        }
         // per-call I/O pointers for the launches of this sigma call that live in a captured graph (lp_finalize)
         if (d.io_table_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
             d.io_table_out[0] = d.io_table_val[0];
@@ -930,13 +944,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         if (need_rng) {
             const bool torch_kind = RNG == 2 ? (d.rng_kind == LP_RNG_TORCH) : (RNG == 1);
             uint64_t seq = d.rng_offset, seed = d.rng_seed;
-            if constexpr (!SMALL) {
-                if (d.rng_offset_ptr) {                          // device-side state of a replayed graph
-                    rng_w0 = d.rng_offset_ptr[0];
-                    rng_w1 = d.rng_offset_ptr[1];
-                    rng_have = true;
-                }
-            }
             if (rng_have) {
                 seq += rng_w0;
                 if (torch_kind) seed = rng_w1;
