@@ -148,12 +148,42 @@ __device__ __forceinline__ void normal_pair(uint64_t elem, uint64_t seq, uint64_
 // rocRAND's Box-Muller (rocrand_normal.h, box_muller(unsigned, unsigned)) restated expression for expression -- the
 // same constants, the same fused a + x*a shapes, library logf / sqrtf, the native sine / cosine of __sincosf: the
 // library no longer reaches into rocrand_device::detail.  (sine first: .x of the pair is the sine branch.)
+// The library logf / correctly rounded sqrtf of that expression, restated for the ARGUMENTS Box-Muller can hand them (round 5):
+// what the ROCm device library computes for a normal-range argument, minus its range handling.  u = 2^-32 (x + 1) lies in
+// [2^-32, 1]: never denormal, its logarithm finite -- ocml's logf is v_log_f32 (log2) times ln 2 in two pieces (head
+// 0x3f317217, tail 0x3377d1cf, the product's rounding error recovered with an fma); the x < 2^-126 rescaling by 2^32 and the
+// |log2| < inf select around it never act.  -2 ln u lies in {-0} u [1.19e-7, 44.4]: ocml's sqrtf is v_sqrt_f32 followed by
+// one step down / one step up in the last place against the exact residual (fma); its x < 2^-96 rescaling never acts, its
+// "zero or infinity is its own root" select is kept (u = 1 gives -0).  12 -> 5 and 16 -> 11 VALU instructions, four of each
+// per lane and draw of a kernel that is VALU-bound (C5 with the reference's noise stream: 585 instructions per wave in round
+// 4).  Bit-equality with torch.randn is what the engine's load-time self-check and tests/test_gpu_kernels.py::
+// test_torch_normal_reproduces_torch_randn_bit_for_bit verify on the hardware.
+__device__ __forceinline__ float bm_logf(float u) {
+#pragma clang fp contract(off)
+    const float r = __builtin_amdgcn_logf(u);
+    const float head = __uint_as_float(0x3f317217u), tail = __uint_as_float(0x3377d1cfu);
+    const float p = r * head;
+    float e = __builtin_fmaf(r, head, -p);
+    e = __builtin_fmaf(r, tail, e);
+    return p + e;
+}
+
+__device__ __forceinline__ float bm_sqrtf(float x) {
+#pragma clang fp contract(off)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_down = __builtin_fmaf(-down, s, x), e_up = __builtin_fmaf(-up, s, x);
+    float t = (0.0f >= e_down) ? down : s;
+    t = (0.0f < e_up) ? up : t;
+    return __builtin_amdgcn_classf(x, 0x260) ? x : t;          // (+-0, +inf)
+}
+
 __device__ __forceinline__ float2 box_muller_u32(uint32_t x, uint32_t y) {
 #pragma clang fp contract(on)
     float2 r;
     const float u = 2.3283064e-10f + (x * 2.3283064e-10f);
     const float v = 1.46291807e-09f + (y * 1.46291807e-09f);
-    const float s = sqrtf(-2.0f * logf(u));
+    const float s = bm_sqrtf(-2.0f * bm_logf(u));
     __sincosf(v, &r.x, &r.y);
     r.x *= s;
     r.y *= s;

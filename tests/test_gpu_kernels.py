@@ -548,6 +548,30 @@ def test_torch_normal_reproduces_torch_randn_bit_for_bit(lib, n):
     assert lib.lp_torch_normal(out.data_ptr(), x.numel(), seed, off + 1, bg, st) < 0      # offsets come in fours
 
 
+def test_torch_normal_equals_torch_randn_over_a_quarter_billion_draws(lib):
+    """Round 5 restated the device library's logf / sqrtf inside the Box-Muller of LP_RNG_TORCH for the arguments it can receive
+    (lp_common.h::bm_logf / bm_sqrtf: no denormal rescaling, no infinity select).  That is only right if no draw ever needs the
+    dropped range handling and the kept arithmetic is the library's own: 4 x 2^26 draws from different generator states against
+    torch.randn, BITWISE (torch.equal would let -0.0 pass for +0.0: the sign of a zero root is part of the restatement)."""
+    import torch
+    from lanpaint_amd import LanPaint, _cabi
+    dev = torch.device("cuda", 0)
+    gen = LanPaint._generator(dev)
+    n = 1 << 26
+    bg, inc = LanPaint._randn_policy(dev, n)
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(n, device=dev)
+    for seed in (0, 1, 20250924, 2 ** 40 + 7):
+        torch.manual_seed(seed)
+        gen.set_offset(4 * (seed % 1000))
+        s, off = gen.initial_seed(), gen.get_offset()
+        ref = torch.randn(n, device=dev)
+        assert gen.get_offset() - off == inc
+        _cabi.check(lib.lp_torch_normal(out.data_ptr(), n, s, off, bg, st), "lp_torch_normal")
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), seed
+        assert torch.isfinite(ref).all() and float(ref.abs().max()) > 5.0          # the tails were visited
+
+
 @pytest.mark.parametrize("rng", ["philox", "torch"])
 @pytest.mark.parametrize("kind", ["temporal", "box", "blob"])
 @pytest.mark.parametrize("phase", ["steady", "first", "last"])
