@@ -238,7 +238,8 @@ __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64
 }
 
 // The four values thread `idx` of ATen's kernel produces with one normal4 call: elements idx, idx + bg, idx + 2 bg,
-// idx + 3 bg of the tensor (the `Strided` lane layout).
+// idx + 3 bg of the tensor.  The streaming kernels evaluate it per ATen thread and hand the values to the lanes that hold
+// those elements through LDS (step_kernel.hip, ST).
 __device__ __forceinline__ void torch_normal4(uint32_t idx, uint64_t seed, uint64_t offset, float (&o)[4]) {
 #pragma clang fp contract(on)
     const uint4 c = philox4x32_10<true>(offset >> 2, idx, seed);
@@ -298,69 +299,9 @@ __device__ __forceinline__ uint32_t pack_half2(int dt, float lo, float hi) {
     return static_cast<uint32_t>(f32_to_f16(lo)) | (static_cast<uint32_t>(f32_to_f16(hi)) << 16);
 }
 
-// Where the V elements of one lane live.  Normally V consecutive elements from index i (an int64_t).  `Strided`:
-// element k at i + k * s while that is < n -- the element-to-thread map of ATen's random kernels (a thread's
-// k-th value goes block*grid elements further on), used by the LP_RNG_TORCH large-latent variant so that one
-// Philox4x32 block serves four elements as it does in torch.  Each of its accesses is a coalesced 4-byte stream.
-// Loads of a slot past the end are redirected to the last element (no branch around a load, the value is never
-// stored); only the stores are predicated.
-struct Strided {
-    uint32_t e[4];     // element index per slot (lp_step takes this layout for tensors below 2^30 elements only: four
-                       // registers of indices instead of eight -- the strided kernels sat at 78 VGPRs, 6 waves per SIMD --
-                       // and BYTE offsets that fit 32 bits, see at_bytes)
-    bool ok[4];        // slot inside the tensor
-    // slots base + i + k s that fall into [lo, hi) (one batch row's part of one round of ATen's grid-stride loop)
-    __device__ __forceinline__ Strided(int64_t i, int64_t s, int64_t base, int64_t lo, int64_t hi) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t t = base + i + k * s;
-            ok[k] = t >= lo && t < hi;
-            e[k] = static_cast<uint32_t>(ok[k] ? t : lo);
-        }
-    }
-};
-// Element e of a tensor at p, addressed as "pointer + 32-bit BYTE offset": p is a kernel argument (SGPR pair), so the access
-// is `global_load v, v_off, s[base]` -- one offset register per slot shared by every tensor of the launch.  Written as p[e]
-// with a 32-bit e the compiler must assume that 4 e overflows 32 bits and builds a 64-bit address PAIR per tensor and slot
-// (3-4 VALU instructions and two VGPRs each, kept alive until the stores: the last-iteration strided kernels sat at 70 VGPRs).
-template <typename T>
-__device__ __forceinline__ const T* at_bytes(const void* p, uint32_t e) {
-    return reinterpret_cast<const T*>(static_cast<const char*>(p) + static_cast<uint32_t>(e * static_cast<uint32_t>(sizeof(T))));
-}
-template <typename T>
-__device__ __forceinline__ T* at_bytes(void* p, uint32_t e) {
-    return reinterpret_cast<T*>(static_cast<char*>(p) + static_cast<uint32_t>(e * static_cast<uint32_t>(sizeof(T))));
-}
-// The same for an access inside a predicated block (the stores of slots that may lie outside the tensor): the offset passes
-// through an empty asm, which keeps the address arithmetic IN that block -- instruction selection works block by block, and an
-// address computed once next to the loads reaches the store's block as a finished 64-bit value in a VGPR pair.
-template <typename T>
-__device__ __forceinline__ const T* at_bytes_here(const void* p, uint32_t e) {
-    uint32_t off = e * static_cast<uint32_t>(sizeof(T));
-    asm volatile("" : "+v"(off));
-    return reinterpret_cast<const T*>(static_cast<const char*>(p) + off);
-}
-template <typename T>
-__device__ __forceinline__ T* at_bytes_here(void* p, uint32_t e) {
-    uint32_t off = e * static_cast<uint32_t>(sizeof(T));
-    asm volatile("" : "+v"(off));
-    return reinterpret_cast<T*>(static_cast<char*>(p) + off);
-}
+// Where the V elements of one lane live: V consecutive elements from index i (an int64_t).
 __device__ __forceinline__ int64_t elem_index(int64_t i, int k) { return i + k; }
-__device__ __forceinline__ int64_t elem_index(const Strided& x, int k) { return static_cast<int64_t>(x.e[k]); }
-__device__ __forceinline__ bool elem_ok(const Strided& x, int k) { return x.ok[k]; }
 
-template <int V>
-__device__ __forceinline__ void load_f32(const float* __restrict__ p, const Strided& x, float (&o)[V]) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) o[k] = __builtin_nontemporal_load(at_bytes_here<float>(p, x.e[k]));
-}
-template <int V>
-__device__ __forceinline__ void store_f32(float* __restrict__ p, const Strided& x, const float (&v)[V]) {
-#pragma unroll
-    for (int k = 0; k < V; ++k)
-        if (elem_ok(x, k)) __builtin_nontemporal_store(v[k], at_bytes_here<float>(p, x.e[k]));
-}
 
 template <int V>
 __device__ __forceinline__ void load_f32(const float* __restrict__ p, int64_t i, float (&o)[V]) {
@@ -417,23 +358,7 @@ __device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, int
     }
 }
 
-template <int V>
-__device__ __forceinline__ void load_raw(const void* __restrict__ p, int dt, const Strided& x, Raw<V>& r) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        r.w[k] = (dt == DT_F32) ? __float_as_uint(*at_bytes_here<float>(p, x.e[k]))
-                                : static_cast<uint32_t>(*at_bytes_here<uint16_t>(p, x.e[k]));
-    }
-}
 
-// strided lanes keep one storage word per element (no packing of 16-bit pairs)
-template <int V>
-__device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V], const Strided&) {
-#pragma unroll
-    for (int k = 0; k < V; ++k)
-        o[k] = (dt == DT_F32) ? __uint_as_float(r.w[k])
-               : (dt == DT_BF16) ? bf16_to_f32(static_cast<uint16_t>(r.w[k])) : f16_to_f32(static_cast<uint16_t>(r.w[k]));
-}
 
 template <int V>
 __device__ __forceinline__ void cvt_raw(int dt, const Raw<V>& r, float (&o)[V]) {
@@ -473,15 +398,6 @@ __device__ __forceinline__ void load_any(const void* __restrict__ p, int dt, int
     cvt_raw<V>(dt, r, o);
 }
 
-template <int V>
-__device__ __forceinline__ void store_any(void* __restrict__ p, int dt, const Strided& x, const float (&v)[V]) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        if (!elem_ok(x, k)) continue;
-        if (dt == DT_F32) *at_bytes_here<float>(p, x.e[k]) = v[k];
-        else *at_bytes_here<uint16_t>(p, x.e[k]) = (dt == DT_BF16) ? f32_to_bf16(v[k]) : f32_to_f16(v[k]);
-    }
-}
 
 template <int V>
 __device__ __forceinline__ void store_any(void* __restrict__ p, int dt, int64_t i, const float (&v)[V]) {
@@ -568,28 +484,7 @@ __device__ __forceinline__ void load_mask_raw(const void* __restrict__ p, uint32
     }
 }
 
-template <int V>
-__device__ __forceinline__ void load_mask_raw(const void* __restrict__ p, uint32_t flags, const Strided& x, Raw<V>& r) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        r.w[k] = (flags & LP_FL_MASK_BITS) ? *at_bytes<uint32_t>(p, x.e[k] >> 5)
-                 : (flags & LP_FL_MASK_U8) ? static_cast<uint32_t>(*at_bytes<uint8_t>(p, x.e[k]))
-                                           : __float_as_uint(*at_bytes<float>(p, x.e[k]));
-    }
-}
 
-template <int V>
-__device__ __forceinline__ void cvt_mask(uint32_t flags, const Strided& x, const Raw<V>& r, float (&m)[V]) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        if (flags & LP_FL_MASK_BITS) {
-            m[k] = static_cast<float>((r.w[k] >> (static_cast<uint32_t>(elem_index(x, k)) & 31u)) & 1u);
-        } else {
-            m[k] = (flags & LP_FL_MASK_U8) ? static_cast<float>(r.w[k]) : __uint_as_float(r.w[k]);
-            if (flags & LP_FL_MASK_DENOISE) m[k] = 1.0f - ((m[k] > 0.5f) ? 1.0f : 0.0f);
-        }
-    }
-}
 
 template <int V>
 __device__ __forceinline__ void cvt_mask(uint32_t flags, int64_t i, const Raw<V>& r, float (&m)[V]) {

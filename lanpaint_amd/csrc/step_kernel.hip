@@ -349,11 +349,13 @@ enum : int { MODE_ROW = 0, MODE_PER_EL = 1, MODE_HARD = 2 };
 // masks, a uint8 mask goes through the PH = 0 kernel.
 // RNG: in-kernel generator fixed at compile time in the hot variants (0 = Philox2x32 pair, 1 = torch's randn
 // stream reproduced exactly) or 2 = read d.rng_kind at run time.
-// ST (with VEC = 4, RNG = 1, n_el > bg): the lane's four elements are ATen's -- idx, idx + bg, idx + 2 bg,
-// idx + 3 bg of one round of its grid-stride loop -- so ONE Philox4x32 block and its two Box-Muller pairs serve all
-// four, as in torch's own kernel, instead of one block per element (LP_RNG_TORCH on video latents: 26 -> 14 us).
-// Batches and tensors of several rounds: one blockIdx.y per (round, batch row crossing it), each block working on the
-// elements that belong to both with that row's coefficients.
+// ST (with VEC = 4, RNG = 1, n_el > bg): the launch is laid out like ATen's random kernel -- a block is 256 of its threads, each
+// evaluating ONE Philox4x32 block and its two Box-Muller pairs per draw for the four elements it serves in torch (idx, idx + bg,
+// idx + 2 bg, idx + 3 bg of one round of its grid-stride loop) -- and the values are transposed through LDS to the lanes that
+// stream those elements 16 bytes at a time (wave w of the block: the 256 consecutive elements of slot w).  LP_RNG_TORCH on video
+// latents: 26 us with one block per element, 14 -> 11.5 us with four 4-byte streams per lane (rounds 2-4), now the Philox2x32
+// kernels' access pattern.  Batches and tensors of several rounds: one blockIdx.y per (round, batch row crossing it), each
+// block working on the elements that belong to both with that row's coefficients.
 // ES: the POST phase also evaluates the inner early-stop rule (LP_FL_ES): 1 = per-block sums for the decision kernel
 // that follows, 2 = the launch first applies the verdict of the iteration before itself (gated loops, small grids).
 template <int VEC, int MODE, uint32_t PH, int X0W, int RNG, bool ST = false, int ES = 0>
@@ -598,19 +600,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
     // address in this straight-line body a kernarg pointer + one offset and lets the scalar loads (coefficient
     // row, replayed-graph RNG counter) fly together with the vector loads instead of ahead of a loop
     const int64_t g_raw = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    // ST (round 5): the block is 256 ATen threads -- [256 b, 256 b + 256) of the generator's launch -- whose values fall on FOUR
+    // runs of 256 consecutive elements, bg apart (slot k of thread j: element base + k bg + 256 b + j).  Wave w of the block
+    // takes run w, 16 bytes per lane like every other streaming launch; the values reach it through LDS (below).
+    int64_t st_i = 0;
+    if constexpr (ST) st_i = st_base + static_cast<int64_t>(threadIdx.x >> 6) * static_cast<int64_t>(d.rng_bg) +
+                             static_cast<int64_t>(blockIdx.x) * kBlock + static_cast<int64_t>(threadIdx.x & 63) * VEC;
     // ES: every lane stays for the block reduction; a lane past the end recomputes the last group and stores nothing
-    const bool active = g_raw < groups;
-    if constexpr (!ES) {
+    // ST: every lane stays for the noise exchange; a lane outside the row's part of the round works on the part's first
+    // group and stores nothing (segment bounds are multiples of four elements: a lane's group never straddles one)
+    const bool active = ST ? (st_i >= st_lo && st_i < st_hi) : (g_raw < groups);
+    if constexpr (!ES && !ST) {
         if (!active) return;
     }
     const int64_t g = active ? g_raw : groups - 1;
     float es_p[kEsSums] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool es_zero_wave = false;           // the wave added nothing to its sums (mask-uniform, all known): no reduction tree needed
     {
-        const auto i = [&] {
-            if constexpr (ST) return Strided(g, static_cast<int64_t>(d.rng_bg), st_base, st_lo, st_hi);
-            else return row_base + g * VEC;
-        }();
+        const int64_t i = ST ? (active ? st_i : st_lo) : row_base + g * VEC;
 
         // ---- AV packs (LP_FL_AV; MiniMax-H3 flat audio / video packs, lanpaint.py:60-74) ---------------------------------------
         // The reference blends per-stream times with a full-size 0/1 indicator (VE * (1 - ai) + VE_a * ai, ...): every element
@@ -769,12 +776,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         // In a mixed wave (mask edges, fine-grained masks) each LANE still leaves out the stream none of its four elements
         // reads: the loads run under the lanes' predicate, and a 128-byte line no active lane touches is not fetched
         // (eight lanes = 32 consecutive elements of one region; 50 % box on 1.2 GB: -7 %, disc -4 %).
-        constexpr bool RA = HARD && VEC == 4 && !ST && (PH & kPost) != 0;
+        constexpr bool RA = HARD && VEC == 4 && (PH & kPost) != 0;
         // Wave-uniform ARITHMETIC (round 4; the streaming kernel turned out VALU-bound, not bandwidth-bound: 538 VALU
         // instructions per wave keep the SIMDs > 80 % busy, profiles/r04_sq_*.md): a wave whose 256 mask bits are all 0 or
         // all 1 takes its region's coefficients from SGPRs -- no mask decode, no per-element selects -- through the very
         // expressions of the per-element path (same operations on the same values: bit-identical results).
-        constexpr bool UNI = HARD && VEC == 4 && !ST && (PH & (kPost | LP_PH_PRE_HALF)) != 0 && (PH & LP_PH_REPLACE) == 0;
+        constexpr bool UNI = HARD && VEC == 4 && (PH & (kPost | LP_PH_PRE_HALF)) != 0 && (PH & LP_PH_REPLACE) == 0;
         constexpr bool MIXSEL = UNI && ES == 0;       // mixed waves of these kernels: both regions computed, results selected (below)
         int uni = -1;                                // 0: every element inpaint, 1: every element known, -1: mixed
         bool need_x0 = true, need_known = true;
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
             // region-aware like the POST streams below: a wave of 256 inpaint elements (mask bits all 0) keeps its x and reads
             // neither the noise nor the known latent -- 12 -> 4 B / element read there (streaming kernels, bit-packed mask)
             bool need_kn = true;
-            if constexpr (HARD && VEC == 4 && !ST && (PH & LP_PH_REPLACE) != 0) {
+            if constexpr (HARD && VEC == 4 && (PH & LP_PH_REPLACE) != 0) {
                 if (!(fl & LP_FL_NO_REGION_SKIP)) {
                     const uint32_t nib = (m_raw.w[0] >> (static_cast<uint32_t>(i) & 31u)) & 0xFu;
                     need_kn = __ballot(nib != 0u) != 0ull;
@@ -830,21 +837,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 }
             }
         }
-        // ST: the same decision per SLOT -- the 64 elements one wave holds in slot k are consecutive.  A slot nobody in
-        // the wave reads a stream for has that stream's load pointed at one shared element (a cache line instead of
-        // four, no branch); what it returns is never used (the table path selects by the mask bit).
-        auto i_x0 = i, i_kn = i;
-        if constexpr (ST && HARD && (PH & kPost) != 0) {
-            if (!given && d.x0_big != d.x0 && !(fl & (LP_FL_CFG_FUSED | LP_FL_NO_REGION_SKIP))) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    const bool bit = ((m_raw.w[k] >> (static_cast<uint32_t>(elem_index(i, k)) & 31u)) & 1u) != 0u;
-                    const bool ok = elem_ok(i, k);
-                    if (__ballot(ok && !bit) == 0ull) i_x0.e[k] = static_cast<uint32_t>(st_lo);
-                    if (__ballot(ok && bit) == 0ull) i_kn.e[k] = static_cast<uint32_t>(st_lo);
-                }
-            }
-        }
+        const int64_t i_x0 = i, i_kn = i;
         if (post) {
             if constexpr (PAIR) {
                 if (need_x0) load_raw_pair(d.x0, i, pair_x0, x0_raw);
@@ -953,10 +946,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 const bool draw_post = post && !host_post, draw_pre = (ph & LP_PH_PRE_HALF) && !host_pre;
                 const uint64_t off_pre = seq + (draw_post ? d.rng_inc : 0u);
                 if constexpr (ST) {
-                    static_assert(!ST || VEC == 4, "the strided layout is four elements per lane");
-                    // (round q of the grid-stride loop: Philox counter offset / 4 + q)
-                    if (draw_post) torch_normal4(static_cast<uint32_t>(g), seed, seq + 4ull * st_round, xi_a);
-                    if (draw_pre) torch_normal4(static_cast<uint32_t>(g), seed, off_pre + 4ull * st_round, xi_b);
+                    static_assert(!ST || VEC == 4, "the ATen layout is four elements per lane");
+                    // ATen thread j = 256 b + threadIdx.x evaluates ONE Philox4x32 block per draw (round q of its grid-stride loop:
+                    // counter offset / 4 + q) and gets the values of its four elements -- which lie bg apart.  Round 4 gave the LANE
+                    // those four elements (four 4-byte streams per tensor: 55 memory instructions per lane, 585 VALU instructions per
+                    // wave with their per-slot predicates and addresses).  Now the values are TRANSPOSED through LDS -- written
+                    // [slot][thread], read back by wave `slot` as 16 bytes per lane -- so that every tensor is streamed 16 bytes per
+                    // lane in memory order like the Philox2x32 kernels' (8 KB of LDS per block, one barrier): the generator keeps
+                    // its order, memory keeps its own, LDS is where they meet.
+                    __shared__ __attribute__((aligned(16))) float st_xi[2][4][kBlock];
+                    const uint32_t aten_thread = static_cast<uint32_t>(g_raw);
+                    if (draw_post) {
+                        float z[4];
+                        torch_normal4(aten_thread, seed, seq + 4ull * st_round, z);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) st_xi[0][k][threadIdx.x] = z[k];
+                    }
+                    if (draw_pre) {
+                        float z[4];
+                        torch_normal4(aten_thread, seed, off_pre + 4ull * st_round, z);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) st_xi[1][k][threadIdx.x] = z[k];
+                    }
+                    __syncthreads();
+                    const int w = threadIdx.x >> 6, l4 = (threadIdx.x & 63) * 4;
+                    if (draw_post) {
+                        const float4 q = *reinterpret_cast<const float4*>(&st_xi[0][w][l4]);
+                        xi_a[0] = q.x; xi_a[1] = q.y; xi_a[2] = q.z; xi_a[3] = q.w;
+                    }
+                    if (draw_pre) {
+                        const float4 q = *reinterpret_cast<const float4*>(&st_xi[1][w][l4]);
+                        xi_b[0] = q.x; xi_b[1] = q.y; xi_b[2] = q.z; xi_b[3] = q.w;
+                    }
                 } else {
                     const bool small = d.n_el <= static_cast<int64_t>(d.rng_bg);     // one ATen thread per element
 #pragma unroll
@@ -1617,7 +1638,7 @@ static hipError_t launch_phase(const lp_step_desc& d, hipStream_t stream, Timer*
     // ATen's element-to-thread layout pays off when a Philox block really serves several elements of this tensor
     // (batch rows: as long as a row covers at least half a round most lanes still use two or more values of their block)
     const bool strided = VEC == 4 && rng_torch && !d.xi_post && !d.xi_pre && d.n_el > static_cast<int64_t>(d.rng_bg) &&
-                         d.n_el < (1ll << 30) &&               /* 32-bit byte offsets, lp_common.h at_bytes */
+                         (d.rng_bg % kBlock) == 0 &&           /* a block is 256 whole ATen threads */
                          (d.rows == 1 || d.el_per_row >= 2 * static_cast<int64_t>(d.rng_bg)) && st_segments(d) != 0;
 #define LP_HOT(MODE_, PH_)                                                                                   \
     (strided ? (x0_half ? launch<4, MODE_, PH_, 2, 1, true>(d, stream, timer) : launch<4, MODE_, PH_, 4, 1, true>(d, stream, timer)) \
