@@ -1,0 +1,332 @@
+"""Property test of the host plumbing's state machine.
+
+`lanpaint_amd/lanpaint.py` caches per-tensor facts (packed masks, rings, noise verdicts), captures sigma calls as hipGraphs
+keyed on shapes / addresses / hyper-parameters, replays them through snapshotted descriptors, and runs in several launch modes.
+The hand-written tests sample that state space; this one walks it at random: hypothesis draws a SEQUENCE of events -- sigma
+calls interleaved with an in-place mask rewrite, a new mask object, a rewritten / zeroed noise tensor, a hyper-parameter
+change, a different inner-step count, torch.inference_mode() switched on or off, the inner early stop switched on or off, a
+fresh `x` tensor, a jump in the schedule, a new `model_options` dict -- for an engine in `graph="auto"` (the default),
+`graph=True`, eager launches, or behind KSamplerX0Inpaint's split-phase node path.  After EVERY call the returned `out` and the
+in-place `x` are compared with the CPU oracle run from the same inputs on the draws the kernels themselves generated
+(rng="torch": what torch.randn returns from the same generator state, the generator then required to stand where the
+reference would leave it; rng="philox": lp_philox_normal for the sequence numbers the launches used).  400 sequences in all
+(100 per mode); a counter-example is a bug in the caches or the capture keys, never an acceptable flake -- fix it and keep the
+sequence as a regression case below.
+"""
+import contextlib
+import ctypes
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import lanpaint_oracle as orc
+from tests import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+REL = 5e-5
+N_SIG = 12
+EVENTS = ("call", "call", "call", "call", "mask_inplace", "mask_new", "noise_rewrite", "noise_zero", "hyper", "n_steps",
+          "inference", "early_stop", "x_new", "jump", "options_new")
+SHAPES = ((1, 4, 16, 16), (2, 4, 8, 24), (1, 4, 4, 8, 8), (3, 2, 6, 10))
+
+
+class _Sampling:
+    def __init__(self, flow):
+        self.lanpaint_noise_scaling_kind = "flow" if flow else "ve"
+        self.noise_scale = 1.0
+        self.flow = flow
+
+    def noise_scaling(self, sigma, noise, latent_image, max_denoise=False):
+        return (sigma * noise + (1.0 - sigma) * latent_image) if self.flow else (latent_image + noise * sigma)
+
+
+class _Model:
+    def __init__(self, flow):
+        self.inner_model = self
+        self.model_sampling = _Sampling(flow)
+        self.model_type = "FLOW" if flow else "EPS"
+        self.calls = 0
+
+    def __call__(self, x, t, model_options=None, seed=None):
+        self.calls += 1
+        return 0.9 * x, 0.8 * x
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _close(a, b, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert np.isfinite(a).all(), f"{what}: non-finite"
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= REL * scale, f"{what}: max abs err {err:.3e} > {REL * scale:.3e}"
+
+
+class _Job:
+    """One engine + the tensors of its job + the oracle twin; `event` applies one drawn event, `call` runs one checked call."""
+
+    def __init__(self, mode, rng, shape, flow, packed, seed):
+        import torch
+        from lanpaint_amd import LanPaint, nodes, pack_mask
+        self.torch, self.mode, self.rng, self.shape, self.flow, self.packed = torch, mode, rng, shape, flow, packed
+        self.g = np.random.default_rng(seed)
+        self.sig = gc.flow_sigmas(N_SIG) if flow else gc.karras_sigmas(N_SIG, 0.05, 12.0)
+        self.pos, self.n_steps, self.inference, self.es, self.options = 0, 3, False, False, {}
+        self.hyper = dict(lamb=5.0, beta=1.0, step=0.2)
+        self.model = _Model(flow)
+        self.node = mode == "node"
+        if self.node:
+            self.model.model_type = nodes.ModelType.FLOW if flow else "EPS"
+        msf = 1.0 if self.node else 0.0
+        kw = {"auto": {}, "graph": {"graph": True}, "eager": {"graph": False}, "node": {"graph": True}}[mode]
+        self.engine = LanPaint(self.model, self.n_steps, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, MinStepFrac=msf, rng=rng, philox_seed=11, **kw)
+        self.oracle_draws = []
+        self.oracle = orc.OracleLanPaint(_Model(flow), self.n_steps, 15.0, 5.0, 1.0, 0.2, is_flow=flow, min_step_frac=msf,
+                                         randn=lambda like: self.oracle_draws.pop(0))
+        self.pack_mask = pack_mask
+        self.y = self._dev(self.g.standard_normal(shape, dtype=np.float32))
+        self.noise = self._dev(self.g.standard_normal(shape, dtype=np.float32))
+        self.new_mask()
+        s0 = float(self.sig[0])
+        self.x = ((s0 * self.noise + (1 - s0) * self.y) if flow else (self.y + self.noise * s0)).clone()
+        if self.node:
+            self.k = nodes.KSamplerX0Inpaint(self.model, self._dev(self.sig))
+            self.k.latent_image, self.k.noise = self.y, self.noise
+            self.k.PaintMethod = self.engine
+            self.k.LanPaint_early_stop, self.k.LanPaint_min_step_frac = 1, msf
+
+    def _dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+    def _mask_values(self):
+        m = (self.g.random(self.shape) > 0.45).astype(np.float32)
+        m.reshape(-1)[:2] = (0.0, 1.0)                    # never all known / all inpaint
+        return m
+
+    def new_mask(self):
+        """`mask`: latent_mask (1 = known) for the engine, or ComfyUI's denoise_mask (1 = inpaint) behind the node."""
+        m = self._mask_values()
+        with (self.torch.inference_mode() if self.inference else contextlib.nullcontext()):      # (an inference tensor: no version counter)
+            self.mask = self._dev(1.0 - m if self.node else m)
+            if self.packed and not self.node:
+                self.mask = self.pack_mask(self.mask)
+
+    def latent_mask_np(self):
+        m = _np(self.mask)
+        return orc.binarize_and_invert(m) if self.node else m
+
+    def event(self, name, arg):
+        t = self.torch
+        if name == "mask_inplace":
+            # (an inference tensor may only be written under inference mode; a normal one either way)
+            with (t.inference_mode() if (self.inference or self.mask.is_inference()) else contextlib.nullcontext()):
+                m = self._mask_values()
+                self.mask.copy_(self._dev(1.0 - m if self.node else m))
+        elif name == "mask_new":
+            self.new_mask()
+        elif name == "noise_rewrite":
+            self.noise.copy_(self._dev(self.g.standard_normal(self.shape, dtype=np.float32)))
+        elif name == "noise_zero":
+            if not self.node:                              # (KSAMPLER.sample vouches for its run's noise: assume_static_noise)
+                self.noise = t.zeros_like(self.noise) if arg % 2 else self.noise.zero_()
+        elif name == "hyper":
+            self.hyper = dict(lamb=(5.0, 3.0, 7.5)[arg % 3], beta=(1.0, 0.7)[arg % 2], step=(0.2, 0.15, 0.3)[(arg // 2) % 3])
+            self.engine.chara_lamb, self.engine.chara_beta, self.engine.step_size = self.hyper["lamb"], self.hyper["beta"], self.hyper["step"]
+            self.oracle.lamb, self.oracle.beta, self.oracle.step_size = self.hyper["lamb"], self.hyper["beta"], self.hyper["step"]
+        elif name == "n_steps":
+            self.n_steps = (1, 2, 3, 5, 0)[arg % 5]
+        elif name == "inference":
+            self.inference = not self.inference
+        elif name == "early_stop":
+            if self.rng == "torch":                        # (the oracle-side draw order of a watched Philox loop differs per launch form)
+                self.es = not self.es
+                self.options = dict(self.options)
+                if self.es:
+                    self.options["lanpaint_semantic_stop"] = {"threshold": (1e-30, 1e6)[arg % 2], "patience": 1 + arg % 2}
+                else:
+                    self.options.pop("lanpaint_semantic_stop", None)
+        elif name == "x_new":
+            self.x = self.x.clone()
+        elif name == "jump":
+            self.pos = arg % (N_SIG - 1)
+        elif name == "options_new":
+            self.options = dict(self.options)
+
+    def _philox(self, seq, slot, n_el):
+        from lanpaint_amd import _cabi
+        t = self.torch
+        out = t.empty(n_el, dtype=t.float32, device=DEV)
+        _cabi.check(_cabi.load().lp_philox_normal(out.data_ptr(), n_el, 11, seq, slot, t.cuda.current_stream().cuda_stream), "lp_philox_normal")
+        return _np(out).reshape(self.shape)
+
+    def call(self, step_no):
+        t = self.torch
+        dev = t.device("cuda", 0)
+        i = self.pos
+        s_np = np.full((self.shape[0],), self.sig[i], dtype=np.float32)
+        sigma = self._dev(s_np)
+        times_np = orc.times_from_sigma(s_np, self.flow)
+        if self.node:
+            n = orc.effective_inner_steps(self.n_steps_node(), self.sig, float(s_np[0]), float(times_np[1].mean()), 1, 1.0)
+        else:
+            n = self.n_steps
+        x_before = _np(self.x).copy()
+        zero_noise = float(self.noise.abs().mean()) < 1e-8
+        per_call = max(0, 2 * n - 1)
+        draws = []
+        if self.rng == "torch":
+            state = t.cuda.get_rng_state(dev)
+            if zero_noise:
+                draws.append(_np(t.randn(self.shape, device=DEV)))
+            draws += [_np(t.randn(self.shape, device=DEV)) for _ in range(per_call)]
+            t.cuda.set_rng_state(state, dev)
+        else:
+            if zero_noise:                                  # (the regenerated noise is a torch.randn_like draw in every mode)
+                state = t.cuda.get_rng_state(dev)
+                draws.append(_np(t.randn(self.shape, device=DEV)))
+                t.cuda.set_rng_state(state, dev)
+            c0, p0 = self.engine.rng_position(dev)
+        mo = self.options if (self.options or self.node) else None
+        with (t.inference_mode() if self.inference else contextlib.nullcontext()):
+            if self.node:
+                out = self.k(self.x, sigma, self.mask, model_options=self.options, seed=0)
+            else:
+                times = tuple(self._dev(v) for v in times_np)
+                out = self.engine(self.x, self.y, self.noise, sigma, self.mask, times, mo, 0, n_steps=n)
+        _ = self.engine.iterations_run                      # (a replayed early-stop loop reports its length on request)
+        ran = self.engine.last_inner_steps
+        if self.rng == "philox":
+            c1, p1 = self.engine.rng_position(dev)
+            base = c0 if c1 != c0 else (1 << 48) + p0         # replayed launches: device-side counter; eager ones: 2^48 + host count
+            n_el = int(np.prod(self.shape))
+            draws += [self._philox(base + kk // 2, kk % 2, n_el) for kk in range(per_call)]
+        self.oracle_draws[:] = draws
+        self.oracle.n_steps = n
+        xo = x_before.copy()
+        it0 = self.oracle.iterations_run
+        out_o = self.oracle(xo, _np(self.y), _np(self.noise), s_np, self.latent_mask_np(), times_np,
+                            self.options if self.es else None, 0, n_steps=n)
+        ran_o = self.oracle.iterations_run - it0
+        what = f"step {step_no} ({self.mode}/{self.rng}, sigma[{i}], n={n}, es={self.es}, inference={self.inference})"
+        if self.rng == "torch":                             # the generator stands where the reference leaves it: what the oracle consumed
+            used = len(draws) - len(self.oracle_draws)
+            state_after = t.cuda.get_rng_state(dev)
+            t.cuda.set_rng_state(state, dev)
+            for _ in range(used):
+                t.randn(self.shape, device=DEV)
+            assert t.equal(t.cuda.get_rng_state(dev), state_after), f"{what}: generator state"
+        assert ran == ran_o and (self.es or ran == n), f"{what}: iterations {ran} (engine) vs {ran_o} (oracle), n = {n}"
+        _close(_np(out), out_o, f"{what}: out")
+        _close(_np(self.x), xo, f"{what}: in-place x")
+        # Euler update between sigma calls, then on along the schedule
+        if i + 1 < N_SIG:
+            r = float(self.sig[i + 1] / self.sig[i]) if self.sig[i] != 0 else 0.0
+            with (t.inference_mode() if self.inference else contextlib.nullcontext()):
+                self.x = t.lerp(out, self.x, r)
+        self.pos = min(i + 1, N_SIG - 2)
+
+    def n_steps_node(self):
+        return self.engine.n_steps
+
+
+def _run_sequence(mode, rng, shape_i, flow, packed, events, seed):
+    job = _Job(mode, rng, SHAPES[shape_i % len(SHAPES)], flow, packed, seed)
+    calls = 0
+    for step_no, (name, arg) in enumerate(events):
+        if name == "call":
+            job.call(step_no)
+            calls += 1
+        else:
+            job.event(name, arg)
+    job.call(len(events))                                   # every sequence ends on a call that sees the last events
+    job.torch.cuda.synchronize()
+    return job
+
+
+_events = st.lists(st.tuples(st.sampled_from(EVENTS), st.integers(0, 1000)), min_size=6, max_size=18)
+_common = dict(max_examples=100, deadline=None, derandomize=True, database=None,
+               suppress_health_check=list(HealthCheck))
+
+
+@pytest.fixture(autouse=True)
+def _defaults(monkeypatch):
+    for var in ("LANPAINT_AMD_GRAPH", "LANPAINT_AMD_RNG", "LANPAINT_AMD_AUTO_PACK"):
+        monkeypatch.delenv(var, raising=False)
+
+
+@settings(**_common)
+@given(_events, st.integers(0, 3), st.booleans(), st.booleans(), st.integers(0, 2 ** 16))
+def test_random_event_sequences_default_engine(events, shape_i, flow, packed, seed):
+    """graph="auto", rng="torch": what an engine built with no optional keyword does."""
+    _run_sequence("auto", "torch", shape_i, flow, packed, events, seed)
+
+
+@settings(**_common)
+@given(_events, st.integers(0, 3), st.booleans(), st.booleans(), st.sampled_from(["torch", "philox"]), st.integers(0, 2 ** 16))
+def test_random_event_sequences_forced_graphs(events, shape_i, flow, packed, rng, seed):
+    """graph=True: every sigma call captured on first sight and replayed."""
+    _run_sequence("graph", rng, shape_i, flow, packed, events, seed)
+
+
+@settings(**_common)
+@given(_events, st.integers(0, 3), st.booleans(), st.booleans(), st.sampled_from(["torch", "philox"]), st.integers(0, 2 ** 16))
+def test_random_event_sequences_eager_launches(events, shape_i, flow, packed, rng, seed):
+    _run_sequence("eager", rng, shape_i, flow, packed, events, seed)
+
+
+@settings(**_common)
+@given(_events, st.integers(0, 3), st.booleans(), st.sampled_from(["torch", "philox"]), st.integers(0, 2 ** 16))
+def test_random_event_sequences_behind_the_sampler_callable(events, shape_i, flow, rng, seed):
+    """KSamplerX0Inpaint: the split-phase node path (replace launch before the host knows n_eff, speculated counts, one FFI
+    trip per sigma call) with ComfyUI's denoise_mask as the mask the events rewrite."""
+    _run_sequence("node", rng, shape_i, flow, False, events, seed)
+
+
+@pytest.mark.parametrize("mode,rng", [("auto", "torch"), ("graph", "philox"), ("graph", "torch"), ("node", "torch"), ("node", "philox")])
+def test_the_walk_really_replays_graphs(mode, rng):
+    """The property tests above are only worth something if the sequences reach the machinery: one fixed walk per mode --
+    steady calls, then every kind of event, then steady calls again -- must have captured sigma calls, replayed them (the Python
+    backbone is not called by a replay) and re-captured after the events that change what a capture bakes in."""
+    events = [("call", 0)] * 4 + [("mask_inplace", 1), ("call", 0), ("call", 0), ("hyper", 4), ("call", 0), ("call", 0), ("mask_new", 0),
+                                  ("call", 0), ("call", 0), ("inference", 0), ("mask_new", 0), ("call", 0), ("call", 0), ("mask_inplace", 3),
+                                  ("call", 0), ("x_new", 0), ("call", 0), ("early_stop", 1), ("call", 0), ("call", 0), ("early_stop", 0),
+                                  ("n_steps", 3), ("call", 0), ("call", 0), ("noise_rewrite", 0), ("call", 0), ("options_new", 0), ("call", 0)]
+    job = _run_sequence(mode, rng, 0, mode == "node", mode == "graph", events, 5)
+    eng = job.engine
+    n_calls = sum(1 for e in events if e[0] == "call") + 1
+    assert len(eng._graphs) >= 2, len(eng._graphs)                        # captured, and captured again after the events
+    assert job.model.calls < n_calls * (5 + 1) + 40                       # most calls were replays: the Python backbone was not called
+    assert eng.iterations_run > 0 and not eng._graph_blocked
+
+
+# ---- regression cases: sequences that once failed, kept verbatim (mode, rng, shape index, flow, packed, events, seed) -----------
+REGRESSIONS = [
+    ("graph", "torch", 1, True, True, [("call", 0), ("call", 0), ("noise_zero", 0), ("call", 0), ("call", 0), ("noise_rewrite", 0),
+                                       ("call", 0), ("inference", 0), ("mask_new", 0), ("call", 0), ("mask_inplace", 2), ("call", 0)], 3),
+]
+
+
+@pytest.mark.parametrize("case", REGRESSIONS)
+def test_regression_sequences(case):
+    _run_sequence(*case)
+
+
+def test_the_walk_has_teeth():
+    """A check that cannot fail proves nothing: tell only the ENGINE about a hyper-parameter change (the oracle keeps the old
+    value) and the very next call must be flagged; likewise a mask rewritten behind the oracle's back."""
+    job = _Job("graph", "torch", SHAPES[0], False, True, 1)
+    job.call(0)
+    job.call(1)
+    job.engine.chara_lamb = 3.0
+    with pytest.raises(AssertionError, match="max abs err"):
+        job.call(2)
+    job.oracle.lamb = 3.0
+    job.call(3)                                               # in step again
+    real = job.latent_mask_np
+    job.latent_mask_np = lambda: 1.0 - real()
+    with pytest.raises(AssertionError, match="max abs err"):
+        job.call(4)
