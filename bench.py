@@ -217,7 +217,7 @@ class Bf16StubOracle:
         return _bf16_round(xb * self.s0), _bf16_round(xb * self.s1)
 
 
-def parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow, max_sigmas=None):
+def parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow, max_sigmas=None, oracle_model=None):
     """ONE schedule pass of the engine that is about to be timed -- same object, same launch mode (graph replay / eager),
     same noise generator, same mask format -- in lockstep with the CPU oracle (oracle/lanpaint_oracle.py, the checker) fed
     the very draws the engine's kernels generate:
@@ -243,8 +243,11 @@ def parity_check(engine, x0, y, noise, mask, sig_list, times_list, ratios, n_thi
 
     seed = int(engine.philox_seed if engine.philox_seed is not None else 0) & 0xFFFFFFFFFFFFFFFF
     draws = []
-    model = StubBackbone(flow) if engine.model_dtype is None else Bf16StubOracle(flow, n_el)
-    assert engine.model_dtype in (None, torch.bfloat16), "parity_check restates the stub for fp32 and bf16 backbones"
+    if oracle_model is not None:          # a caller-supplied restatement of the backbone (e.g. SDXLShapedBackbone.as_oracle_model())
+        model = oracle_model
+    else:
+        model = StubBackbone(flow) if engine.model_dtype is None else Bf16StubOracle(flow, n_el)
+        assert engine.model_dtype in (None, torch.bfloat16), "parity_check restates the stub for fp32 and bf16 backbones"
     oracle = OracleLanPaint(model, n_think, HYPER["Friction"], float(engine.chara_lamb), float(engine.chara_beta),
                             float(engine.step_size), is_flow=flow, min_step_frac=float(engine.min_step_frac),
                             randn=lambda like: draws.pop(0))
@@ -1181,6 +1184,67 @@ def extra_lines(args, dev):
         "note": "C2 through KSamplerX0Inpaint, MinStepFrac=1.0, EarlyStop=1 (n_eff = round(5(1-abt)), last sigma 0); "
                 "the n_eff rule needs sigma's position from the device once per sigma: one call into the library per sigma "
                 "(lp_node_call) queues the call for a speculated count, the device checks the guess and voids a miss"}
+    # ---- BASELINE configs[1] / [3] with a backbone that exercises what the path was built for (round 5): SDXL 1x4x128x128, a
+    # random-init SDXL-SHAPED bf16 stand-in (three levels of ResBlocks, self- + cross-attention at 32 x 32: MIOpen / hipBLASLt /
+    # SDPA on the matrix cores), ONE batched cond + uncond pass per call, FusedCFGHeads (the kernels form both CFG heads from the
+    # bf16 predictions) and model_dtype = bf16 (x_in emitted as bf16).  Parity against the oracle driving the same module
+    # (tests/sdxl_standin.py::as_oracle_model), then it/s and where a sigma call's time goes: the same number of backbone passes
+    # alone (one hipGraph of n + 1 forwards) against the whole call.
+    try:
+        from tests.sdxl_standin import SDXLShapedBackbone
+        shape, flow, n_sig, n_think = WORKLOADS["c2_sdxl"]
+        sig_np = karras_sigmas(n_sig)
+        x0, y, noise, mask = make_inputs(shape, flow, float(sig_np[0]), args.seed, dev, tt)
+        mask = attach_mask_format(mask, args.mask_format)
+        sig_list = [torch.full((1,), float(s), dtype=torch.float32, device=dev) for s in sig_np]
+        times_list = [times_from_sigma(s, flow) for s in sig_list]
+        ratios = euler_ratios(sig_list, 4)
+        net = SDXLShapedBackbone(dev, flow=flow)
+        eng = LanPaint(net, n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"], rng=args.rng,
+                       philox_seed=args.seed, graph=bool(args.graph), model_dtype=torch.bfloat16)
+        par = parity_check(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think, flow, max_sigmas=10,
+                           oracle_model=net.as_oracle_model())
+        for _ in range(2):
+            schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        torch.cuda.synchronize()
+        it0, t0, reps = eng.iterations_run, time.perf_counter(), 3
+        for _ in range(reps):
+            xl = schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        call_ms = 1e3 * dt / (reps * n_sig)
+        # the backbone alone: n_think + 1 forward passes per sigma call, captured like the engine captures them
+        xin = x0.to(torch.bfloat16)
+        gb, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=dev)
+        for _ in range(2):
+            net.predict(xin, sig_list[3])
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.graph(gb, stream=side):
+            for _ in range(n_think + 1):
+                keep = net.predict(xin, sig_list[3])
+        for _ in range(3):
+            gb.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            gb.replay()
+        torch.cuda.synchronize()
+        bb_ms = 1e3 * (time.perf_counter() - t0) / 30
+        del keep
+        out["sdxl_shaped_backbone"] = {
+            "value": (eng.iterations_run - it0) / dt if par["ok"] else None, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
+            "sigma_call_ms": call_ms, "backbone_only_ms_per_sigma_call": bb_ms, "backbone_passes_per_sigma_call": n_think + 1,
+            "langevin_path_ms_per_sigma_call": call_ms - bb_ms, "langevin_path_share_of_sigma_call": (call_ms - bb_ms) / call_ms,
+            "finite": bool(torch.isfinite(xl).all()), "captured_calls": len(eng._graphs), "backbone_parameters": net.n_params,
+            "parity_check": {k: par[k] for k in ("mse_x", "mse_denoised_max", "ok", "sigmas_checked", "launch_modes")},
+            "kernel_flags": "LP_FL_CFG_FUSED | LP_FL_X0_BF16 | LP_FL_XIN_BF16 | LP_FL_MASK_BITS",
+            "backbone": "tests/sdxl_standin.py: random-init SDXL-shaped UNet stand-in (128/256/512 channels at 128/64/32 px, GroupNorm-SiLU-conv "
+                        "ResBlocks, self-attention over 1024 tokens + cross-attention to [77, 2048] text states, ADM vector [2816]), "
+                        "bf16, one batched cond + uncond pass per call, latent 1x4x128x128, 30 sigmas x 5 (BASELINE configs[1]); "
+                        "MFMA-busy of its kernels vs the lp:: kernels: profiles/r05_sdxl_standin_pmc_mfma.md"}
+        torch.cuda.empty_cache()
+    except Exception as e:                       # the stand-in is not a deliverable; never fail the bench on it
+        out["sdxl_shaped_backbone"] = {"error": repr(e)}
     # ---- dummy UNet backbone on the SD1.5 shape
     try:
         from tests.dummy_unet import DummyUNetBackbone

@@ -139,3 +139,30 @@ def test_bf16_backbone_configuration_against_the_oracle(workload, max_sigmas):
     r = _check(job, eng, max_sigmas=max_sigmas)
     assert r["ok"] and r["mse_x"] < 1e-5 and r["mse_denoised_max"] < 1e-5, r      # (measured 2e-8 / 2e-6: a few one-ulp bf16 flips
     assert set(r["launch_modes"]) == {"graph"}                                       # at |x| ~ 15, the first sigma of the schedule)
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_sdxl_shaped_bf16_backbone_with_fused_cfg_heads_against_the_oracle(graph):
+    """BASELINE configs[1] / [3] behind a backbone that exercises the matrix cores (round 5): the SDXL-shaped bf16 stand-in
+    (tests/sdxl_standin.py: ResBlocks at 128 / 64 / 32 px, self- + cross-attention over 1024 tokens), one batched cond + uncond
+    pass per call handed over as FusedCFGHeads, model_dtype = bf16 -- i.e. the kernels read two bf16 predictions, form both CFG
+    heads themselves and emit the next input as bf16.  Against the oracle driving the SAME module with the reference's eager
+    cfg_function form; bound: BASELINE's MSE < 1e-5 (a bf16 rounding that flips on an fp32 last-bit difference moves the
+    backbone's input by one bf16 ulp)."""
+    import torch
+    import bench
+    from lanpaint_amd import LanPaint, _cabi
+    from tests.sdxl_standin import SDXLShapedBackbone
+    job = _job("c2_sdxl", "bits")
+    net = SDXLShapedBackbone(torch.device("cuda", 0))
+    h = bench.HYPER
+    eng = LanPaint(net, job["n_think"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], rng="philox", philox_seed=9,
+                   graph=graph, model_dtype=torch.bfloat16)
+    r = bench.parity_check(eng, job["x0"], job["y"], job["noise"], job["mask"], job["sig_list"], job["times_list"], job["ratios"],
+                           job["n_think"], job["flow"], max_sigmas=4, oracle_model=net.as_oracle_model())
+    assert r["ok"] and r["mse_x"] < 1e-5 and r["mse_denoised_max"] < 1e-5, r
+    assert set(r["launch_modes"]) == {"graph" if graph else "eager"}
+    fl = eng._desc.flags if not graph else next(iter(eng._graphs.values())).keep.base_flags
+    if not graph:       # the think-loop launches really took the fused-CFG, half-width forms
+        assert fl & _cabi.LP_FL_CFG_FUSED and fl & _cabi.LP_FL_X0_BF16 and fl & _cabi.LP_FL_MASK_BITS
+    assert net.calls >= 4 * (job["n_think"] + 1) if not graph else net.calls > 0
