@@ -9,7 +9,13 @@ smallest nn.Module that exercises what the Langevin path was built to sit behind
   * ONE batched cond + uncond pass per call: the latent is doubled along the batch axis, the two halves differ only in their
     conditioning, and the call returns `FusedCFGHeads(cond, uncond, scale, scale_BIG)` -- what
     `lanpaint_amd.nodes.sampling_function_LanPaint` returns for ComfyUI's stock cfg_function -- so the step kernel forms both
-    CFG heads itself from bf16 outputs (LP_FL_CFG_FUSED | LP_FL_X0_BF16) and emits the next input as bf16 (LP_FL_XIN_BF16).
+    CFG heads itself (LP_FL_CFG_FUSED),
+  * ComfyUI's data flow around the network (comfy/model_base.py BaseModel.apply_model): the latent is cast to the network's
+    dtype on the way in, the network's output comes back as fp32 and the denoised prediction x0 = c_skip x + c_out eps is
+    formed in fp32 from the fp32 latent -- the predictions the Langevin path receives are fp32 tensors.  (`half_out=True`
+    instead rounds the predictions to the network's dtype -- LP_FL_X0_BF16 next to an engine with model_dtype = bf16,
+    LP_FL_XIN_BF16: every stream half-width.  At sigma ~ 14 a latent value is ~ 60, where bf16 resolves 0.25: such a run is
+    precision-limited by its own storage format, whoever computes the Langevin step.)
 
 The same object serves the oracle side of the parity check through `as_oracle_model()`: numpy in, the identical module on the
 device, the reference's eager `uncond + (cond - uncond) * scale` twice (nodes.py:161-175 with ComfyUI's cfg_function), numpy out.
@@ -120,12 +126,12 @@ class SDXLShapedBackbone:
     batched cond + uncond pass, the x0 predictions of both halves, CFG left to the consumer (FusedCFGHeads)."""
 
     def __init__(self, device, flow=False, dtype=torch.bfloat16, seed=0, cfg_scale=5.0, cfg_scale_big=8.0, fused=True,
-                 channels=(128, 256, 512)):
+                 channels=(128, 256, 512), half_out=False):
         from lanpaint_amd.types import FusedCFGHeads
         self._heads_type = FusedCFGHeads
         self.inner_model = self
         self.model_sampling = _Sampling(flow)
-        self.device, self.dtype, self.flow, self.fused = device, dtype, flow, fused
+        self.device, self.dtype, self.flow, self.fused, self.half_out = device, dtype, flow, fused, half_out
         self.net = SDXLShapedNet(ch=channels, seed=seed).to(device=device, dtype=dtype).eval()
         g = torch.Generator().manual_seed(1000 + seed)
         self.ctx = torch.randn((1, 77, 2048), generator=g).to(device=device, dtype=dtype)          # SDXL text states
@@ -136,23 +142,24 @@ class SDXLShapedBackbone:
 
     @torch.no_grad()
     def predict(self, x, t):
-        """(cond, uncond) x0 predictions, bf16, from ONE pass over the doubled batch (cond half: the text states; uncond half:
-        zeros -- ComfyUI's calc_cond_batch concatenates the two the same way)."""
+        """(cond, uncond) x0 predictions from ONE pass over the doubled batch (cond half: the text states; uncond half: zeros --
+        ComfyUI's calc_cond_batch concatenates the two the same way); fp32 unless `half_out`."""
         b = x.shape[0]
         sig = t.reshape(-1).float()
         sig = sig.expand(b) if sig.numel() == 1 else sig
-        xin = x.to(self.dtype)
+        x32 = x.float()
         if self.flow:
-            c_in, c_skip, c_out = torch.ones_like(sig), torch.ones_like(sig), -sig                  # x0 = x - t * v
+            c_in, c_out = torch.ones_like(sig), -sig                                               # x0 = x - t * v
         else:
-            c_in = 1.0 / (sig ** 2 + 1.0).sqrt()                                                   # EPS parameterisation: x0 = x - sigma * eps
-            c_skip, c_out = torch.ones_like(sig), -sig
-        v = lambda a: a.reshape(-1, 1, 1, 1).to(self.dtype)                                        # noqa: E731
-        x2 = torch.cat([xin * v(c_in), xin * v(c_in)], dim=0)
+            c_in, c_out = 1.0 / (sig ** 2 + 1.0).sqrt(), -sig                                      # EPS: x0 = x - sigma * eps
+        v = lambda a: a.reshape(-1, 1, 1, 1)                                                        # noqa: E731
+        net_in = (x32 * v(c_in)).to(self.dtype)
         ctx = torch.cat([self.ctx.expand(b, -1, -1), torch.zeros_like(self.ctx).expand(b, -1, -1)], dim=0)
         adm = torch.cat([self.adm.expand(b, -1), torch.zeros_like(self.adm).expand(b, -1)], dim=0)
-        out = self.net(x2, torch.cat([sig, sig]), ctx, adm)
-        x0 = torch.cat([xin, xin], dim=0) * v(torch.cat([c_skip, c_skip])) + out * v(torch.cat([c_out, c_out])) * 0.25
+        eps = self.net(torch.cat([net_in, net_in], dim=0), torch.cat([sig, sig]), ctx, adm).float()
+        x0 = torch.cat([x32, x32], dim=0) + eps * v(torch.cat([c_out, c_out])) * 0.25
+        if self.half_out:
+            x0 = x0.to(self.dtype)
         return x0[:b], x0[b:]
 
     def __call__(self, x, t, model_options=None, seed=None):
@@ -163,10 +170,10 @@ class SDXLShapedBackbone:
         diff = cond - uncond                                                                          # the reference's eager form
         return uncond + diff * self.scale, uncond + diff * self.scale_big
 
-    def as_oracle_model(self):
-        """The oracle's view of the same backbone: numpy fp32 in; the input rounded to bf16 as the kernel's emit / the final
-        call's cast do; the identical module on the device; the reference's eager CFG combination in the module's dtype
-        (what `cfg_function` computes on bf16 tensors); numpy fp32 out."""
+    def as_oracle_model(self, input_dtype=None):
+        """The oracle's view of the same backbone: numpy fp32 in (rounded to `input_dtype` first when the engine emits its
+        model-space latent in that dtype: model_dtype); the identical module on the device; the reference's eager CFG
+        combination `uncond + (cond - uncond) * scale`, twice (nodes.py:161-175 with ComfyUI's cfg_function); numpy fp32 out."""
         outer = self
 
         class _OracleModel:
@@ -177,10 +184,12 @@ class SDXLShapedBackbone:
 
             def __call__(self, x, t, model_options=None, seed=None):
                 self.calls += 1
-                xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(outer.device).to(outer.dtype)
+                xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(outer.device)
+                if input_dtype is not None:
+                    xt = xt.to(input_dtype)
                 tt = torch.from_numpy(np.ascontiguousarray(np.asarray(t, dtype=np.float32).reshape(-1))).to(outer.device)
                 cond, uncond = outer.predict(xt, tt)
-                diff = cond.float() - uncond.float()                # the kernel forms the heads in fp32 from the bf16 predictions
+                diff = cond.float() - uncond.float()
                 h0 = uncond.float() + diff * outer.scale
                 h1 = uncond.float() + diff * outer.scale_big
                 return h0.cpu().numpy(), h1.cpu().numpy()
