@@ -183,5 +183,5 @@ def test_sdxl_shaped_backbone_with_fused_cfg_heads_against_the_oracle(graph):
                            job["n_think"], job["flow"], max_sigmas=3, oracle_model=net.as_oracle_model(input_dtype=torch.bfloat16))
     assert np.isfinite(r["mse_x"]) and r["mse_x"] <= max(1e-5, 50.0 * noise_floor) and r["mse_x"] < 0.5, (r["mse_x"], noise_floor)
     if not graph:
-        fl = eng._desc.flags
-        assert fl & _cabi.LP_FL_CFG_FUSED and fl & _cabi.LP_FL_X0_BF16 and fl & _cabi.LP_FL_XIN_BF16
+        fl = eng._desc.flags           # (of the call's LAST think launch, whose emit is the fp32 x that is written back: no XIN flag there)
+        assert fl & _cabi.LP_FL_CFG_FUSED and fl & _cabi.LP_FL_X0_BF16 and eng.model_dtype == torch.bfloat16
