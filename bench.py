@@ -682,7 +682,8 @@ def steady_kernel_name(workload, rng, mask_format):
     strided = rng == "torch" and vec == 4 and WORKLOADS[workload][0][0] == 1
     return (f"lp::lp_step_kernel<{vec}, {2 if mask_format == 'bits' else 0}, 28u, 4, {1 if rng == 'torch' else 0}, "
             f"{'true' if strided else 'false'}, 0>  (VEC, MODE: 2 = bit-packed hard mask, PH 28 = POST_STEADY|PRE_HALF|EMIT, "
-            "fp32 backbone outputs, RNG: 0 = Philox 1 = torch stream, ATen-strided lanes, early stop: 0 = off 1 = on "
+            "fp32 backbone outputs, RNG: 0 = Philox 1 = torch stream, ST: generation in ATen's thread order with the values transposed "
+            "through LDS (round 5; the reference's stream past ATen's grid cap), early stop: 0 = off 1 = on "
             "2 = on with the verdict folded into the launch)")
 
 
@@ -957,10 +958,11 @@ def measure_hbm_bound_shape(_cabi, dev, workload="c5_wan", launches=100, every_s
                 "mean_launch_us": event_us, "median_launch_us": float(np.median(durs)) * 1e6,
                 "min_launch_us": float(durs.min()) * 1e6, "launches_timed": int(durs.size), "warm_burst_s": warm_s,
                 "warm_burst_launches": warmed, "committed_profile": committed_profile(prof_key),
-                "limiter_note": ("streaming sizes: the launch is co-limited by VALU issue, not by HBM alone -- SQ counters of this "
-                                 "kernel (profiles/r04_sq_*.md before, r04_after_sq_*.md after round 4's reductions): 538 -> 366 VALU "
-                                 "instructions per wave with fp32 heads (631 -> 417 with bf16 heads), SQ_INSTS_VMEM 7.4 per wave; "
-                                 "x 4 cycles x waves / 1024 SIMDs = 275 k of a 330 k-cycle launch before, 187 k after")
+                "limiter_note": ("streaming sizes: the launch is co-limited by VALU issue, not by HBM alone -- SQ_INSTS_VALU / SQ_WAVES of this "
+                                 "kernel: 538 (round 3) -> 326 (round 4) -> 216 per wave in round 5 with fp32 heads, 631 -> 375 -> 267 with "
+                                 "bf16 heads, 585 -> 322 with the reference's noise stream (profiles/r05_sq_*.log / .md); rocprofv3 mean per "
+                                 "dispatch, same box against the round-4 library: 8.45 -> 7.88 us, 8.54 -> 7.84, 11.6 -> 10.2 "
+                                 "(profiles/r05_ab_r04_vs_r05_*.log)")
                 if n_el > 512 * 1024 else None})
     return out
 
