@@ -1257,6 +1257,32 @@ class LanPaint:
             state[4] = 1          # [4]: "this sigma call is valid" -- 0 voids a captured lp_finalize (a speculated call, lp_node_call)
         return state
 
+    _capture_state_ready = set()
+
+    @classmethod
+    def _warm_capture_state(cls, dev):
+        """Once per device, before this process's first capture through the engine: a trivial capture OUTSIDE inference mode.
+        torch creates the device generator's graph-capture state (its seed / offset tensors) at the first capture of the process
+        and updates it in place at every later `capture_begin`.  Created under torch.inference_mode() -- how ComfyUI runs its
+        nodes -- they are inference tensors, and the first capture attempted outside inference mode afterwards dies inside
+        capture_begin on that in-place update, leaving the generator in its capturing state (every later torch.randn of the
+        process then raises "Offset increment outside graph capture").  Found by the property test of the capture state machine
+        (tests/test_gpu_state_machine.py); as normal tensors the state can be updated from either mode."""
+        if dev.index in cls._capture_state_ready:
+            return
+        cls._capture_state_ready.add(dev.index)
+        try:
+            with torch.inference_mode(False), torch.no_grad():
+                g = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream(device=dev)
+                s.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                    torch.zeros(1, device=dev)
+                torch.cuda.current_stream(dev).wait_stream(s)
+                del g
+        except Exception:          # (a torch build that refuses: the engine's own captures will say why)
+            pass
+
     def _capture(self, key, x, sigma, latent_mask, current_times, n_steps, model_options, seed, IS_FLUX, IS_FLOW,
                  replace_in_graph=None):
         """Capture one sigma call.  `replace_in_graph` (default: on, LANPAINT_AMD_REPLACE_IN_GRAPH=0 turns it off): the
@@ -1266,6 +1292,7 @@ class LanPaint:
         raw graph handles and a call the steady-state path takes (dense fp32 tensors, a fusable replace form); anything
         else is captured the round-2 way, with the replace launch outside the graph."""
         dev = x.device
+        self._warm_capture_state(dev)
         if replace_in_graph is None:
             replace_in_graph = os.environ.get("LANPAINT_AMD_REPLACE_IN_GRAPH", "1") != "0"
         raw_ok = self.rng in ("philox", "torch") and os.environ.get("LANPAINT_AMD_RAW_GRAPH", "1") != "0"

@@ -330,3 +330,47 @@ def test_the_walk_has_teeth():
     job.latent_mask_np = lambda: 1.0 - real()
     with pytest.raises(AssertionError, match="max abs err"):
         job.call(4)
+
+
+def test_first_capture_under_inference_mode_does_not_poison_later_captures():
+    """Counter-example found by the walks above when they ran late in the whole suite (kept as a regression case): torch creates
+    the device generator's graph-capture state at the FIRST capture of the process; made under torch.inference_mode() those
+    tensors are inference tensors, the first capture attempted OUTSIDE inference mode afterwards dies inside capture_begin on
+    their in-place update, and the generator stays "capturing" (every later torch.randn raises).  The engine now registers that
+    state itself, outside inference mode, before its first capture.  In a fresh process: capture under inference mode, then
+    outside, then draw from the generator."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch
+from lanpaint_amd import LanPaint
+from tests.test_gpu_state_machine import _Model
+def run(inference):
+    dev = "cuda"
+    with (torch.inference_mode() if inference else torch.no_grad()):
+        g = torch.Generator(device="cpu").manual_seed(3)
+        y, noise = torch.randn((1, 4, 16, 16), generator=g).to(dev), torch.randn((1, 4, 16, 16), generator=g).to(dev)
+        mask = (torch.rand((1, 4, 16, 16), generator=g) > 0.5).float().to(dev)
+        eng = LanPaint(_Model(False), 3, 15.0, 5.0, 1.0, 0.2, graph=True)
+        x = (y + noise * 2.0).clone()
+        for _ in range(3):
+            s = torch.full((1,), 2.0, device=dev)
+            out = eng(x, y, noise, s, mask, (s, 1 / (1 + s ** 2), s / (1 + s)), None, 0)
+        torch.cuda.synchronize()
+        return len(eng._graphs), bool(torch.isfinite(out).all())
+a = run(True)
+b = run(False)
+c = run(True)
+z = torch.randn(8, device="cuda")
+print(json.dumps({"graphs": [a[0], b[0], c[0]], "finite": [a[1], b[1], c[1]], "randn_ok": bool(torch.isfinite(z).all())}))
+''' % root
+    env = {k: v for k, v in os.environ.items() if k not in ("LANPAINT_AMD_GRAPH", "LANPAINT_AMD_RNG")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["graphs"] == [1, 1, 1] and all(rec["finite"]) and rec["randn_ok"], rec
