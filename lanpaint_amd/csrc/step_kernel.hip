@@ -1085,7 +1085,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 } else {
                     sc = row_scale_of(k);
                 }
-                xt[k] = flow ? xr * sc : xr / sc;
+                if constexpr (VEC == 4 && !PER_EL && PH != 0) {
+                    // streaming replace launch of a VE model: the row's scale divides all four elements of the lane -- the reciprocal
+                    // formed once per lane above (rc.rscale) and one residual correction per element give the IEEE quotient
+                    // (div_shared: 11 + 4 x 3 instructions instead of 4 x 11; round 5, the last of round 4's listed candidates)
+                    xt[k] = flow ? xr * sc : div_shared(xr, sc, rc.rscale);
+                } else {
+                    xt[k] = flow ? xr * sc : xr / sc;
+                }
             }
         }
 

@@ -817,3 +817,38 @@ def test_shared_divisor_emit_equals_ieee_division(lib, phase):
     for name, a, b in zip(("x_t", "C", "x_in"), *res):
         assert torch.equal(a, b), name
     assert torch.isfinite(res[0][2]).all() and not torch.equal(res[0][2], torch.zeros_like(res[0][2]))
+
+
+def test_ve_replace_launch_shared_divisor_equals_ieee_division(lib):
+    """The VE replace launch `x_t = x / sqrt(1 + sigma^2)` (lanpaint.py:96-99) at 16 bytes per lane divides through
+    lp_common.h::div_shared with the reciprocal of the row's scale (round 5); one element per lane divides.  The same fused
+    replace + coefficient-table launch on an SDXL batch, both widths forced: bitwise equal x_t, model-space x_in and table."""
+    import torch
+    import bench
+    from lanpaint_amd import _cabi
+    dev = torch.device("cuda", 0)
+    ph = _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS
+    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
+    bench.MASK_KIND, bench.MASK_FORMAT = "box", "bits"
+    try:
+        d, keep, n_el = bench.standalone_step(_cabi, "c3_sdxl_b4", dev, ph)
+    finally:
+        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    bufs, _m, coef, sig, ve, abt = keep
+    bufs["x"].mul_(23.0)
+    d.t_ve, d.t_abt, d.t_rsig, d.t_ve_stride, d.t_abt_stride, d.t_rsig_stride = ve.data_ptr(), abt.data_ptr(), sig.data_ptr(), 1, 1, 1
+    d.coef_out = coef.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for tune in (_cabi.LP_TUNE_VEC4, _cabi.LP_TUNE_VEC1):
+        bufs["x_t"].zero_()
+        bufs["x_in"].zero_()
+        coef.zero_()
+        d.tune = tune
+        _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
+        torch.cuda.synchronize()
+        res.append([bufs["x_t"].clone(), bufs["x_in"].clone(), coef.clone()])
+    for name, a, b in zip(("x_t", "x_in", "coefficient table"), *res):
+        assert torch.equal(a, b), name
+    assert torch.isfinite(res[0][0]).all() and float(res[0][0].abs().max()) > 1.0
+    assert float(coef[0, _cabi.LP_C_RSCALE]) == 1.0 / float(coef[0, _cabi.LP_C_SCALE]) or abs(float(coef[0, _cabi.LP_C_RSCALE]) * float(coef[0, _cabi.LP_C_SCALE]) - 1.0) < 1e-6
