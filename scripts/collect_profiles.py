@@ -15,7 +15,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "profiles")
 DST = os.path.join(ROOT, "profiles")
 N_EL = {"c1": ("c1_sd15", 16384), "c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c4": ("c4_flux", 65536),
         "c5": ("c5_wan", 2096640), "xwanb16": ("x_wan_b16", 33546240), "xwanb16_noskip": ("x_wan_b16_every_stream", 33546240),
-        "c5_bf16": ("c5_wan_bf16", 2096640), "xwanb16_bf16": ("x_wan_b16_bf16", 33546240)}
+        "c5_bf16": ("c5_wan_bf16", 2096640), "xwanb16_bf16": ("x_wan_b16_bf16", 33546240), "c5_torch": ("c5_wan_torch", 2096640)}
 BYTES_PER_EL = {"c5_wan_bf16": 30, "x_wan_b16_bf16": 30}          # bf16 x0, x0_BIG in, bf16 x_in out; 36 otherwise
 
 

@@ -18,6 +18,9 @@ for wl in c3_sdxl_b4:c3 c5_wan:c5 x_wan_b16:xwanb16; do
   rocprofv3 --kernel-trace --stats -d /tmp/p_${wl#*:} -o t -- python $R/scripts/microbench_step.py ${wl%%:*} steady 50 > $OUT/${wl#*:}_microbench_under_rocprof.log 2>&1
   summ /tmp/p_${wl#*:}/t_results.db > $OUT/${wl#*:}_kernel_trace.md 2>&1
 done
+# the reference's noise stream (rng="torch", the engine default) at the video latent: ATen-ordered generation, LDS transpose (round 5)
+rocprofv3 --kernel-trace --stats -d /tmp/p_c5_torch -o t -- python $R/scripts/microbench_step.py c5_wan steady 50 torch > $OUT/c5_torch_microbench_under_rocprof.log 2>&1
+summ /tmp/p_c5_torch/t_results.db > $OUT/c5_torch_kernel_trace.md 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/p_c5b -o t -- python $R/bench.py --workload c5_wan --steps 4 --warmup 2 --repeats 0 --no-cpu-baseline --no-large-shape --extras 0 > $OUT/c5_bench_under_rocprof.json.log 2>&1
 summ /tmp/p_c5b/t_results.db > $OUT/c5_bench_kernel_trace.md 2>&1
 # the same past-L3 launch with every operand streamed regardless of the mask (region-aware streams off)
