@@ -119,3 +119,56 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "liblanpaint_oracle" not in src and "ref_engine" not in src and "_lanpaint_reference_engine" not in src, f
+
+
+def test_roofline_fraction_is_a_fraction_in_every_committed_round5_line():
+    """`roofline.frac` above 1 is not a roofline (round 4's C5 line printed 1.09: 36 B per element against a
+    launch that legitimately skips streams).  Every bench line committed from round 5 on carries 0 < frac <= 1 and
+    frac_counter <= 1 in its `roofline*` blocks; the every-operand figure lives in `frac_every_stream`."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_bench_*.json")))
+    assert files, "no committed round-5 bench lines under profiles/"
+
+    def blocks(line):
+        for key in ("roofline", "roofline_hbm_bound_shape", "roofline_hbm_past_l3"):
+            b = line.get(key)
+            if isinstance(b, dict) and "frac" in b:
+                yield key, b
+                if isinstance(b.get("region_aware_streams"), dict):
+                    yield key + ".region_aware_streams", b["region_aware_streams"]
+        for k, b in (line.get("bf16_heads") or {}).items():
+            if isinstance(b, dict) and "frac" in b:
+                yield "bf16_heads." + k, b
+
+    seen = 0
+    for f in files:
+        line = json.load(open(f))
+        for key, b in blocks(line):
+            seen += 1
+            assert 0.0 < b["frac"] <= 1.0, (os.path.basename(f), key, b["frac"])
+            assert b.get("frac_counter") is None or 0.0 < b["frac_counter"] <= 1.0, (os.path.basename(f), key)
+            assert b["algorithmic_bytes_per_launch"] <= b["every_stream_bytes_per_launch"] + 1e-6
+            assert b.get("traffic") is None or "committed_constant" in b["traffic_source"]
+    assert seen >= len(files)
+
+
+def test_steady_bytes_model():
+    """The bytes a steady launch REQUIRES (bench.steady_bytes_per_launch): SURVEY 8(d)'s 36 B with the mask's own width, and for
+    the region-aware launches (bit mask, > 512 Ki elements) the mask actually used."""
+    import numpy as np
+    import bench
+    half = np.zeros((1, 4, 8, 8), np.float32)
+    half[..., :4] = 1.0
+    r = bench.steady_bytes_per_launch(half, "f32", 65536)
+    assert r["bytes_per_element_every_stream"] == 36.0 and r["required"] == r["every_stream"] == 36 * 65536
+    r = bench.steady_bytes_per_launch(half, "bits", 65536)                       # latency-bound size: every operand streamed
+    assert r["bytes_per_element_required"] == 32.125 and not r["region_aware_launch"]
+    r = bench.steady_bytes_per_launch(half, "bits", 2096640)                     # streaming size, 50 % box
+    assert r["region_aware_launch"] and abs(r["bytes_per_element_required"] - 26.125) < 1e-9
+    assert r["bytes_per_element_every_stream"] == 32.125
+    mask = bench.make_mask((1, 16, 21, 60, 104), "temporal")                     # C5: latent frames >= 8 of 21 inpainted
+    r = bench.steady_bytes_per_launch(mask, "bits", 2096640)
+    assert abs(r["known_fraction"] - 8 / 21) < 1e-9 and abs(r["bytes_per_element_required"] - (20.125 + 4 * 13 / 21 + 8 * 8 / 21)) < 1e-9
+    assert bench.steady_bytes_per_launch(mask, "bits", 2096640, every_stream=True)["required"] == 32.125 * 2096640
+    r = bench.steady_bytes_per_launch(mask, "bits", 2096640, model_dtype="bf16")
+    assert r["bytes_per_element_every_stream"] == 26.125
