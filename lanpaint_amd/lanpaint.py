@@ -1362,6 +1362,16 @@ class LanPaint:
                                  replace_in_graph=False)
         self._iterations_run = it0
         self._capturing, self._cap_offset = counter, 0
+        # No cyclic garbage collection while the stream is capturing: a collection that happens to run inside the captured region
+        # finalises whatever unreachable objects the process holds -- among them other engines' captures, whose destructors destroy
+        # hipGraph / hipGraphExec handles and free their memory pools.  Those calls are illegal on a capturing thread; the error
+        # surfaces in a C++ destructor and aborts the process ("Fatal Python error: Aborted ... Garbage-collecting", met once in
+        # the 400-sequence property test, which leaves hundreds of dead engines behind).  torch collects BEFORE a capture; it
+        # cannot stop the collector from firing during one.  (Reference counting still frees what drops to zero: tensors go back
+        # to the caching allocator, which knows about captures.)
+        import gc
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
         try:
             # thread_local: a live RCCL communicator's watchdog thread issues HIP calls of its own;
             # in the default "global" mode those would invalidate this thread's capture
@@ -1381,6 +1391,8 @@ class LanPaint:
                     cap.final_in_graph = True
         finally:
             self._capturing = None
+            if gc_was_enabled:
+                gc.enable()
         cap.launches = self._cap_offset
         self._es_opts = es_user
         torch.cuda.set_rng_state(rng_state, dev)

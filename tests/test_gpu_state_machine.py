@@ -374,3 +374,47 @@ print(json.dumps({"graphs": [a[0], b[0], c[0]], "finite": [a[1], b[1], c[1]], "r
     assert p.returncode == 0, p.stderr[-3000:]
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["graphs"] == [1, 1, 1] and all(rec["finite"]) and rec["randn_ok"], rec
+
+
+def test_garbage_collection_during_a_capture_does_not_abort_the_process():
+    """Second counter-example the walks produced (once, late in the whole suite: "Fatal Python error: Aborted ... Garbage-collecting"
+    inside a captured backbone call): a cyclic collection that fires while the stream is capturing finalises other engines' dead
+    captures, whose destructors destroy graph handles and free memory pools -- illegal on a capturing thread, raised in a C++
+    destructor, process gone.  The engine now keeps the collector off for the captured region.  In a fresh process: dead engines
+    with captures tied into reference cycles, the collector set to fire at every opportunity, then more captures."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json, gc
+sys.path.insert(0, %r)
+import torch
+from lanpaint_amd import LanPaint
+from tests.test_gpu_state_machine import _Model
+dev = "cuda"
+g = torch.Generator(device="cpu").manual_seed(3)
+y, noise = torch.randn((1, 4, 16, 16), generator=g).to(dev), torch.randn((1, 4, 16, 16), generator=g).to(dev)
+mask = (torch.rand((1, 4, 16, 16), generator=g) > 0.5).float().to(dev)
+def job(n_steps):
+    eng = LanPaint(_Model(False), n_steps, 15.0, 5.0, 1.0, 0.2, graph=True)
+    x = (y + noise * 2.0).clone()
+    s = torch.full((1,), 2.0, device=dev)
+    for _ in range(2):
+        out = eng(x, y, noise, s, mask, (s, 1 / (1 + s ** 2), s / (1 + s)), None, 0)
+    cycle = [eng]
+    cycle.append(cycle)                      # unreachable only through a cycle: the collector's business, not the ref count's
+    return len(eng._graphs), bool(torch.isfinite(out).all())
+done = [job(2 + k %% 3) for k in range(6)]
+torch.cuda.synchronize()
+gc.set_threshold(1, 1, 1)                    # collect at every opportunity from here on
+done += [job(2 + k %% 3) for k in range(6)]
+torch.cuda.synchronize()
+print(json.dumps({"graphs": [d[0] for d in done], "finite": all(d[1] for d in done), "gc_enabled_after": gc.isenabled()}))
+''' % root
+    env = {k: v for k, v in os.environ.items() if k not in ("LANPAINT_AMD_GRAPH", "LANPAINT_AMD_RNG")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["graphs"] == [1] * 12 and rec["finite"] and rec["gc_enabled_after"], rec
