@@ -1253,7 +1253,11 @@ def extra_lines(args, dev):
         out["sdxl_shaped_backbone"] = {
             "value": (eng.iterations_run - it0) / dt if ok else None, "unit": "think-iterations/s", "ms_per_step": 1e3 * dt / reps,
             "sigma_call_ms": call_ms, "backbone_only_ms_per_sigma_call": bb_ms, "backbone_passes_per_sigma_call": n_think + 1,
-            "langevin_path_ms_per_sigma_call": call_ms - bb_ms, "langevin_path_share_of_sigma_call": (call_ms - bb_ms) / call_ms,
+            # (the difference of two ~15 ms wall-clock figures: it comes out at +-0.02 ms, i.e. the Langevin path is below the
+            # backbone's own run-to-run noise; the rocprofv3 kernel trace of the same workload puts the lp:: kernels at 0.17 % of
+            # the GPU time -- profiles/r05_sdxl_standin_time_split.md)
+            "langevin_path_ms_per_sigma_call": max(0.0, call_ms - bb_ms), "langevin_path_share_of_sigma_call": max(0.0, (call_ms - bb_ms) / call_ms),
+            "langevin_path_share_kernel_trace": 0.0017, "langevin_path_share_source": "profiles/r05_sdxl_standin_time_split.md (committed rocprofv3 pass)",
             "finite": bool(torch.isfinite(xl).all()), "captured_calls": len(eng._graphs), "backbone_parameters": net.n_params,
             "parity_check_fp32_weights": {k: par32[k] for k in ("mse_x", "mse_denoised_max", "ok", "sigmas_checked", "launch_modes")},
             "parity_check_bf16_weights": {k: par[k] for k in ("mse_x", "mse_denoised_max", "sigmas_checked", "launch_modes")},
