@@ -1257,20 +1257,23 @@ class LanPaint:
             state[4] = 1          # [4]: "this sigma call is valid" -- 0 voids a captured lp_finalize (a speculated call, lp_node_call)
         return state
 
-    _capture_state_ready = set()
+    _capture_sentinels = {}
 
     @classmethod
     def _warm_capture_state(cls, dev):
-        """Once per device, before this process's first capture through the engine: a trivial capture OUTSIDE inference mode.
-        torch creates the device generator's graph-capture state (its seed / offset tensors) at the first capture of the process
-        and updates it in place at every later `capture_begin`.  Created under torch.inference_mode() -- how ComfyUI runs its
-        nodes -- they are inference tensors, and the first capture attempted outside inference mode afterwards dies inside
-        capture_begin on that in-place update, leaving the generator in its capturing state (every later torch.randn of the
-        process then raises "Offset increment outside graph capture").  Found by the property test of the capture state machine
-        (tests/test_gpu_state_machine.py); as normal tensors the state can be updated from either mode."""
-        if dev.index in cls._capture_state_ready:
+        """Once per device, before this process's first capture through the engine: a trivial capture OUTSIDE inference mode whose
+        graph object is then KEPT for the life of the process.  torch allocates the device generator's graph-capture state (its
+        seed / offset tensors) when the FIRST graph registers with the generator, updates it in place at every `capture_begin`,
+        and frees it again when the LAST registered graph dies.  Allocated under torch.inference_mode() -- how ComfyUI runs its
+        nodes -- the state is inference tensors, and the first capture attempted outside inference mode while any graph is still
+        alive dies inside capture_begin on that in-place update, leaving the generator in its capturing state (every later
+        torch.randn of the process then raises "Offset increment outside graph capture").  Found by the property test of the
+        capture state machine (tests/test_gpu_state_machine.py) -- twice: a warm-up capture that was freed again only moved the
+        hazard to the next moment no graph was alive.  With one sentinel graph registered from normal mode and never freed, the
+        state stays allocated as normal tensors, which either mode may update."""
+        if dev.index in cls._capture_sentinels:
             return
-        cls._capture_state_ready.add(dev.index)
+        cls._capture_sentinels[dev.index] = None
         try:
             with torch.inference_mode(False), torch.no_grad():
                 g = torch.cuda.CUDAGraph()
@@ -1279,7 +1282,7 @@ class LanPaint:
                 with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                     torch.zeros(1, device=dev)
                 torch.cuda.current_stream(dev).wait_stream(s)
-                del g
+                cls._capture_sentinels[dev.index] = g
         except Exception:          # (a torch build that refuses: the engine's own captures will say why)
             pass
 

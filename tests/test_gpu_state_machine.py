@@ -336,9 +336,10 @@ def test_first_capture_under_inference_mode_does_not_poison_later_captures():
     """Counter-example found by the walks above when they ran late in the whole suite (kept as a regression case): torch creates
     the device generator's graph-capture state at the FIRST capture of the process; made under torch.inference_mode() those
     tensors are inference tensors, the first capture attempted OUTSIDE inference mode afterwards dies inside capture_begin on
-    their in-place update, and the generator stays "capturing" (every later torch.randn raises).  The engine now registers that
-    state itself, outside inference mode, before its first capture.  In a fresh process: capture under inference mode, then
-    outside, then draw from the generator."""
+    their in-place update, and the generator stays "capturing" (every later torch.randn raises).  torch frees that state again
+    when the last registered graph dies, so the hazard returns whenever no graph is alive: the engine keeps one sentinel graph,
+    registered outside inference mode, for the life of the process.  In a fresh process: capture under inference mode, let every
+    graph die, capture outside, and again both ways, then draw from the generator."""
     import json
     import os
     import subprocess
@@ -363,17 +364,21 @@ def run(inference):
             out = eng(x, y, noise, s, mask, (s, 1 / (1 + s ** 2), s / (1 + s)), None, 0)
         torch.cuda.synchronize()
         return len(eng._graphs), bool(torch.isfinite(out).all())
+import gc
 a = run(True)
+gc.collect()                    # every engine and its graphs gone: torch frees the generator's capture state with the last graph
 b = run(False)
+gc.collect()
 c = run(True)
+d = run(False)
 z = torch.randn(8, device="cuda")
-print(json.dumps({"graphs": [a[0], b[0], c[0]], "finite": [a[1], b[1], c[1]], "randn_ok": bool(torch.isfinite(z).all())}))
+print(json.dumps({"graphs": [a[0], b[0], c[0], d[0]], "finite": [a[1], b[1], c[1], d[1]], "randn_ok": bool(torch.isfinite(z).all())}))
 ''' % root
     env = {k: v for k, v in os.environ.items() if k not in ("LANPAINT_AMD_GRAPH", "LANPAINT_AMD_RNG")}
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-3000:]
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert rec["graphs"] == [1, 1, 1] and all(rec["finite"]) and rec["randn_ok"], rec
+    assert rec["graphs"] == [1, 1, 1, 1] and all(rec["finite"]) and rec["randn_ok"], rec
 
 
 def test_garbage_collection_during_a_capture_does_not_abort_the_process():
