@@ -9,7 +9,8 @@ for round in 1 2; do
     if [ $tree = r04 ]; then T=$R/build/r04_tree; else T=$R; fi
     cd /tmp
     timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_c2_$$ -o t -- python $T/bench.py --steps 20 --warmup 3 --repeats 0 --no-cpu-baseline --no-large-shape --extras 0 > /dev/null 2>&1
-    echo "round $round $tree C2 bench under rocprofv3: $(python $R/scripts/rocprof_summary.py /tmp/p_c2_$$/t_results.db 2>&1 | grep 'lp_step_kernel<1, 2, 28u' | head -1 | cut -c1-50,128-215)"
+    python $R/scripts/rocprof_summary.py /tmp/p_c2_$$/t_results.db > $O/c2_kernel_trace_${tree}_tree_round$round.md 2>&1
+    echo "round $round $tree C2 bench under rocprofv3: $(grep 'lp_step_kernel<1, 2, 28u' $O/c2_kernel_trace_${tree}_tree_round$round.md | head -1 | cut -c1-50,128-215)"
     rm -rf /tmp/p_c2_$$; cd $R
   done
 done | tee $O/ab_c2_rocprof.log
