@@ -184,3 +184,139 @@ def test_the_arbiter_has_teeth():
     want_out, _, _ = _walk(ref, job, 1)
     got_out, _, _ = _walk(mine, job, 2)
     assert float((got_out[-1].double() - want_out[-1].double()).abs().max()) > 1e-2
+
+
+# ------------------------------------------------------------------ the rest of the engine's call surface, same arbiter
+def _walk_with_options(engine, job, seed, options_for_call, extra_kw=None):
+    """`_walk` with a fresh model_options dict per sigma call (the stopper reads and the trace list fills it) and optional
+    keyword arguments of the AV form; returns per call (out, x, trace records) and the generator state."""
+    import torch
+    torch.manual_seed(seed)
+    x = job["x0"].clone()
+    calls = []
+    with torch.no_grad():
+        for i, (s, t) in enumerate(zip(job["sig_list"], job["times_list"])):
+            mo = options_for_call(i)
+            den = engine(x, job["y"], job["noise"], s, job["mask"], t, mo, 0, n_steps=job["n_think"], **(extra_kw or {}))
+            calls.append((den.clone(), x.clone(), list(mo.get("lanpaint_semantic_trace", [])) if mo else []))
+            if i + 1 < len(job["sig_list"]):
+                x = torch.lerp(den, x, job["ratios"][i])
+    torch.cuda.synchronize()
+    return calls, torch.cuda.get_rng_state(0).clone()
+
+
+@pytest.mark.parametrize("workload,thr,pat,n_think,n_sig,ramp", [
+    ("c2_sdxl", 8.0, 1, 10, 14, None),    # the threshold scales with abt: the early (noisy) calls run out, the later ones stop
+    ("c2_sdxl", 8.0, 2, 10, 14, None),    # patience_eff = patience + 1 quiet checks in a row (the drift anchor is live in between)
+    ("c2_sdxl", 1e-9, 2, 6, 6, None),     # armed, never fires: the watched loop runs to the end
+    ("c3_sdxl_b4", 8.0, 1, 8, 13, (1.0, 0.9, 0.8, 0.7)),   # four rows on their own sigmas: abt is the mean over rows
+    ("c5_wan", 2000.0, 1, 6, 2, None),    # 5-D video latent: no ring weight (earlystop.py:32-50 returns None)
+], ids=["c2_patience1", "c2_patience2", "c2_never_fires", "c3_rows", "c5_video"])
+def test_inner_early_stop_reference_on_gpu_vs_default_engine_same_seed(workload, thr, pat, n_think, n_sig, ramp):
+    """earlystop.py's stopper inside the reference loop on the GPU (it breaks out of its Python loop and stops drawing) next
+    to the product's device-side verdict (graph launches gated on the device, the generator rewound by the draws the
+    skipped iterations would have made): per sigma call the same iteration count, the same trace records, outputs inside the
+    fp32 tolerance above -- and the same generator state at the end, which fails if a single draw is miscounted."""
+    import torch
+    job = _job(workload, row_ramp=ramp, n_sig=n_sig)
+    job["n_think"] = n_think
+    ref, mine = _engines(job)
+    opt = lambda i: {"lanpaint_semantic_stop": {"threshold": thr, "patience": pat}, "lanpaint_semantic_trace": []}   # noqa: E731
+    want, want_state = _walk_with_options(ref, job, 5150, opt)
+    got, got_state = _walk_with_options(mine, job, 5150, opt)
+    ran = []
+    for i, ((go, gx, gt), (wo, wx, wt)) in enumerate(zip(got, want)):
+        assert len(gt) == len(wt), f"sigma call {i}: {len(gt)} iterations against the reference's {len(wt)}"
+        for key in ("inner_step", "patience_counter", "patience_eff", "stopped"):
+            assert [r[key] for r in gt] == [r[key] for r in wt], (i, key)
+        for key in ("dist", "threshold", "threshold_eff", "abt"):
+            np.testing.assert_allclose([r[key] for r in gt], [r[key] for r in wt], rtol=2e-4, err_msg=f"call {i}: {key}")
+        assert [r["dist_ring"] is None for r in gt] == [r["dist_ring"] is None for r in wt]
+        assert [r["dist_drift"] is None for r in gt] == [r["dist_drift"] is None for r in wt]
+        _compare(go, wo, f"sigma call {i}: out")
+        _compare(gx, wx, f"sigma call {i}: in-place x")
+        ran.append(len(wt))
+    assert torch.equal(got_state, want_state), "generator state differs: a skipped iteration's draws were not rewound exactly"
+    assert mine.iterations_run == sum(ran) == ref_iterations(ref, ran)
+    if thr < 1e-6:
+        assert all(r == n_think for r in ran)
+    else:
+        assert any(r < n_think for r in ran), ran          # the stop did fire somewhere on this schedule
+    print(f"[early stop on the reference, {workload} thr={thr} patience={pat}] iterations per sigma call: {ran}")
+
+
+def ref_iterations(ref, ran):
+    """The reference keeps no iteration counter; its backbone stub's call count is one final call + one per iteration."""
+    return ref.inner_model.calls - len(ran)
+
+
+@pytest.mark.parametrize("shape,split,rows_differ", [((1, 8, 66000), 40001, False), ((3, 4, 777), 500, True)],
+                         ids=["one_row_16B_lanes", "rows_on_their_own_time_pairs"])
+def test_av_pack_reference_on_gpu_vs_default_engine_same_seed(shape, split, rows_differ):
+    """The flat audio+video pack (lanpaint.py:60-74, 173-180: per-element blended times, the audio correction on the score)
+    through the reference on the GPU and through the product's two-row table path, same seed, three calls with moving times."""
+    import torch
+    from tests.test_gpu_av import _case
+    from lanpaint_amd import LanPaint
+    from oracle import lanpaint_oracle as orc
+    c = _case(shape, split, seed=77, rows_differ=rows_differ)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda")   # noqa: E731
+    ref_cls = _reference_class()
+    res = {}
+    for tag, cls in (("ref", ref_cls), ("mine", LanPaint)):
+        torch.manual_seed(2718)
+        eng = cls(TwoHeads(True), 4, 15.0, 5.0, 1.0, 0.2, False, True)
+        outs = []
+        x = tt(c["x"])
+        with torch.no_grad():
+            for k in range(3):
+                f = np.float32(1.0 - 0.15 * k)
+                tv, ta = orc.times_from_sigma(c["sigma"] * f, True), orc.times_from_sigma(np.asarray(c["times_a"][1]) * f, True)
+                out = eng(x, tt(c["y"]), tt(c["noise"]), tt(c["sigma"] * f), tt(c["mask"]), tuple(tt(t) for t in tv), None, 0,
+                          current_times_audio=tuple(tt(t) for t in ta), audio_indicator=tt(c["ai"]),
+                          audio_correction=tt(c["corr"]))
+                outs.append((out.clone(), x.clone()))
+        torch.cuda.synchronize()
+        res[tag] = (outs, torch.cuda.get_rng_state(0).clone(), eng)
+    assert res["mine"][2]._desc.flags & (1 << 17), "the product did not take the two-row table (LP_FL_AV)"
+    for k, ((go, gx), (wo, wx)) in enumerate(zip(res["mine"][0], res["ref"][0])):
+        _compare(go, wo, f"AV call {k}: out")
+        _compare(gx, wx, f"AV call {k}: in-place x")
+    assert torch.equal(res["mine"][1], res["ref"][1])
+
+
+@pytest.mark.parametrize("variant", ["is_flux", "soft_mask", "undeclared_noise_scaling", "single_head_backbone"])
+def test_engine_variants_reference_on_gpu_vs_default_engine_same_seed(variant):
+    """IS_FLUX (lanpaint.py:20-22 folds it into the flow form), a soft mask (per-element replace / score weights), a
+    model_sampling the product cannot recognise (its noise_scaling is called back, lanpaint.py:86-92), and a backbone that
+    returns ONE tensor (unpack_model_output's list / tensor branches, lanpaint.py:31-46)."""
+    import torch
+    import bench
+    from lanpaint_amd import LanPaint
+    from tests.stubs import OpaqueVESampling
+    flow = variant == "is_flux"
+    job = _job("c4_flux" if flow else "c1_sd15", n_sig=6)
+    if variant == "soft_mask":
+        g = torch.Generator(device="cuda").manual_seed(3)
+        job["mask"] = torch.rand(job["mask"].shape, device="cuda", generator=g)
+
+    class OneHead(TwoHeads):
+        def __call__(self, x, t, model_options=None, seed=None):
+            self.calls += 1
+            return x / (1.0 + t.reshape((-1,) + (1,) * (x.ndim - 1)) ** 2)
+
+    def model():
+        m = OneHead(flow) if variant == "single_head_backbone" else TwoHeads(flow)
+        if variant == "undeclared_noise_scaling":
+            m.model_sampling = OpaqueVESampling()
+        return m
+
+    h = bench.HYPER
+    args = (job["n_think"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"], flow, False)
+    ref, mine = _reference_class()(model(), *args), LanPaint(model(), *args)
+    want_out, want_x, want_state = _walk(ref, job, 1234)
+    got_out, got_x, got_state = _walk(mine, job, 1234)
+    for i, (a, b, c, d) in enumerate(zip(got_out, want_out, got_x, want_x)):
+        _compare(a, b, f"{variant}: sigma call {i}: out")
+        _compare(c, d, f"{variant}: sigma call {i}: in-place x")
+    assert torch.equal(got_state, want_state)
