@@ -480,9 +480,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
                 const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
                 if (g >= d.el_per_row / VEC) return;
                 const int64_t i = static_cast<int64_t>(row) * d.el_per_row + g * VEC;
-                const float sc = load_row(d.coef, row).scale;
                 float xt[VEC], xo[VEC];
                 load_f32<VEC>(d.x_t, i, xt);
+                if constexpr (PH == 0 && MODE == MODE_ROW && !ST) {
+                    if (fl & LP_FL_AV) {             // AV pack: every element on its own stream's table row (2 r: video, 2 r + 1: audio)
+                        const uint32_t word = static_cast<const uint32_t*>(d.av_bits)[i >> 5];
+                        const uint32_t nib = word >> (static_cast<uint32_t>(i) & 31u);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            const float sc = d.coef[static_cast<int64_t>(2 * row + static_cast<int>((nib >> k) & 1u)) * LP_COEF_STRIDE + LP_C_SCALE];
+                            xo[k] = (fl & LP_FL_FLOW) ? xt[k] / sc : xt[k] * sc;
+                        }
+                        store_any<VEC>(d.x_in, xin_dtype(fl), i, xo);
+                        return;
+                    }
+                }
+                const float sc = load_row(d.coef, row).scale;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) xo[k] = (fl & LP_FL_FLOW) ? xt[k] / sc : xt[k] * sc;
                 store_any<VEC>(d.x_in, xin_dtype(fl), i, xo);
@@ -1691,7 +1704,6 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
         if (!d.av_bits || !aligned(d.av_bits, 4) || !d.coef || (d.flags & LP_FL_PER_ELEMENT) || (ph & (LP_PH_COEFFS | LP_PH_SIGMA)) ||
             !(d.av_frac >= 0.0f && d.av_frac <= 1.0f))
             return LP_E_INVALID;
-        if (d.flags & LP_FL_ES_GATED) return LP_E_UNSUPPORTED;      // (a stopped gated launch re-emits with ONE row's scale)
     }
     if (d.rng_kind != LP_RNG_PHILOX && d.rng_kind != LP_RNG_TORCH) return LP_E_INVALID;
     if (d.rng_kind == LP_RNG_TORCH && (d.rng_bg == 0 || (d.rng_inc & 3u) || d.rng_inc == 0)) return LP_E_INVALID;

@@ -1055,11 +1055,15 @@ class LanPaint:
         if self.audio_indicator is not None or self.audio_correction is not None:
             # AV packs replay only on the two-row table (LP_FL_AV: per-row time pairs + a 0/1 indicator), whose per-call inputs --
             # the interleaved times, the correction tensor -- live in workspace buffers the prologue refreshes; the reference-
-            # shaped per-element form builds fresh full-size tensors per call, and a gated stop is not built for the table yet
-            if (self.audio_indicator is None or self.current_times_audio is None or self._es_opts is not None
+            # shaped per-element form builds fresh full-size tensors per call.  (A gated early stop rides along since round 5: a
+            # stopped launch re-emits every element with its own stream's scale; rows with different audio shares keep the host
+            # stopper -- the device-side threshold takes ONE share, see __call__.)
+            if (self.audio_indicator is None or self.current_times_audio is None
                     or any(t.numel() not in (1, rows) for t in self.current_times_audio)
-                    or os.environ.get("LANPAINT_AMD_AV_TABLE", "1") == "0"
-                    or self._indicator_pack(self.audio_indicator, x.shape) is None):
+                    or os.environ.get("LANPAINT_AMD_AV_TABLE", "1") == "0"):
+                return False
+            packed = self._indicator_pack(self.audio_indicator, x.shape)
+            if packed is None or (self._es_opts is not None and not packed[2]):
                 return False
         if self._es_opts is not None and (not self._es_opts["device"] or self.rng not in ("torch", "philox")):
             return False         # a custom distance_fn / a sharded batch keeps the stopper on the host; a gated loop

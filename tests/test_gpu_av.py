@@ -233,3 +233,75 @@ def test_rows_with_different_audio_shares_keep_the_host_stopper():
     # without a stopper the table path is still taken for such an indicator (the share only enters the stop threshold)
     _, _, eng2 = _run_engine(c, 2, draws[:3])
     assert eng2._desc.flags & (1 << 17)
+
+
+@pytest.mark.parametrize("shape,split,patience", [((1, 4, 3000), 1777, 1), ((2, 2, 600), 401, 2), ((1, 8, 66000), 40001, 1)],
+                         ids=["one_row", "two_rows_own_times", "16B_lanes_seam_in_a_quad"])
+def test_av_pack_with_early_stop_replays_as_a_graph_bitwise_equal_to_the_watched_loop(shape, split, patience):
+    """Round 5: the one combination round 4 still refused -- a GATED (replayed) early stop on an AV call.  The stopped launches
+    of the replay re-emit the committed state with every element's own stream scale (table row 2 r / 2 r + 1 by the indicator
+    bit).  Against the eager loop, which asks the mailbox after every iteration (itself pinned to the oracle's stopper above):
+    the same iteration counts and trace, the same bits in x / out, torch's generator left in the same place -- over sigma calls
+    on which the stop lands on different iterations (and once not at all)."""
+    import torch
+    from lanpaint_amd import LanPaint
+    n_steps = 8
+    rows_differ = shape[0] > 1
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    c = _case(shape, split, seed=33, rows_differ=rows_differ)
+    ai, y, noise, mask = tt(c["ai"]), tt(c["y"]), tt(c["noise"]), tt(c["mask"])
+    bs = (-1,) + (1,) * (len(shape) - 1)
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(78)
+        eng = LanPaint(MODELS["linear_tuple"](flow=True), n_steps, 15.0, 5.0, 1.0, 0.2, IS_FLOW=True, graph=graph)
+        x, runs = tt(c["x"]), []
+        for k, (f, thr) in enumerate(((1.0, 5.0), (0.8, 5.0), (0.6, 1e-9), (0.4, 5.0))):
+            s_v = (c["sigma"] * np.float32(f)).astype(np.float32)
+            s_a = (np.asarray(c["times_a"][2]) * np.float32(f)).astype(np.float32)
+            mo = {"lanpaint_semantic_stop": {"threshold": thr, "patience": patience}, "lanpaint_semantic_trace": []}
+            it0 = eng.iterations_run
+            out = eng(x, y, noise, tt(s_v), mask, tuple(tt(t) for t in orc.times_from_sigma(s_v, True)), mo, 0,
+                      current_times_audio=tuple(tt(t) for t in orc.times_from_sigma(s_a, True)), audio_indicator=ai,
+                      audio_correction=tt(c["corr"]))
+            tr = mo["lanpaint_semantic_trace"]
+            runs.append((out.clone(), x.clone(), eng.iterations_run - it0,
+                         [(t["inner_step"], t["patience_counter"], t["stopped"]) for t in tr], [t["dist"] for t in tr]))
+            x = x + 0.1 * (out - x)
+        torch.cuda.synchronize()
+        res[graph] = (runs, int(torch.cuda.default_generators[0].get_offset()), len(eng._graphs), eng._desc.flags)
+    assert res[True][2] >= 1 and res[False][2] == 0
+    assert res[True][3] & (1 << 17) and res[False][3] & (1 << 17)            # both on the two-row table
+    for k, (g, e) in enumerate(zip(res[True][0], res[False][0])):
+        assert g[2] == e[2] and g[3] == e[3], (k, g[2], e[2])
+        np.testing.assert_allclose(g[4], e[4], rtol=1e-12)
+        assert torch.equal(g[0], e[0]) and torch.equal(g[1], e[1]), f"sigma call {k}"
+    assert res[True][1] == res[False][1]
+    ran = [r[2] for r in res[True][0]]
+    assert ran[2] == n_steps and any(r < n_steps for r in ran), ran
+
+
+def test_av_early_stop_with_the_unfolded_gated_schedule():
+    """LP_TUNE_ES_NO_FOLD (a developer switch of the descriptor): the verdict sits in a one-wave kernel between the launches and a
+    stopped launch leaves through the kernel's early exit -- the path that used to re-emit with one row's scale."""
+    import torch
+    from lanpaint_amd import LanPaint, _cabi
+    shape, split, n_steps = (1, 4, 3000), 1777, 8
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
+    c = _case(shape, split, seed=34)
+    res = {}
+    for tune in (0, _cabi.LP_TUNE_ES_NO_FOLD):
+        torch.manual_seed(5)
+        eng = LanPaint(MODELS["linear_tuple"](flow=True), n_steps, 15.0, 5.0, 1.0, 0.2, IS_FLOW=True, graph=True)
+        eng._desc.tune = tune
+        x = tt(c["x"])
+        mo = {"lanpaint_semantic_stop": {"threshold": 5.0, "patience": 1}}
+        out = eng(x, tt(c["y"]), tt(c["noise"]), tt(c["sigma"]), tt(c["mask"]), tuple(tt(t) for t in c["times_v"]), mo, 0,
+                  current_times_audio=tuple(tt(t) for t in c["times_a"]), audio_indicator=tt(c["ai"]),
+                  audio_correction=tt(c["corr"]))
+        torch.cuda.synchronize()
+        assert len(eng._graphs) == 1 and eng._desc.tune == tune
+        res[tune] = (out.clone(), x.clone(), eng.iterations_run)
+    a, b = res[0], res[_cabi.LP_TUNE_ES_NO_FOLD]
+    assert a[2] == b[2] < n_steps
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

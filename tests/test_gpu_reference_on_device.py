@@ -212,15 +212,18 @@ def _walk_with_options(engine, job, seed, options_for_call, extra_kw=None):
     ("c3_sdxl_b4", 8.0, 1, 8, 13, (1.0, 0.9, 0.8, 0.7)),   # four rows on their own sigmas: abt is the mean over rows
     ("c5_wan", 2000.0, 1, 6, 2, None),    # 5-D video latent: no ring weight (earlystop.py:32-50 returns None)
 ], ids=["c2_patience1", "c2_patience2", "c2_never_fires", "c3_rows", "c5_video"])
-def test_inner_early_stop_reference_on_gpu_vs_default_engine_same_seed(workload, thr, pat, n_think, n_sig, ramp):
+@pytest.mark.parametrize("kw", [{}, {"graph": True}], ids=["default_engine", "gated_graph_launches"])
+def test_inner_early_stop_reference_on_gpu_vs_default_engine_same_seed(workload, thr, pat, n_think, n_sig, ramp, kw):
     """earlystop.py's stopper inside the reference loop on the GPU (it breaks out of its Python loop and stops drawing) next
     to the product's device-side verdict (graph launches gated on the device, the generator rewound by the draws the
     skipped iterations would have made): per sigma call the same iteration count, the same trace records, outputs inside the
-    fp32 tolerance above -- and the same generator state at the end, which fails if a single draw is miscounted."""
+    fp32 tolerance above -- and the same generator state at the end, which fails if a single draw is miscounted.
+    (The default engine meets a fresh model_options dict per call here and so stays on watched eager launches; `graph=True`
+    puts the same schedule through the device-gated launches of a replayed graph.)"""
     import torch
     job = _job(workload, row_ramp=ramp, n_sig=n_sig)
     job["n_think"] = n_think
-    ref, mine = _engines(job)
+    ref, mine = _engines(job, **kw)
     opt = lambda i: {"lanpaint_semantic_stop": {"threshold": thr, "patience": pat}, "lanpaint_semantic_trace": []}   # noqa: E731
     want, want_state = _walk_with_options(ref, job, 5150, opt)
     got, got_state = _walk_with_options(mine, job, 5150, opt)
@@ -238,6 +241,7 @@ def test_inner_early_stop_reference_on_gpu_vs_default_engine_same_seed(workload,
         ran.append(len(wt))
     assert torch.equal(got_state, want_state), "generator state differs: a skipped iteration's draws were not rewound exactly"
     assert mine.iterations_run == sum(ran) == ref_iterations(ref, ran)
+    assert (len(mine._graphs) >= 1 and all(c.es is not None for c in mine._graphs.values())) if kw else not mine._graphs
     if thr < 1e-6:
         assert all(r == n_think for r in ran)
     else:
@@ -320,3 +324,45 @@ def test_engine_variants_reference_on_gpu_vs_default_engine_same_seed(variant):
         _compare(a, b, f"{variant}: sigma call {i}: out")
         _compare(c, d, f"{variant}: sigma call {i}: in-place x")
     assert torch.equal(got_state, want_state)
+
+
+@pytest.mark.parametrize("kw", [{}, {"graph": True}], ids=["default_engine", "gated_graph_launches"])
+def test_av_pack_with_inner_early_stop_reference_on_gpu_vs_default_engine_same_seed(kw):
+    """Both at once: the reference's stopper on a flat audio+video pack (threshold from the mean of the BLENDED abt tensor,
+    earlystop.py:104-110) against the product on the two-row table -- watched eager launches (default engine, a fresh options
+    dict per call) and the device-gated launches of a replayed graph (round 5)."""
+    import torch
+    from tests.test_gpu_av import _case
+    from lanpaint_amd import LanPaint
+    shape, split, n_steps = (1, 8, 66000), 40001, 8
+    c = _case(shape, split, seed=78)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda")   # noqa: E731
+    res = {}
+    for tag, cls in (("ref", _reference_class()), ("mine", LanPaint)):
+        torch.manual_seed(1618)
+        eng = cls(TwoHeads(True), n_steps, 15.0, 5.0, 1.0, 0.2, False, True, **(kw if tag == "mine" else {}))
+        x, y, noise, mask, ai, corr = (tt(c[k]) for k in ("x", "y", "noise", "mask", "ai", "corr"))
+        sig, tv, ta = tt(c["sigma"]), tuple(tt(t) for t in c["times_v"]), tuple(tt(t) for t in c["times_a"])
+        calls = []
+        with torch.no_grad():
+            for k in range(4):
+                mo = {"lanpaint_semantic_stop": {"threshold": 5.0 if k != 2 else 1e-9, "patience": 1}, "lanpaint_semantic_trace": []}
+                out = eng(x, y, noise, sig, mask, tv, mo, 0, current_times_audio=ta, audio_indicator=ai, audio_correction=corr)
+                calls.append((out.clone(), x.clone(), list(mo["lanpaint_semantic_trace"])))
+                x = x + 0.1 * (out - x)
+        torch.cuda.synchronize()
+        res[tag] = (calls, torch.cuda.get_rng_state(0).clone(), eng)
+    ran = []
+    for k, ((go, gx, gt), (wo, wx, wt)) in enumerate(zip(res["mine"][0], res["ref"][0])):
+        assert [(r["inner_step"], r["patience_counter"], r["stopped"]) for r in gt] == \
+               [(r["inner_step"], r["patience_counter"], r["stopped"]) for r in wt], k
+        np.testing.assert_allclose([r["dist"] for r in gt], [r["dist"] for r in wt], rtol=2e-4)
+        np.testing.assert_allclose([r["threshold_eff"] for r in gt], [r["threshold_eff"] for r in wt], rtol=1e-5)
+        _compare(go, wo, f"AV + early stop, call {k}: out")
+        _compare(gx, wx, f"AV + early stop, call {k}: in-place x")
+        ran.append(len(wt))
+    assert torch.equal(res["mine"][1], res["ref"][1])
+    assert ran[2] == n_steps and any(r < n_steps for r in ran), ran
+    mine = res["mine"][2]
+    assert mine._desc.flags & (1 << 17), "the product did not take the two-row table (LP_FL_AV)"
+    assert (len(mine._graphs) >= 1) == bool(kw)
