@@ -179,7 +179,8 @@ typedef struct lp_hyper {
                                           that stream's row -- no per-element transcendental, where the reference-shaped
                                           LP_FL_PER_ELEMENT form needs three full-size time tensors and evaluates exp / expm1 per
                                           element; only the wave straddling the seam of a row uses the per-element formulas.
-                                          Not with LP_PH_COEFFS / LP_FL_PER_ELEMENT / LP_FL_ES_GATED.                          */
+                                          Not with LP_PH_COEFFS / LP_FL_PER_ELEMENT.  (With LP_FL_ES_GATED a stopped launch
+                                          re-emits every element with its own stream's scale.)                                 */
 #define LP_FL_X0S_GIVEN     (1u << 9)  /* `x0` already holds x0s = x_t + score(x_t) (public
                                           langevin_dynamics(x_t, score, ...) entry, lanpaint.py:192,218) */
 
