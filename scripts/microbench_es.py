@@ -67,3 +67,22 @@ run("plain steady launch", lambda d, keep: None)
 run("ES step + decide (gated)", es_setup(True))
 run("ES step + decide (watched: mailbox fence per iteration)", es_setup(False))
 run("ES step + decide (gated, no mailbox at all)", es_setup(True, host=False))
+
+
+def tuned(tune, **kw):
+    inner = es_setup(True, **kw)
+
+    def f(d, keep):
+        ds = inner(d, keep)
+        d.tune = tune
+        return ds
+    return f
+
+
+# what a deferred-verdict loop would launch per iteration: the early-stop step with its sums and atomics but
+# nothing that waits for a verdict -- here the unfolded launch without its decision kernel (run-time-phase kernel: an upper bound)
+run("ES step, unfolded, NO decision kernel (upper bound of a deferred-verdict launch)",
+    tuned(_cabi.LP_TUNE_ES_NO_FOLD | _cabi.LP_TUNE_ES_NO_DECIDE))
+run("ES step, unfolded, no decision kernel, no atomics",
+    tuned(_cabi.LP_TUNE_ES_NO_FOLD | _cabi.LP_TUNE_ES_NO_DECIDE | _cabi.LP_TUNE_ES_NO_ATOMICS))
+run("ES step, unfolded, WITH decision kernel", tuned(_cabi.LP_TUNE_ES_NO_FOLD))
