@@ -215,6 +215,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t subseq, ui
 // Which Philox block and which of its four normals element li of the tensor takes.  n_el <= bg (every image-sized
 // latent: bg is n_el rounded up to 256 while the grid is uncapped) means one ATen thread per element -- no 64-bit
 // division; past the grid cap bg is 256 * 2048 on this chip, a power of two.
+template <bool WIDE = false>          // (WIDE: one 32 x 32 -> 64 multiply per product of a Philox round, see philox2x32_10)
 __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64_t offset, uint32_t bg, bool small) {
 #pragma clang fp contract(on)
     uint32_t idx, q;
@@ -228,7 +229,7 @@ __device__ __forceinline__ float torch_normal(uint64_t li, uint64_t seed, uint64
         idx = static_cast<uint32_t>(li % bg);
         q = static_cast<uint32_t>(li / bg);
     }
-    const uint4 c = philox4x32_10((offset >> 2) + (q >> 2), idx, seed);
+    const uint4 c = philox4x32_10<WIDE>((offset >> 2) + (q >> 2), idx, seed);
     // rocrand_normal4 (what ATen calls) = Box-Muller on (c.x, c.y) and on (c.z, c.w); only the pair this element's value comes
     // from is transformed (the other three values belong to elements bg, 2 bg, 3 bg away)
     const uint32_t ii = q & 3u;

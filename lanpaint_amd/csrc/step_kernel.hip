@@ -996,8 +996,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         const uint64_t li = static_cast<uint64_t>(elem_index(i, k));
-                        if (draw_post) xi_a[k] = torch_normal(li, seed, seq, d.rng_bg, small);
-                        if (draw_pre) xi_b[k] = torch_normal(li, seed, off_pre, d.rng_bg, small);
+                        // (phase-specialised kernels: one v_mad_u64_u32 per product of a Philox4x32 round instead of a mul_hi / mul_lo
+                        // pair -- 40 quarter-rate multiplies per draw instead of 80 in a launch that has one wave per SIMD at image sizes)
+                        if (draw_post) xi_a[k] = torch_normal<PH != 0>(li, seed, seq, d.rng_bg, small);
+                        if (draw_pre) xi_b[k] = torch_normal<PH != 0>(li, seed, off_pre, d.rng_bg, small);
                     }
                 }
             } else {
