@@ -27,7 +27,7 @@ STAMPS = ["kernel entry", "operand loads issued", "noise generated", "operands a
           "arithmetic done", "stores issued", "block sums written"]
 
 
-def run(wl, early_stop, half=False):
+def run(wl, early_stop, half=False, rng="philox"):
     dev = torch.device("cuda", 0)
     lib = _cabi.load()
     steady = _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT
@@ -43,11 +43,15 @@ def run(wl, early_stop, half=False):
             d.es_x0s[k] = ds.x0s[k].data_ptr()
         d.es_threshold, d.es_patience_eff, d.es_index, d.es_n_steps = 1e-30, 2, 1, 64
     reps = 50
+    if rng == "torch":                 # the device generator's randn stream reproduced in the kernel (the engine's default)
+        from lanpaint_amd import LanPaint
+        d.rng_kind, d.rng_seed = _cabi.LP_RNG_TORCH, 1234
+        d.rng_bg, d.rng_inc = LanPaint._randn_policy(dev, n_el)
 
     def launches():
         st = torch.cuda.current_stream(dev).cuda_stream
         for k in range(reps):
-            d.rng_offset = k
+            d.rng_offset = k if rng != "torch" else 2 * k * d.rng_inc
             _cabi.check(lib.lp_step(ctypes.byref(d), st))
 
     launches()
@@ -65,7 +69,8 @@ def run(wl, early_stop, half=False):
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / (40 * reps) * 1e6
     h = clk.cpu().numpy()
-    label = ("early-stop launch (gated, verdict folded in)" if early_stop else "plain steady launch") + (", bf16 heads in / bf16 x_in out" if half else "")
+    label = ("early-stop launch (gated, verdict folded in)" if early_stop else "plain steady launch") + (", bf16 heads in / bf16 x_in out" if half else "") + \
+        (", reference noise stream (Philox4x32 + library Box-Muller)" if rng == "torch" else "")
     print(f"\n{wl}, {label}: {us:.2f} us per launch in a replayed graph of {reps} (instrumented build)")
     print(f"  the last block entered {(h[30] - h[14]) * 10.0:.0f} ns after the first one (s_memrealtime, 10 ns ticks): the time the "
           f"dispatcher needs to start the launch's {d.el_per_row * d.rows // (4 if n_el > 512 * 1024 else 1) // 256} blocks")
@@ -83,6 +88,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "bf16":          # fp32 heads against bf16 heads, plain launch
         run(wl, False)
         run(wl, False, half=True)
+    elif len(sys.argv) > 2 and sys.argv[2] == "torch":       # in-kernel Philox2x32 against the reference's noise stream, plain launch
+        run(wl, False)
+        run(wl, False, rng="torch")
     else:
         run(wl, False)
         run(wl, True)
