@@ -45,6 +45,11 @@ extern "C" {
 
 #define LP_ABI_VERSION 18
 
+/* The library is built with -fvisibility=hidden: the entry points declared LP_API below are its ONLY dynamic symbols (the
+ * dispatch functions, kernel handles and device stubs of the C++ side stay internal; tests/test_cabi_exports.py checks
+ * `nm -D --defined-only` lists nothing but lp_*). */
+#define LP_API __attribute__((visibility("default")))
+
 /* ---- error codes ------------------------------------------------------- */
 #define LP_OK             0
 #define LP_E_INVALID     -1   /* null / inconsistent argument                  */
@@ -372,8 +377,8 @@ typedef struct lp_final_desc {
 } lp_final_desc;
 
 /* ---- entry points --------------------------------------------------------- */
-int lp_abi_version(void);
-const char* lp_strerror(int code);
+LP_API int lp_abi_version(void);
+LP_API const char* lp_strerror(int code);
 
 /* K1  per-row coefficient table on the device.
  * Replaces: KSamplerX0Inpaint scalars feeding LanPaint.LanPaint (lanpaint.py:81-82),
@@ -384,7 +389,7 @@ const char* lp_strerror(int code);
  * per-row step size (the `step_size` argument of the public langevin_dynamics,
  * lanpaint.py:192) instead of StepSize*max(1-abt, MinStepFrac).  t_model (nullable):
  * copied into slot LP_C_TMODEL.                                                */
-int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const float* abt, int abt_stride,
+LP_API int lp_coeffs(const lp_hyper* hyper, const float* ve_sigma, int ve_stride, const float* abt, int abt_stride,
               const float* replace_sigma, int rs_stride, const float* step_override, int step_stride,
               const float* t_model, int t_stride, int rows, float* coef_table, void* stream);
 
@@ -416,7 +421,7 @@ typedef struct lp_call_desc {
                                            (hipGraphExecKernelNodeSetParams) before the graph launch -- the whole
                                            sigma call is then ONE hipGraphLaunch with nothing eager in front       */
 } lp_call_desc;
-int lp_replay_call(const lp_call_desc* call, void* stream);
+LP_API int lp_replay_call(const lp_call_desc* call, void* stream);
 
 /* One hipGraphLaunch per sigma call (round 3).  A sigma call captured WITH its replace launch (lanpaint.py:81-99,
  * the first node of the graph) needs that node's per-call arguments -- the sampler's x, the noise, sigma / times,
@@ -435,9 +440,9 @@ typedef struct lp_graph_binding {
     uint32_t shared_bytes;
     uint32_t reserved;
 } lp_graph_binding;
-int lp_graph_bind_replace(void* graph, const lp_step_desc* captured_replace, lp_graph_binding* out);
-int lp_graph_clone_tail(void* graph, void** tail_graph_out, void** tail_exec_out);
-int lp_graph_release(void* tail_graph, void* tail_exec);
+LP_API int lp_graph_bind_replace(void* graph, const lp_step_desc* captured_replace, lp_graph_binding* out);
+LP_API int lp_graph_clone_tail(void* graph, void** tail_graph_out, void** tail_exec_out);
+LP_API int lp_graph_release(void* tail_graph, void* tail_exec);
 
 /* K1a  sigma -> (VE_sigma, abt, flow_t) per batch row plus the two scalars the inner-step rule needs,
  * in ONE launch.  Replaces the ~15 eager scalar ops + 2 host syncs of KSamplerX0Inpaint.__call__
@@ -445,13 +450,13 @@ int lp_graph_release(void* tail_graph, void* tail_exec);
  * separately rounded fp32 op in the reference's order (no FMA contraction), so n_eff decisions match.
  * times_out: [3][rows] = VE_sigma, abt, flow_t.  scalars_out: [2] = { index of the schedule entry
  * closest to mean(sigma) (first minimum), mean(1 - abt) }.                                        */
-int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
+LP_API int lp_sigma_times(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
                    float* times_out, float* scalars_out, void* stream);
 /* Same launch with a mailbox: `scalars_out` may be device-visible PINNED HOST memory; after the two scalars the
  * kernel stores `seq` to `seq_out` with a system-scope release, so a host thread polling *seq_out learns the two
  * numbers ~2 us after the kernel ran instead of through a blocking device->host copy (the one host dependency of
  * the per-sigma inner-step rule, nodes.py:286-299: sigma exists only on the device, in stream order).       */
-int lp_sigma_times_mailbox(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
+LP_API int lp_sigma_times_mailbox(const float* sigma, int32_t rows, const float* schedule, int32_t schedule_len, int32_t is_flow,
                            float* times_out, float* scalars_out, int32_t* seq_out, int32_t seq, void* stream);
 
 /* The sampler-facing callable's steady state in ONE host call (round 3).  KSamplerX0Inpaint.__call__ (nodes.py:229-315)
@@ -499,43 +504,43 @@ typedef struct lp_node_call_desc {
     int32_t             hit;            /* out: 1 = ... and the guess was right                                   */
     float               step_f, frac;   /* out: the two scalars as read from the mailbox                          */
 } lp_node_call_desc;
-int lp_node_call(lp_node_call_desc* call, void* stream);
+LP_API int lp_node_call(lp_node_call_desc* call, void* stream);
 /* the rule alone (host arithmetic; tests pin it against the reference's min_step_frac_effective_steps table)   */
-int32_t lp_effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps, int32_t early_stop,
+LP_API int32_t lp_effective_inner_steps(int32_t n_steps, double step_f, double frac, int32_t total_steps, int32_t early_stop,
                                  double min_step_frac);
 
 /* K0 / K_first / K2  the fused step (phases select the work).
  * Replaces: lanpaint.py:94-99 (REPLACE), :159-184 + :212-220 (score split + Coef_C),
  *           :232-254 (exact OU + noise injection), :274-286 (the scheme),
  *           :144-147 / :163 / :168 (EMIT).                                     */
-int lp_step(const lp_step_desc* desc, void* stream);
+LP_API int lp_step(const lp_step_desc* desc, void* stream);
 
 /* Measurement hooks (bench.py roofline leg): lp_step_timed launches exactly like
  * lp_step but through hipExtLaunchKernelGGL with a start/stop event pair bound to the
  * dispatch itself, so lp_timer_elapsed_ns returns the kernel's own begin->end time
  * (what rocprofv3 --kernel-trace reports), not a host-side interval.  The timer is a
  * caller-owned handle; lp_timer_elapsed_ns blocks until that launch has finished.     */
-int lp_timer_create(void** timer);
-int lp_timer_destroy(void* timer);
-int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);   /* LP_E_UNSUPPORTED for LP_FL_ES launches */
+LP_API int lp_timer_create(void** timer);
+LP_API int lp_timer_destroy(void* timer);
+LP_API int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);   /* LP_E_UNSUPPORTED for LP_FL_ES launches */
 /* n timed launches of the same descriptor from one host call (rng_offset + i per launch), so the GPU stays
  * busy between them: launched one by one through an FFI the host paces a ~10 us kernel and every dispatch
  * starts on an idle chip (measured 13.0 us instead of the 10.5 us rocprofv3 reports for the same kernel). */
-int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n);
-int lp_timer_elapsed_ns(void* timer, double* ns);
+LP_API int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n);
+LP_API int lp_timer_elapsed_ns(void* timer, double* ns);
 
 /* K3  finalise: known-region reprojection + in-place write-back.
  * Replaces: lanpaint.py:154,156.                                               */
-int lp_finalize(const lp_final_desc* desc, void* stream);
+LP_API int lp_finalize(const lp_final_desc* desc, void* stream);
 
 /* Standalone N(0,1) fill with the generator the fused kernel uses: Philox2x32-10, one
  * block per latent element keyed on (seed, element, launch offset), Box-Muller; slot 0 =
  * cosine branch (POST stream), 1 = sine branch (PRE stream).  Lets tests reproduce the
  * in-kernel noise exactly.  Replaces torch.randn_like (lanpaint.py:252).               */
-int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream);
+LP_API int lp_philox_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t slot, void* stream);
 /* Fill `out` with what torch.randn(n_el, device=...) returns for generator state (seed, offset) on this device
  * (test hook for LP_RNG_TORCH; bg as in lp_step_desc.rng_bg).                                            */
-int lp_torch_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t bg, void* stream);
+LP_API int lp_torch_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, uint32_t bg, void* stream);
 
 /* K4  inner early-stop metric (earlystop.py:32-55).
  * lp_boundary_ring: ring[i] = (mask<=0.5) & any 4-neighbour(H,W) known, as fp32
@@ -545,8 +550,8 @@ int lp_torch_normal(float* out, int64_t n_el, uint64_t seed, uint64_t offset, ui
  *                   (NULL => acc[2..3] = 0).  acc is a device double[4]; the
  *                   reduction order is fixed, so results are deterministic.
  *                   block_scratch: device double[4 * scratch_blocks].          */
-int lp_boundary_ring(const float* mask, float* ring, int64_t planes, int32_t height, int32_t width, void* stream);
-int lp_wmse_pair(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el,
+LP_API int lp_boundary_ring(const float* mask, float* ring, int64_t planes, int32_t height, int32_t width, void* stream);
+LP_API int lp_wmse_pair(const float* a, const float* b, const float* mask, const float* ring, int64_t n_el,
                  double* acc, double* block_scratch, int32_t scratch_blocks, void* stream);
 
 /* Bytes of the bit-packed form of an n_el-element mask (whole 64-bit ballot words). */
@@ -557,12 +562,12 @@ int lp_wmse_pair(const float* a, const float* b, const float* mask, const float*
  * denoise_mask, bit = !(v > 0.5) (nodes.py:281-283 folded in).  `bits` holds LP_MASK_BITS_BYTES(n_el)
  * bytes, 8-byte aligned; tail bits are 0.  `nonbinary` (nullable, device int32) is set to 1 when an
  * input value is neither 0 nor 1 (soft mask: the packed form would not be equivalent).             */
-int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream);
+LP_API int lp_pack_mask(const float* mask, int64_t n_el, uint32_t flags, void* bits, int32_t* nonbinary, void* stream);
 /* Same launch, which also writes the fp32 latent_mask (1 = known; nodes.py:281-283 with LP_FL_MASK_DENOISE) to `latent_out`
  * (n_el floats; may be the same buffer as `mask` when flags == 0 -- the kernel declares neither pointer restrict).  One launch re-derives BOTH forms of a mask whose tensor may have been
  * rewritten in place -- what KSamplerX0Inpaint does on every sigma call for tensors that carry no version counter
  * (torch.inference_mode), where the reference recomputes the mask on every call anyway (nodes.py:277-283).             */
-int lp_pack_mask_latent(const float* mask, int64_t n_el, uint32_t flags, void* bits, float* latent_out, void* stream);
+LP_API int lp_pack_mask_latent(const float* mask, int64_t n_el, uint32_t flags, void* bits, float* latent_out, void* stream);
 
 /* ATen's nearest-exact source-index rules (F.interpolate(mode="nearest-exact"): nodes.py:78,88,110,125-127,1079,1278-1287).
  * "Bit-exact mask index math" means the rule of the kernel torch runs on the device the REFERENCE holds the mask on -- the
@@ -586,7 +591,7 @@ int lp_pack_mask_latent(const float* mask, int64_t n_el, uint32_t flags, void* b
  * (0 = the scalar rule: every caller of ABI <= 17 passed 0 or 1 here),
  * with dst batch b reading src batch b % src_b and dst channel c reading src
  * channel c % src_c (the reference's repeat + slice).  `flags`: LP_RESHAPE_BINARIZE | (rule << LP_RESHAPE_RULE_SHIFT). */
-int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
+LP_API int lp_reshape_mask(const float* src, int32_t src_b, int32_t src_c, int32_t src_f, int32_t src_h, int32_t src_w,
                     float* dst, int32_t batch, int32_t channels, int32_t dst_f, int32_t dst_h, int32_t dst_w,
                     int32_t temporal_taps, int32_t flags, void* stream);
 
@@ -611,7 +616,7 @@ typedef struct lp_blend_desc {
     int32_t nn_rule;                          /* LP_NN_ATEN_* rule of the mask resample (ABI 18) */
     int32_t reserved0;
 } lp_blend_desc;
-int lp_mask_blend(const lp_blend_desc* desc, void* stream);
+LP_API int lp_mask_blend(const lp_blend_desc* desc, void* stream);
 
 #ifdef __cplusplus
 }

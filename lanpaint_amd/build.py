@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["step_kernel.hip", "aux_kernels.hip", "blend_kernel.hip", "cabi.hip"]
-HEADERS = [os.path.join(CSRC, "lp_common.h"), os.path.join(ROOT, "include", "lanpaint_hip.h")]
+HEADERS = [os.path.join(CSRC, "lp_common.h"), os.path.join(CSRC, "exports.map"), os.path.join(ROOT, "include", "lanpaint_hip.h")]
 OUT = os.path.join(HERE, "liblanpaint_hip.so")
 
 
@@ -57,8 +57,10 @@ def _compile(out, extra, verbose):
     # -fhip-fp32-correctly-rounded-divide-sqrt, -fno-fast-math: hipcc's defaults, spelled out because parity rests on them --
     # `/` and sqrtf are IEEE-rounded, and lp_common.h::div_shared equals IEEE division only while its reciprocal `1.0f / c` is
     # correctly rounded (tests/test_gpu_kernels.py::test_shared_divisor_emit_equals_ieee_division)
+    # -fvisibility=hidden: the extern "C" entry points (LP_API in include/lanpaint_hip.h) are the library's only dynamic symbols
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fno-fast-math",
-           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared",
+           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
            "-mllvm", "-amdgpu-kernarg-preload-count=14",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     cmd += extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]

@@ -25,33 +25,55 @@ def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend: Optional[str] = None, device: Optional[torch.device] = None, single_rank_group: bool = False) -> Tuple[int, int]:
+_FORCE_COLLECTIVES = False      # set by init(single_rank_group=True): a ONE-rank group goes through the real collectives
+
+
+def _collectives_on(group=None) -> bool:
+    """Is there somebody to talk to?  No process group: no.  A group of ONE rank: only when the real path was asked for
+    (`init(single_rank_group=True)`, the self-test; or LANPAINT_AMD_FORCE_COLLECTIVES=1) -- a host application's own
+    one-rank group (say a gloo group ComfyUI never created for us) must not turn every reduction into a collective: with
+    gloo that is a host copy, with nccl a per-iteration RCCL call on the host-stopper path."""
+    if not dist.is_initialized():
+        return False
+    if dist.get_world_size(group) > 1:
+        return True
+    return _FORCE_COLLECTIVES or os.environ.get("LANPAINT_AMD_FORCE_COLLECTIVES") == "1"
+
+
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None, single_rank_group: bool = False,
+         timeout_s: Optional[float] = None) -> Tuple[int, int]:
     """Initialise the default process group from the environment.  World size 1 is a no-op unless `single_rank_group`: then
-    a ONE-rank group is brought up on a free local port, so that the collectives below really go through the library
-    (RCCL for "nccl") instead of their no-group shortcuts -- `single_rank_selftest`, the GPU tests."""
+    a ONE-rank group is brought up over a file store (no port to race for), so that the collectives below really go through
+    the library (RCCL for "nccl") instead of their no-group shortcuts -- `single_rank_selftest`, the GPU tests.
+    `timeout_s`: rendezvous and collective timeout (a stuck peer raises instead of hanging the job)."""
+    global _FORCE_COLLECTIVES
+    import datetime
     rank, world, local_rank = env_world()
     if world <= 1 and not single_rank_group:
         return 0, 1
-    if world <= 1 and not dist.is_initialized():
-        import socket
-        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        kw = {}
-        if backend == "nccl":
-            device = device or torch.device("cuda", torch.cuda.current_device())
-            torch.cuda.set_device(device)
-            kw["device_id"] = device
-        import datetime
-        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                timeout=datetime.timedelta(seconds=120), **kw)
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if timeout_s is not None:
+        kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+    if world <= 1:
+        _FORCE_COLLECTIVES = True
+        if not dist.is_initialized():
+            import tempfile
+            if backend == "nccl":
+                device = device or torch.device("cuda", torch.cuda.current_device())
+                torch.cuda.set_device(device)
+                kw["device_id"] = device
+            kw.setdefault("timeout", datetime.timedelta(seconds=120))
+            store = tempfile.NamedTemporaryFile(prefix="lanpaint_amd_pg_", delete=False)
+            store.close()
+            try:
+                os.unlink(store.name)                  # the FileStore creates it; a stale file would be read as an old rendezvous
+            except OSError:
+                pass
+            dist.init_process_group(backend, init_method=f"file://{store.name}", rank=0, world_size=1, **kw)
         return 0, 1
     if not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        kw = {}
         if backend == "nccl":
             device = device or torch.device("cuda", local_rank)
             torch.cuda.set_device(device)
@@ -107,8 +129,7 @@ def broadcast_job(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0,
     single packed byte buffer (xGMI is per-link bound: one large transfer, not many small ones).
     Non-src ranks may pass None.  Returns {name: tensor} on `device` on every rank.  `stats` (optional dict) receives
     {"bytes": size of the packed buffer, "ms": wall time of the one data collective on this rank, "backend"}."""
-    if not dist.is_initialized():         # no process group: nothing to share with.  (A group of ONE rank does go through the
-        # collectives -- a one-rank RCCL group is how the code path is exercised on a one-GPU box.)
+    if not _collectives_on(group):        # nobody to share with (no group; a one-rank group unless the real path was asked for)
         return {k: (t.to(device) if device is not None else t) for k, t in (tensors or {}).items()}
     rank = dist.get_rank(group)
     header = [_pack_header(tensors) if rank == src else None]
@@ -146,7 +167,7 @@ def broadcast_job(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0,
 
 def reduce_throughput(elapsed_s: float, units: int, device: Optional[torch.device] = None, group=None) -> Tuple[float, int]:
     """(max elapsed over ranks, total units over ranks): whole-job throughput = units / elapsed."""
-    if not dist.is_initialized():
+    if not _collectives_on(group):
         return float(elapsed_s), int(units)
     dev = device if (device is not None and dist.get_backend(group) == "nccl") else (
         torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
@@ -170,7 +191,7 @@ def gather_rank_reports(report: dict, group=None) -> Optional[dict]:
     """Every rank contributes one small dict; rank 0 gets the evidence block of a multi-rank run:
     {backend, world_size, ranks_reporting, device_per_rank, rccl_version, per_rank_it_s, per_rank}.  None without a
     process group.  One object all-gather, outside any timed region."""
-    if not dist.is_initialized():
+    if not _collectives_on(group):
         return None
     world = dist.get_world_size(group)
     reports = [None] * world
@@ -188,7 +209,7 @@ def gather_rank_reports(report: dict, group=None) -> Optional[dict]:
 def all_reduce_stop_sums(acc: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the early-stop partial sums {sum(w d^2), sum(w)} x {inpaint, ring} over the ranks that
     share one (sharded) batch, in place; identity when no process group is up."""
-    if dist.is_initialized():
+    if _collectives_on(group):
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc
 
@@ -199,6 +220,7 @@ def single_rank_selftest(backend: Optional[str] = None, device_index: int = 0) -
     packed uint8 device broadcast), reduce_throughput (fp64 device all-reduces MAX / SUM), all_reduce_stop_sums,
     gather_rank_reports (all_gather_object) -- and compare what comes back with what went in, byte for byte.  Returns a
     JSON-able record; destroys the group it created."""
+    global _FORCE_COLLECTIVES
     import time
     use_cuda = torch.cuda.is_available()
     backend = backend or ("nccl" if use_cuda else "gloo")
@@ -241,5 +263,6 @@ def single_rank_selftest(backend: Optional[str] = None, device_index: int = 0) -
                 dist.destroy_process_group()
             except Exception:
                 pass
+            _FORCE_COLLECTIVES = False
     rec["total_s"] = time.perf_counter() - t0
     return rec

@@ -58,6 +58,14 @@ class NumpyBackend:
         return float(np.sum(a))
 
     @staticmethod
+    def sum(a):
+        return np.sum(a, dtype=np.float32)
+
+    @staticmethod
+    def clone(a):
+        return np.array(a, copy=True)
+
+    @staticmethod
     def ndim(a):
         return np.ndim(a)
 
@@ -109,6 +117,12 @@ class TorchBackend:
     def sum_float(self, a):
         return float(self.torch.sum(a))
 
+    def sum(self, a):
+        return self.torch.sum(a)
+
+    def clone(self, a):
+        return a.detach().clone()
+
     def ndim(self, a):
         return a.ndim
 
@@ -119,7 +133,7 @@ class TorchBackend:
         dst.copy_(src)
 
     def zeros_like_bool(self, a):
-        return self.torch.zeros(a.shape, dtype=self.torch.bool)
+        return self.torch.zeros_like(a, dtype=self.torch.bool)
 
     def to_f32(self, a):
         return a.to(self.torch.float32)
@@ -306,52 +320,59 @@ def abt_scale(abt_val: float) -> float:
     return min(1.0, max(0.0, 4.0 * c * (1.0 - c)))
 
 
-def boundary_weight(latent_mask: np.ndarray, inpaint_weight: np.ndarray) -> Optional[np.ndarray]:
+def boundary_weight(latent_mask, inpaint_weight, xp=None):
     """earlystop.py:32-49: inpaint pixels 4-adjacent (H,W) to a known pixel; 4-D only."""
-    if latent_mask.ndim != 4:
+    xp = xp or NumpyBackend()
+    if xp.ndim(latent_mask) != 4:
         return None
     known = latent_mask > 0.5
-    nb = np.zeros_like(known)
+    nb = xp.zeros_like_bool(known)
     nb[:, :, 1:, :] |= known[:, :, :-1, :]
     nb[:, :, :-1, :] |= known[:, :, 1:, :]
     nb[:, :, :, 1:] |= known[:, :, :, :-1]
     nb[:, :, :, :-1] |= known[:, :, :, 1:]
-    return ((~known) & nb).astype(np.float32) * inpaint_weight
+    return xp.to_f32((~known) & nb) * inpaint_weight
 
 
-def weighted_mse(a: np.ndarray, b: np.ndarray, w: np.ndarray) -> float:
+def weighted_mse(a, b, w, xp=None) -> float:
     """earlystop.py:52-55 (fp32 sums, +1e-12 in the denominator)."""
-    d2 = (a.astype(np.float32) - b.astype(np.float32)) ** 2
-    denom = np.sum(w, dtype=np.float32) + np.float32(1e-12)
-    return float(np.sum(d2 * w, dtype=np.float32) / denom)
+    xp = xp or NumpyBackend()
+    d2 = (xp.to_f32(a) - xp.to_f32(b)) ** 2
+    denom = xp.sum(w) + 1e-12
+    return float(xp.sum(d2 * w) / denom)
 
 
 class OracleEarlyStopper:
-    """earlystop.py:58-336 restated for the default metric (no custom distance_fn,
-    which is host Python in the reference and stays host Python in the product)."""
+    """earlystop.py:58-336 restated for the default metric (no custom distance_fn, which is host Python in the reference and
+    stays host Python in the product).  Works on either backend; `trace_sink` (a list) receives the reference's per-iteration
+    record (earlystop.py:315-334) with `tags` = (case_id, outer_step, bench_timestep)."""
 
-    def __init__(self, threshold: float, patience: int, latent_mask: np.ndarray, abt_mean: float):
+    def __init__(self, threshold: float, patience: int, latent_mask, abt_mean: float, xp=None, trace_sink=None,
+                 tags=(None, None, None)):
+        self.xp = xp = xp or NumpyBackend()
         self.enabled = (threshold > 0.0) and (patience > 0)
         self.patience_eff = max(1, patience) + 1
+        self.threshold = threshold
         self.threshold_eff = threshold * abt_scale(abt_mean) if self.enabled else threshold
+        self.abt_val = abt_mean
         self.inpaint = self.ring = None
         if self.enabled and self.threshold_eff <= 0.0:
             self.enabled = False
         if self.enabled:
-            self.inpaint = (1 - latent_mask).astype(np.float32)
-            if float(np.sum(self.inpaint)) < 1e-6:
+            self.inpaint = xp.to_f32(1 - latent_mask)
+            if xp.sum_float(self.inpaint) < 1e-6:
                 self.enabled = False
             else:
-                self.ring = boundary_weight(latent_mask, self.inpaint)
+                self.ring = boundary_weight(latent_mask, self.inpaint, xp)
         self.counter = 0
         self.anchor = None
         self.trace = []
+        self.trace_sink, self.tags = (trace_sink if isinstance(trace_sink, list) else None), tags
 
-    def _dist(self, a, b):
-        d = weighted_mse(a, b, self.inpaint)
-        if self.ring is not None:
-            d = max(d, weighted_mse(a, b, self.ring))
-        return d
+    def _pair(self, a, b):
+        d_in = weighted_mse(a, b, self.inpaint, self.xp)
+        d_ring = weighted_mse(a, b, self.ring, self.xp) if self.ring is not None else None
+        return d_in, d_ring, (d_in if d_ring is None else max(d_in, d_ring))
 
     def step(self, x_before, x_after, prev_state, state) -> bool:
         """earlystop.py:238-336."""
@@ -359,16 +380,18 @@ class OracleEarlyStopper:
             return False
         x0_prev = None if prev_state is None else prev_state.x0
         x0_cur = None if state is None else state.x0
+        d_ring = d_drift = None
         if x0_prev is not None and x0_cur is not None:
-            dist = self._dist(x0_cur, x0_prev)
+            d_in, d_ring, dist = self._pair(x0_cur, x0_prev)
         else:
-            dist = weighted_mse(x_after, x_before, self.inpaint)
+            d_in = dist = weighted_mse(x_after, x_before, self.inpaint, self.xp)
         if x0_cur is not None:
             if dist <= self.threshold_eff:
                 if self.anchor is None:
-                    self.anchor = np.array(x0_cur, copy=True)
+                    self.anchor = self.xp.clone(x0_cur)
                 else:
-                    dist = max(dist, self._dist(x0_cur, self.anchor))
+                    d_drift = self._pair(x0_cur, self.anchor)[2]
+                    dist = max(dist, d_drift)
             else:
                 self.anchor = None
         if dist <= self.threshold_eff:
@@ -378,6 +401,13 @@ class OracleEarlyStopper:
             self.anchor = None
         stop = self.counter >= self.patience_eff
         self.trace.append({"dist": dist, "counter": self.counter, "stopped": stop})
+        if self.trace_sink is not None:
+            self.trace_sink.append({"case_id": self.tags[0], "outer_step": self.tags[1], "bench_timestep": self.tags[2],
+                                    "inner_step": len(self.trace), "dist": dist, "dist_inpaint": d_in, "dist_ring": d_ring,
+                                    "dist_drift": d_drift, "threshold": float(self.threshold_eff),
+                                    "threshold_eff": float(self.threshold_eff), "patience_counter": int(self.counter),
+                                    "patience_eff": int(self.patience_eff), "abt": float(self.abt_val), "custom_dist": False,
+                                    "stopped": bool(stop)})
         return stop
 
 
@@ -567,12 +597,23 @@ class OracleLanPaint:
 
         stopper = None
         thr, pat = self.early_stop_threshold, self.early_stop_patience
-        if isinstance(model_options, dict) and isinstance(model_options.get("lanpaint_semantic_stop"), dict):
-            ss = model_options["lanpaint_semantic_stop"]
-            thr = float(ss.get("threshold", thr))
-            pat = int(ss.get("patience", pat))
-        if thr > 0.0 and pat > 0 and xp.name == "numpy":
-            stopper = OracleEarlyStopper(thr, pat, np.asarray(latent_mask), xp.mean_float(abt))
+        sink, tags = None, (None, None, None)
+        if isinstance(model_options, dict):
+            if isinstance(model_options.get("lanpaint_semantic_stop"), dict):                 # earlystop.py:74-95
+                ss = model_options["lanpaint_semantic_stop"]
+                thr = float(ss.get("threshold", thr))
+                pat = int(ss.get("patience", pat))
+                if pat > 0 and ss.get("min_steps") is not None:
+                    try:
+                        ms = int(ss.get("min_steps"))
+                    except (TypeError, ValueError):
+                        ms = 0
+                    if ms > 1:
+                        pat = max(pat, ms - 1)
+            sink = model_options.get("lanpaint_semantic_trace")
+            tags = (model_options.get("bench_case_id"), model_options.get("bench_outer_step"), model_options.get("bench_timestep"))
+        if thr > 0.0 and pat > 0:
+            stopper = OracleEarlyStopper(thr, pat, latent_mask, xp.mean_float(abt), xp=xp, trace_sink=sink, tags=tags)
             if not stopper.enabled:
                 stopper = None
         self.last_stopper = stopper

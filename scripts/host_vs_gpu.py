@@ -25,11 +25,14 @@ dev = torch.device("cuda", 0)
 sig_np = bench.flow_sigmas(n_sig) if flow else bench.karras_sigmas(n_sig)
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
 x0, y, noise, mask = bench.make_inputs(shape, flow, float(sig_np[0]), 0, dev, tt)
-mask = bench.attach_mask_format(mask, "bits")
+mode = sys.argv[3] if len(sys.argv) > 3 else "philox"
+if mode == "philox":
+    mask = bench.attach_mask_format(mask, "bits")
 sig_list = [torch.full((shape[0],), float(s), dtype=torch.float32, device=dev) for s in sig_np]
 times_list = [bench.times_from_sigma(s, flow) for s in sig_list]
 ratios = bench.euler_ratios(sig_list, len(shape))
-eng = LanPaint(bench.StubBackbone(flow), 5, 15.0, 5.0, 1.0, 0.2, rng="philox", graph=graph)
+eng = (LanPaint(bench.StubBackbone(flow), n_think, 15.0, 5.0, 1.0, 0.2, IS_FLOW=flow, rng="philox", graph=graph) if mode == "philox"
+       else LanPaint(bench.StubBackbone(flow), n_think, 15.0, 5.0, 1.0, 0.2, False, flow))       # the drop-in engine
 for _ in range(3):
     bench.schedule_pass(eng, x0, y, noise, mask, sig_list, times_list, ratios, n_think)
 torch.cuda.synchronize()
@@ -41,7 +44,7 @@ t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 calls = reps * n_sig
-print(f"{wl} graph={graph}: host enqueue {t_host / calls * 1e6:.1f} us per sigma call, wall {t_all / calls * 1e6:.1f} us per sigma call "
+print(f"{wl} graph={graph} mode={mode}: host enqueue {t_host / calls * 1e6:.1f} us per sigma call, wall {t_all / calls * 1e6:.1f} us per sigma call "
       f"({'host' if t_host > 0.9 * t_all else 'GPU'}-bound)")
 pr = cProfile.Profile()
 pr.enable()

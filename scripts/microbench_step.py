@@ -34,10 +34,11 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     dev = torch.device("cuda", 0)
     lib = _cabi.load()
-    bench.MASK_KIND = sys.argv[5] if len(sys.argv) > 5 else None
-    bench.MASK_FORMAT = os.environ.get("LANPAINT_AMD_BENCH_MASK_FORMAT", "bits")
+    mask_kind = sys.argv[5] if len(sys.argv) > 5 else None
+    mask_format = os.environ.get("LANPAINT_AMD_BENCH_MASK_FORMAT", "bits")
     half = os.environ.get("LANPAINT_AMD_BENCH_DTYPE") == "bf16"
-    d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase], model_dtype=torch.bfloat16 if half else None)
+    d, keep, n_el = bench.standalone_step(_cabi, wl, dev, PH[phase], model_dtype=torch.bfloat16 if half else None,
+                                          mask_kind=mask_kind, mask_format=mask_format)
     bufs = keep[0]
     if phase == "replacec":
         _b, _m, coef, sig, ve, abt = keep
@@ -115,7 +116,7 @@ def main():
     bytes_ = ({"steady": 36, "first": 32, "last": 36, "replace": 24, "replacec": 24}[phase] - (6 if half and phase != "replace" else 0)) * n_el
     env = {k: v for k, v in os.environ.items() if k.startswith("LANPAINT_AMD_TUNE")}
     print(f"{wl} {phase} n_el={n_el} us/launch={us:.3f} ({bytes_ / us / 1e3:.0f} GB/s algorithmic) "
-          f"heads={'bf16' if half else 'fp32'} rng={rng} mask={bench.MASK_KIND or 'default'}/{bench.MASK_FORMAT}"
+          f"heads={'bf16' if half else 'fp32'} rng={rng} mask={mask_kind or 'default'}/{mask_format}"
           f"{' soft' if os.environ.get('LANPAINT_AMD_BENCH_SOFT') else ''}{' hostxi' if os.environ.get('LANPAINT_AMD_BENCH_HOSTXI') else ''}"
           f"{' av' if os.environ.get('LANPAINT_AMD_BENCH_AV') else ''} region_skip={0 if os.environ.get('LANPAINT_AMD_NO_REGION_SKIP') else 1} torch_mul={us_mul:.3f}us finite={bool(torch.isfinite(bufs['x_t']).all())} env={env}", flush=True)
 

@@ -28,7 +28,6 @@ proc = psutil.Process()
 def inputs(shape, flow, seed=0):
     sig = bench.flow_sigmas(8) if flow else bench.karras_sigmas(8)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
-    bench.MASK_KIND = None
     x0, y, noise, mask = bench.make_inputs(shape, flow, float(sig[0]), seed, dev, tt)
     s = torch.full((shape[0],), float(sig[3]), device=dev)
     return x0, y, noise, mask, s, bench.times_from_sigma(s, flow)

@@ -125,6 +125,13 @@ def run_case(name):
         rec_d["trace_dist"] = np.asarray([t["dist"] for t in tr], dtype=np.float64)
         rec_d["trace_counter"] = np.asarray([t["patience_counter"] for t in tr], dtype=np.int64)
         rec_d["trace_stopped"] = np.asarray([t["stopped"] for t in tr], dtype=np.bool_)
+        # the whole per-iteration record the reference appends (earlystop.py:315-334); None -> NaN
+        nan = lambda v: np.nan if v is None else float(v)      # noqa: E731
+        for key in ("dist_inpaint", "dist_ring", "dist_drift", "threshold", "threshold_eff", "abt"):
+            rec_d["trace_" + key] = np.asarray([nan(t[key]) for t in tr], dtype=np.float64)
+        rec_d["trace_inner_step"] = np.asarray([t["inner_step"] for t in tr], dtype=np.int64)
+        rec_d["trace_patience_eff"] = np.asarray([t["patience_eff"] for t in tr], dtype=np.int64)
+        rec_d["trace_keys"] = np.asarray(sorted(tr[0].keys()) if tr else [])
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec_d)
     return len(rec.draws), model.calls
 

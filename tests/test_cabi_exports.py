@@ -25,6 +25,20 @@ def test_header_functions_are_exported_and_bound(hip_lib):
         assert n in _cabi.EXPORTS, f"{n} has no ctypes binding"
 
 
+def test_the_c_abi_is_the_only_dynamic_surface(hip_lib):
+    """`nm -D --defined-only` of the product library lists the entry points of include/lanpaint_hip.h and
+    nothing else -- no lp::*_dispatch, no kernel handles, no __device_stub__ (built with -fvisibility=hidden, every entry
+    point LP_API, the rest made local by csrc/exports.map)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _cabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert syms == _declared_functions(), sorted(set(syms) ^ set(_declared_functions()))
+    assert all(s.startswith("lp_") for s in syms) and len(syms) == len(_cabi.EXPORTS)
+    hdr = open(HEADER).read()
+    for n in syms:                                    # every declaration carries the visibility attribute
+        assert re.search(r"LP_API\s+[a-z_0-9 \*]+\b%s\s*\(" % n, hdr), n
+
+
 def test_abi_version_and_strerror(hip_lib):
     assert hip_lib.lp_abi_version() == _cabi.ABI_VERSION
     assert hip_lib.lp_strerror(0) == b"ok"

@@ -23,8 +23,7 @@ def _job(workload, mask_format, seed=0, mask_kind=None):
     shape, flow, n_sig, n_think = bench.WORKLOADS[workload]
     sig_np = bench.flow_sigmas(n_sig) if flow else bench.karras_sigmas(n_sig)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
-    bench.MASK_KIND = mask_kind
-    x0, y, noise, mask = bench.make_inputs(shape, flow, float(sig_np[0]), seed, dev, tt)
+    x0, y, noise, mask = bench.make_inputs(shape, flow, float(sig_np[0]), seed, dev, tt, mask_kind=mask_kind)
     mask = bench.attach_mask_format(mask, mask_format)
     sig_list = [torch.full((shape[0],), float(s), dtype=torch.float32, device=dev) for s in sig_np]
     times_list = [bench.times_from_sigma(s, flow) for s in sig_list]
@@ -117,14 +116,25 @@ def test_the_check_has_teeth():
 def test_bench_line_carries_the_parity_check():
     """`python bench.py` prints `parity_check` for the configuration it times and a `value` only next to ok = true."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "0",
-           "--prewarm-seconds", "0.05", "--no-cpu-baseline", "--no-large-shape", "--extras", "0"]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=500)
-    assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "0",
+               "--prewarm-seconds", "0.05", "--no-cpu-baseline", "--no-summary", "--sidecar", os.path.join(tmp, "x.json")]
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=500)
+        assert p.returncode == 0, p.stderr[-3000:]
+        side = json.load(open(os.path.join(tmp, "x.json")))
+    last = p.stdout.rstrip().splitlines()[-1]
+    assert last.startswith("{") and len(last) < 6000
+    line = json.loads(last)
     pc = line["parity_check"]
-    assert pc["ok"] and pc["sigmas_checked"] == 30 and pc["launch_modes"] == {"graph": 30}
+    # the default run IS the drop-in engine: the reference's torch stream, graph="auto" (captured on the job's second call)
+    assert pc["ok"] and pc["sigmas_checked"] == 30 and pc["launch_modes"] == {"torch": 30}
     assert pc["mse_x"] < 1e-9 and pc["mse_denoised_max"] < 1e-9 and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["rng"] == "torch" and cfg["graph"] == "auto" and cfg["mask_format"] == "f32" and cfg["mask_seen_by_kernels"] == "bits"
+    assert cfg["captured_calls"] == 1 and "drop-in" in cfg["engine"]
+    assert "RNG" not in line["roofline"]["kernel"] and ", 1, false, 0>" in line["roofline"]["kernel"]      # the torch-stream instantiation
+    assert side["parity_check"]["draws"] == 270 and side["roofline"]["launches_timed"] == 120 and abs(side["line"]["value"] - line["value"]) <= 1e-5 * line["value"]
 
 
 @pytest.mark.parametrize("workload,max_sigmas", [("c2_sdxl", None), ("c5_wan", 2)])

@@ -14,10 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _cmd(backend, gpus=2, extra=()):
+def _cmd(backend, gpus=2, extra=(), sidecar=None):
     return [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dist-backend", backend, "--steps", "3",
             "--warmup", "1", "--repeats", "1", "--prewarm-seconds", "0.05", "--cpu-seconds", "1.0", "--no-large-shape",
-            "--parity-sigmas", "4", *extra]            # (every rank checks its own replica: keep the numpy passes short here)
+            "--parity-sigmas", "4", *(("--sidecar", sidecar) if sidecar else ()), *extra]
+            # (every rank checks its own replica: keep the numpy passes short here)
 
 
 def _env():
@@ -25,18 +26,27 @@ def _env():
 
 
 def _run(backend, extra=(), gpus=2, timeout=600):
-    p = subprocess.run(_cmd(backend, gpus, extra), env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    """(the headline line, the side-car's full `dist` block with the per-rank reports)"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        side = os.path.join(tmp, "extras.json")
+        p = subprocess.run(_cmd(backend, gpus, extra, side), env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and p.stdout.rstrip().endswith(lines[0]), p.stdout[-2000:]      # ONE line, the last thing on stdout
+        assert len(lines[0]) < 6000, len(lines[0])
+        line = json.loads(lines[0])
+        line["_dist_full"] = json.load(open(side))["dist"]
+    return line
 
 
 def _check(line, backend):
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
     assert line["collective"] == ("rccl" if backend == "nccl" else backend)         # top level: impossible to miss
     assert line["parity_check"]["ok"]
-    d = line["dist"]
+    ds, d = line["dist"], line["_dist_full"]
+    assert "per_rank" not in ds and ds["world_size"] == 2 and ds["it_s"]["min"] > 0 and ds["iterations_per_rank"] == [3 * line["config"]["iterations_per_step"]]
+    assert ds["distinct_final_checksums"] == 2 and ds["parity_ok_all_ranks"] and ds["slowest_rank"] in (0, 1)
     assert line["distinct_devices"] == d["distinct_devices"] and d["shared_checksums_equal"]
     assert d["backend"] == backend and d["world_size"] == 2 and d["ranks_reporting"] == 2
     assert d["launcher"] == "bench.py self-spawn" and d["collectives_in_timed_region"] == 0
@@ -103,7 +113,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
     line = json.loads(lines[0])
     d = line["dist"]
     assert line["n_gpus"] == 2 and d["world_size"] == d["ranks_reporting"] == 2 and d["launcher"] == "external"
-    assert all(r["iterations"] == 3 * line["config"]["iterations_per_step"] for r in d["per_rank"])
+    assert d["iterations_per_rank"] == [3 * line["config"]["iterations_per_step"]] and d["distinct_final_checksums"] == 2
 
 
 @pytest.mark.timeout(1500)
@@ -117,9 +127,9 @@ def test_bench_eight_ranks_rehearse_the_multi_gpu_configurations_baseline_names(
     import torch
     backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
     line = _run(backend, gpus=8, timeout=1400,
-                extra=("--workload", workload, "--steps", "2", "--repeats", "0", "--no-cpu-baseline", "--extras", "0",
-                       "--parity-sigmas", "2"))
-    d = line["dist"]
+                extra=("--workload", workload, "--steps", "2", "--repeats", "0", "--no-cpu-baseline", "--parity-sigmas", "2"))
+    d = line["_dist_full"]
+    assert "per_rank" not in line["dist"] and line["dist"]["world_size"] == 8 and line["dist"]["distinct_final_checksums"] == 8
     assert line["n_gpus"] == 8 and d["world_size"] == d["ranks_reporting"] == 8 and line["collective"] == ("rccl" if backend == "nccl" else "gloo")
     assert line["config"]["rows_per_gpu"] == rows and line["config"]["global_rows"] == 8 * rows == d["global_rows"]
     assert d["collectives_in_timed_region"] == 0 and d["shared_checksums_equal"]

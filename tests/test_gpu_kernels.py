@@ -472,11 +472,7 @@ def test_uint8_mask_flag_through_the_c_abi(lib):
     for phase in (_cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT, _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT):
         res = []
         for fmt in ("f32", "u8"):
-            bench.MASK_FORMAT = fmt
-            try:
-                d, keep, _n = bench.standalone_step(_cabi, "c1_sd15", dev, phase)
-            finally:
-                bench.MASK_FORMAT = "bits"
+            d, keep, _n = bench.standalone_step(_cabi, "c1_sd15", dev, phase, mask_format=fmt)
             assert bool(d.flags & _cabi.LP_FL_MASK_U8) == (fmt == "u8")
             _cabi.check(lib.lp_step(ctypes.byref(d), st), "lp_step")
             torch.cuda.synchronize()
@@ -587,12 +583,7 @@ def test_region_aware_streams_change_nothing_but_the_traffic(lib, kind, phase, r
     ph = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
           "first": _cabi.LP_PH_POST_FIRST | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
           "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT}[phase]
-    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
-    bench.MASK_KIND, bench.MASK_FORMAT = kind, "bits"
-    try:
-        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph)
-    finally:
-        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph, mask_kind=kind, mask_format="bits")
     bufs = keep[0]
     if rng == "torch":
         from lanpaint_amd import LanPaint
@@ -626,13 +617,8 @@ def test_region_aware_replace_and_finalize_change_nothing_but_the_traffic(lib, k
     import bench
     from lanpaint_amd import _cabi
     dev = torch.device("cuda", 0)
-    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
-    bench.MASK_KIND, bench.MASK_FORMAT = kind, "bits"
-    try:
-        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev,
-                                              _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS)
-    finally:
-        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev,
+                                              _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS, mask_kind=kind, mask_format="bits")
     bufs, mask, coef, sig, ve, abt = keep
     d.t_ve, d.t_abt, d.t_rsig, d.t_ve_stride, d.t_abt_stride, d.t_rsig_stride = ve.data_ptr(), abt.data_ptr(), sig.data_ptr(), 1, 1, 1
     d.coef_out = coef.data_ptr()
@@ -684,12 +670,7 @@ def test_half_width_streams_in_lane_pairs_equal_the_eight_byte_path(lib, kind, p
     ph = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
           "first": _cabi.LP_PH_POST_FIRST | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
           "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT}[phase]
-    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
-    bench.MASK_KIND, bench.MASK_FORMAT = kind, "bits"
-    try:
-        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph, model_dtype=dt)
-    finally:
-        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph, model_dtype=dt, mask_kind=kind, mask_format="bits")
     bufs = keep[0]
     # copies of the two heads and an x_in buffer 8 bytes (4 half elements) off a 16-byte boundary
     pad = {k: torch.zeros(n_el + 8, dtype=dt, device=dev) for k in ("x0", "x0b", "x_in")}
@@ -795,12 +776,7 @@ def test_shared_divisor_emit_equals_ieee_division(lib, phase):
     dev = torch.device("cuda", 0)
     ph = {"steady": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_PRE_HALF | _cabi.LP_PH_EMIT,
           "last": _cabi.LP_PH_POST_STEADY | _cabi.LP_PH_EMIT}[phase]
-    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
-    bench.MASK_KIND, bench.MASK_FORMAT = "temporal", "bits"
-    try:
-        d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph)
-    finally:
-        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    d, keep, n_el = bench.standalone_step(_cabi, "c5_wan", dev, ph, mask_kind="temporal", mask_format="bits")
     bufs = keep[0]
     bufs["x_t"].mul_(37.5)                      # quotients over a few binades
     st = torch.cuda.current_stream().cuda_stream
@@ -828,12 +804,7 @@ def test_ve_replace_launch_shared_divisor_equals_ieee_division(lib):
     from lanpaint_amd import _cabi
     dev = torch.device("cuda", 0)
     ph = _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS
-    old_kind, old_fmt = bench.MASK_KIND, bench.MASK_FORMAT
-    bench.MASK_KIND, bench.MASK_FORMAT = "box", "bits"
-    try:
-        d, keep, n_el = bench.standalone_step(_cabi, "c3_sdxl_b4", dev, ph)
-    finally:
-        bench.MASK_KIND, bench.MASK_FORMAT = old_kind, old_fmt
+    d, keep, n_el = bench.standalone_step(_cabi, "c3_sdxl_b4", dev, ph, mask_kind="box", mask_format="bits")
     bufs, _m, coef, sig, ve, abt = keep
     bufs["x"].mul_(23.0)
     d.t_ve, d.t_abt, d.t_rsig, d.t_ve_stride, d.t_abt_stride, d.t_rsig_stride = ve.data_ptr(), abt.data_ptr(), sig.data_ptr(), 1, 1, 1

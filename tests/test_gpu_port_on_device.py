@@ -1,11 +1,13 @@
-"""The UNMODIFIED reference engine ON the MI355X as the direct parity arbiter.
+"""The op-for-op port of the reference engine ON the MI355X as the same-seed arbiter.
 
-`oracle/_ref` is /root/reference/src/LanPaint/lanpaint.py:7-328 compiled where it lies (oracle/build_ref.py; bytecode, no
-source text in this repository).  Here it runs on `cuda` tensors -- its ~164 eager ATen launches per think iteration, its own
-`torch.randn_like` draws -- next to the product engine built with NO optional keyword (`rng="torch"`, `graph="auto"`, the
-reference's fp32 mask), both started from the same `torch.manual_seed`: BASELINE.json's "identical (seed, latent, mask,
-sigmas)".  No oracle and no recorded xi stream sit in between; every sigma call's returned `out` and in-place `x` are compared
-directly, and the device generator must end in the same state (the product generates the reference's draws inside its step
+The reference is a Python package and does not travel to the GPU box in any form (no source, no bytecode).  What runs here is
+`oracle/lanpaint_oracle.py` -- the CPU restatement pinned to reference-generated fixtures (tests/test_oracle_golden.py, all
+array backends; the early-stop trace records included) -- handed DEVICE tensors through its torch backend: the reference's
+eager ATen call sequence (~164 launches per think iteration), drawing its noise with `torch.randn_like` from the device
+generator in the reference's order.  Next to it the product engine built with NO optional keyword (`rng="torch"`,
+`graph="auto"`, the reference's fp32 mask), both started from the same `torch.manual_seed`: BASELINE.json's "identical (seed,
+latent, mask, sigmas)".  No recorded xi stream sits in between; every sigma call's returned `out` and in-place `x` are
+compared directly, and the device generator must end in the same state (the product generates the draws inside its step
 kernel and advances the generator by what they consume).
 
 Tolerance (fp32, stated): max-abs <= 2e-5 * max(1, |ref|_inf) and MSE <= 1e-9 * max(1, |ref|_inf)^2 per tensor -- four orders
@@ -38,14 +40,26 @@ class TwoHeads:
         return 0.9 * x, 0.8 * x
 
 
+class PortOnDevice:
+    """The port behind the reference's constructor / call signature (lanpaint.py:8,44): the replace step goes through the
+    model_sampling's own noise_scaling like the reference's does (lanpaint.py:84-92)."""
+
+    def __init__(self, Model, NSteps, Friction, Lambda, Beta, StepSize, IS_FLUX=False, IS_FLOW=False, EarlyStopThreshold=0.0,
+                 EarlyStopPatience=1, EarlyStopHook=None, MinStepFrac=0.0):
+        from oracle.lanpaint_oracle import OracleLanPaint, TorchBackend
+        ms = Model.inner_model.model_sampling
+        self.inner_model = Model
+        self.port = OracleLanPaint(Model, NSteps, Friction, Lambda, Beta, StepSize, is_flux=IS_FLUX, is_flow=IS_FLOW,
+                                   early_stop_threshold=EarlyStopThreshold, early_stop_patience=EarlyStopPatience,
+                                   min_step_frac=MinStepFrac, backend=TorchBackend(), noise_scaling=ms.noise_scaling,
+                                   noise_scale=float(getattr(ms, "noise_scale", 1.0)))
+
+    def __call__(self, x, latent_image, noise, sigma, latent_mask, current_times, model_options, seed, n_steps=None, **kw):
+        return self.port(x, latent_image, noise, sigma, latent_mask, current_times, model_options, seed, n_steps=n_steps, **kw)
+
+
 def _reference_class():
-    from oracle import ref_engine
-    cls = ref_engine.load_reference()
-    if cls is None:
-        if ref_engine.manifest() is not None:
-            pytest.fail("oracle/_ref is staged but does not load (bytecode of another CPython?): rebuild with `make -C oracle ref`")
-        pytest.skip("oracle/_ref is not staged in this checkout (built from /root/reference by __graft_entry__.build())")
-    return cls
+    return PortOnDevice
 
 
 def _job(workload, row_ramp=None, n_sig=None):
@@ -56,7 +70,6 @@ def _job(workload, row_ramp=None, n_sig=None):
     shape, flow, ns, n_think = bench.WORKLOADS[workload]
     sig_np = bench.flow_sigmas(ns) if flow else bench.karras_sigmas(ns)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
-    bench.MASK_KIND = None
     x0, y, noise, mask = bench.make_inputs(shape, flow, float(sig_np[0]), 0, dev, tt)
     ramp = np.ones(shape[0], np.float32) if row_ramp is None else np.asarray(row_ramp, np.float32)
     sig_list = [tt(np.float32(s) * ramp) for s in sig_np]
@@ -131,7 +144,7 @@ def _same_seed_run(job, seed, inference=False, **product_kw):
     return mine, worst
 
 
-def test_c2_whole_schedule_reference_on_gpu_vs_default_engine_same_seed():
+def test_c2_whole_schedule_port_on_gpu_vs_default_engine_same_seed():
     """BASELINE configs[1]: SDXL 1x4x128x128, 30 Karras sigmas x 5 think iterations -- 30 sigma calls, 270 randn draws."""
     job = _job("c2_sdxl")
     mine, worst = _same_seed_run(job, 20250924)
@@ -141,7 +154,7 @@ def test_c2_whole_schedule_reference_on_gpu_vs_default_engine_same_seed():
     assert worst[1] < 1e-10, worst                                   # what the build achieves
 
 
-def test_c2_reference_on_gpu_vs_default_engine_under_inference_mode():
+def test_c2_port_on_gpu_vs_default_engine_under_inference_mode():
     """ComfyUI runs its nodes under torch.inference_mode(): tensors without version counters (the first 8 sigma calls)."""
     job = _job("c2_sdxl", n_sig=8)
     _same_seed_run(job, 7, inference=True)
@@ -170,7 +183,7 @@ def test_c4_flux_flow_schedule_ten_iterations_per_sigma():
 
 
 @pytest.mark.parametrize("kw", [dict(graph=False), dict(graph=True)])
-def test_c2_reference_on_gpu_vs_forced_launch_modes(kw):
+def test_c2_port_on_gpu_vs_forced_launch_modes(kw):
     """The same comparison with the launch mode forced (eager launches / hipGraph replay from the first call), 10 sigmas."""
     job = _job("c2_sdxl", n_sig=10)
     _same_seed_run(job, 11, **kw)
@@ -213,7 +226,7 @@ def _walk_with_options(engine, job, seed, options_for_call, extra_kw=None):
     ("c5_wan", 2000.0, 1, 6, 2, None),    # 5-D video latent: no ring weight (earlystop.py:32-50 returns None)
 ], ids=["c2_patience1", "c2_patience2", "c2_never_fires", "c3_rows", "c5_video"])
 @pytest.mark.parametrize("kw", [{}, {"graph": True}], ids=["default_engine", "gated_graph_launches"])
-def test_inner_early_stop_reference_on_gpu_vs_default_engine_same_seed(workload, thr, pat, n_think, n_sig, ramp, kw):
+def test_inner_early_stop_port_on_gpu_vs_default_engine_same_seed(workload, thr, pat, n_think, n_sig, ramp, kw):
     """earlystop.py's stopper inside the reference loop on the GPU (it breaks out of its Python loop and stops drawing) next
     to the product's device-side verdict (graph launches gated on the device, the generator rewound by the draws the
     skipped iterations would have made): per sigma call the same iteration count, the same trace records, outputs inside the
@@ -256,7 +269,7 @@ def ref_iterations(ref, ran):
 
 @pytest.mark.parametrize("shape,split,rows_differ", [((1, 8, 66000), 40001, False), ((3, 4, 777), 500, True)],
                          ids=["one_row_16B_lanes", "rows_on_their_own_time_pairs"])
-def test_av_pack_reference_on_gpu_vs_default_engine_same_seed(shape, split, rows_differ):
+def test_av_pack_port_on_gpu_vs_default_engine_same_seed(shape, split, rows_differ):
     """The flat audio+video pack (lanpaint.py:60-74, 173-180: per-element blended times, the audio correction on the score)
     through the reference on the GPU and through the product's two-row table path, same seed, three calls with moving times."""
     import torch
@@ -290,7 +303,7 @@ def test_av_pack_reference_on_gpu_vs_default_engine_same_seed(shape, split, rows
 
 
 @pytest.mark.parametrize("variant", ["is_flux", "soft_mask", "undeclared_noise_scaling", "single_head_backbone"])
-def test_engine_variants_reference_on_gpu_vs_default_engine_same_seed(variant):
+def test_engine_variants_port_on_gpu_vs_default_engine_same_seed(variant):
     """IS_FLUX (lanpaint.py:20-22 folds it into the flow form), a soft mask (per-element replace / score weights), a
     model_sampling the product cannot recognise (its noise_scaling is called back, lanpaint.py:86-92), and a backbone that
     returns ONE tensor (unpack_model_output's list / tensor branches, lanpaint.py:31-46)."""
@@ -327,7 +340,7 @@ def test_engine_variants_reference_on_gpu_vs_default_engine_same_seed(variant):
 
 
 @pytest.mark.parametrize("kw", [{}, {"graph": True}], ids=["default_engine", "gated_graph_launches"])
-def test_av_pack_with_inner_early_stop_reference_on_gpu_vs_default_engine_same_seed(kw):
+def test_av_pack_with_inner_early_stop_port_on_gpu_vs_default_engine_same_seed(kw):
     """Both at once: the reference's stopper on a flat audio+video pack (threshold from the mean of the BLENDED abt tensor,
     earlystop.py:104-110) against the product on the two-row table -- watched eager launches (default engine, a fresh options
     dict per call) and the device-gated launches of a replayed graph (round 5)."""

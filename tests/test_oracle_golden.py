@@ -128,3 +128,40 @@ def test_oracle_on_torch_backend_matches_numpy():
               tuple(t(v) for v in case["times"]), None, 0)
     assert_close(x.numpy(), g["x_out"], "torch-backend x", rel=3e-6)
     assert_close(out.numpy(), g["out"], "torch-backend out", rel=3e-6)
+
+
+TRACE_CASES = [n for n in sorted(gc.CASES) if (gc.CASES[n].get("model_options") or {}).get("lanpaint_semantic_stop")]
+
+
+@pytest.mark.parametrize("backend", ["numpy", "torch"])
+@pytest.mark.parametrize("name", TRACE_CASES)
+def test_port_writes_the_references_trace_records(name, backend):
+    """The record the reference's stopper appends per inner iteration (earlystop.py:315-334: fifteen keys) as the port writes
+    it into `model_options["lanpaint_semantic_trace"]`, on both array backends -- the torch one is what the GPU suite runs on
+    the device as the same-seed arbiter (tests/test_gpu_port_on_device.py), so it is pinned here to what the unmodified
+    reference wrote into the fixture."""
+    import torch
+    from oracle.lanpaint_oracle import TorchBackend
+    case, g = gc.build_case(name), load_golden(name)
+    conv = (lambda a: a) if backend == "numpy" else (lambda a: torch.from_numpy(np.ascontiguousarray(a)))
+    it = iter([conv(d) for d in xi_list(g)])
+    h = case["hyper"]
+    eng = OracleLanPaint(MODELS[case["model"]](flow=case["flow"]), h["NSteps"], h["Friction"], h["Lambda"], h["Beta"], h["StepSize"],
+                         is_flow=case["flow"], min_step_frac=h["MinStepFrac"], randn=lambda like: next(it),
+                         backend=None if backend == "numpy" else TorchBackend())
+    mo = {k: dict(v) if isinstance(v, dict) else v for k, v in case["model_options"].items()}
+    mo.update({"lanpaint_semantic_trace": [], "bench_case_id": "case-7", "bench_outer_step": 3, "bench_timestep": 0.25})
+    x = conv(case["x"].copy())
+    out = eng(x, conv(case["y"]), conv(case["noise"]), conv(case["sigma"]), conv(case["mask"]), tuple(conv(t) for t in case["times"]),
+              mo, 0, n_steps=case["n_steps"])
+    assert_matches_golden(np.asarray(x), np.asarray(out), g, name, rel=3e-6)
+    tr = mo["lanpaint_semantic_trace"]
+    assert len(tr) == len(g["trace_dist"]) and sorted(tr[0]) == list(g["trace_keys"])
+    assert [r["inner_step"] for r in tr] == list(g["trace_inner_step"]) and [r["patience_eff"] for r in tr] == list(g["trace_patience_eff"])
+    assert [r["patience_counter"] for r in tr] == list(g["trace_counter"]) and [r["stopped"] for r in tr] == list(g["trace_stopped"])
+    assert all(r["case_id"] == "case-7" and r["outer_step"] == 3 and r["bench_timestep"] == 0.25 and r["custom_dist"] is False for r in tr)
+    for key in ("dist", "dist_inpaint", "dist_ring", "dist_drift", "threshold", "threshold_eff", "abt"):
+        want = g["trace_" + key]
+        got = np.asarray([np.nan if r[key] is None else r[key] for r in tr], dtype=np.float64)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), key            # None exactly where the reference has None
+        np.testing.assert_allclose(got[~np.isnan(got)], want[~np.isnan(want)], rtol=2e-5, err_msg=key)
