@@ -37,7 +37,7 @@ from . import _cabi
 from ._cabi import (LP_FL_ES, LP_FL_ES_GATED, LP_FL_ES_CLOSE, LP_FL_CFG_FUSED, LP_FL_FLOW, LP_FL_MASK_BITS, LP_FL_MASK_U8, LP_FL_XIN_BF16, LP_FL_XIN_F16, LP_FL_PER_ELEMENT, LP_FL_WRITE_X0S, LP_FL_X0_BF16, LP_FL_X0_F16, LP_FL_X0S_GIVEN,
                     LP_PH_EMIT, LP_PH_POST_FIRST, LP_PH_POST_STEADY, LP_PH_PRE_HALF, LP_PH_REPLACE, LP_REPLACE_FLOW,
                     LP_REPLACE_KNOWN, LP_REPLACE_VE)
-from .earlystop import LanPaintEarlyStopper
+from .earlystop import HostStopper, StopOptions
 from .types import FusedCFGHeads, LangevinState
 
 def raw_stream(device) -> int:
@@ -58,6 +58,15 @@ def tensor_version(t: torch.Tensor) -> int:
         return t._version
     except RuntimeError:
         return -1
+
+
+def _state_x0(state):
+    """x0 of a think-loop state as an overridden langevin_dynamics may return it: a LangevinState, a legacy tuple, or None."""
+    if isinstance(state, LangevinState):
+        return state.x0
+    if isinstance(state, tuple) and len(state) >= 3:
+        return state[2]
+    return None
 
 
 def _as_f32c(t: torch.Tensor) -> torch.Tensor:
@@ -533,30 +542,13 @@ class LanPaint:
 
     # ------------------------------------------------------------------ inner early stop, host side
     def _es_options(self, model_options):
-        """The part of LanPaintEarlyStopper.from_options that needs no device data (earlystop.py:63-103): threshold,
-        patience (with the legacy min_steps floor), distance_fn, trace list.  None = the inner early stop is off."""
-        opts = model_options.get("lanpaint_semantic_stop") if isinstance(model_options, dict) else None
-        threshold, patience, fn = float(self.early_stop_threshold), int(self.early_stop_patience), self.early_stop_hook
-        if isinstance(opts, dict):
-            threshold = float(opts.get("threshold", threshold))
-            patience = int(opts.get("patience", patience))
-            fn = opts.get("distance_fn", fn)
-            if patience > 0 and opts.get("min_steps") is not None:
-                try:
-                    min_steps = int(opts.get("min_steps"))
-                except (TypeError, ValueError):
-                    min_steps = 0
-                if min_steps > 1:
-                    patience = max(patience, min_steps - 1)
-        if not (threshold > 0.0 and patience > 0):
+        """The inner early stop's options for this call (earlystop.StopOptions: the reference's `lanpaint_semantic_stop` /
+        `lanpaint_semantic_trace` contract), plus where the verdict is formed.  None = off."""
+        o = StopOptions.parse(model_options, self.early_stop_threshold, self.early_stop_patience, self.early_stop_hook)
+        if o is None:
             return None
-        trace = model_options.get("lanpaint_semantic_trace") if isinstance(model_options, dict) else None
-        tags = (None, None, None)
-        if isinstance(trace, list):
-            tags = (model_options.get("bench_case_id"), model_options.get("bench_outer_step"), model_options.get("bench_timestep"))
-        return {"threshold": threshold, "patience_eff": max(1, patience) + 1, "distance_fn": fn,
-                "trace": trace if isinstance(trace, list) else None, "tags": tags,
-                "device": not callable(fn) and self.early_stop_group is None}
+        return {"threshold": o.threshold, "patience_eff": o.patience_eff, "distance_fn": o.distance_fn, "trace": o.trace,
+                "tags": o.tags, "device": not callable(o.distance_fn) and self.early_stop_group is None, "parsed": o}
 
     def _device_stop(self, like, n_steps):
         if self._ds is None or not self._ds.matches(like, n_steps):
@@ -1684,12 +1676,11 @@ class LanPaint:
         d.n_el, d.el_per_row, d.rows = st.n_el, st.n_el // st.rows, st.rows
         stopper = None
         if self._capturing is None and st.es is None:
-            stopper = LanPaintEarlyStopper.from_options(
-                model_options=model_options if isinstance(model_options, dict) else None, latent_mask=st.m, abt=st.abt,
-                default_threshold=self.early_stop_threshold, default_patience=self.early_stop_patience,
-                default_distance_fn=self.early_stop_hook)
+            stopper = HostStopper.from_options(
+                StopOptions.parse(model_options, self.early_stop_threshold, self.early_stop_patience, self.early_stop_hook),
+                st.m, st.abt)
             if stopper is not None and self.early_stop_group is not None:
-                stopper.metric.reduce_group = self.early_stop_group       # one batch sharded over ranks
+                stopper.sums.reduce_group = self.early_stop_group        # one batch sharded over ranks
         ran = 0
         if st.compat:
             ran = self._loop_compat(ws, shape, st.m, st.y, st.abt, st.current_times, n_steps, model_options, seed, stopper)
@@ -1899,7 +1890,7 @@ class LanPaint:
                 self._set_xi(d, ws.x_t, want_pre=True, want_post=False)
                 self._launch_step(stream)
             output = self.inner_model(st.x_in, st.t_model, model_options=model_options, seed=seed)
-            x0s = self._x0s_buffer(ws, [args.x0 if args else None, stopper.x0_anchor])
+            x0s = self._x0s_buffer(ws, [args.x0 if args else None, stopper.anchor])
             alive = self._set_model_output(d, output, base_flags | LP_FL_WRITE_X0S, shape)
             d.x0s = x0s.data_ptr()
             d.phases = LP_PH_POST_FIRST if i == 0 else LP_PH_POST_STEADY
@@ -1910,9 +1901,9 @@ class LanPaint:
             ran += 1
             ctx = {"step": i, "steps_done": i + 1, "n_steps": n_steps, "mask": st.m, "latent_image": st.y,
                    "current_times": st.current_times, "seed": seed}
-            if stopper.step(i=i, n_steps=n_steps, x_t_before=x_t_before, x_t_after=ws.x_t,
-                            x_t_prev_for_custom=x_t_before if stopper.has_custom_distance_fn else None,
-                            prev_args=prev_args, args=args, ctx=ctx):
+            if stopper.observe(i, x_before=x_t_before, x_after=ws.x_t,
+                               x_prev_for_user=x_t_before if stopper.has_custom_distance_fn else None,
+                               x0_prev=prev_args.x0 if prev_args is not None else None, x0_cur=args.x0, ctx=ctx):
                 break
         d.x0s = None
         d.phases, d.flags = LP_PH_EMIT, base_flags | self._emit(st, True)
@@ -1939,8 +1930,8 @@ class LanPaint:
             if stopper is not None:
                 ctx = {"step": i, "steps_done": i + 1, "n_steps": n_steps, "mask": m, "latent_image": y,
                        "current_times": current_times, "seed": seed}
-                if stopper.step(i=i, n_steps=n_steps, x_t_before=x_before, x_t_after=x_t, x_t_prev_for_custom=x_prev,
-                                prev_args=prev_args, args=args, ctx=ctx):
+                if stopper.observe(i, x_before=x_before, x_after=x_t, x_prev_for_user=x_prev, x0_prev=_state_x0(prev_args),
+                                   x0_cur=_state_x0(args), ctx=ctx):
                     break
         if x_t.data_ptr() != ws.x_t.data_ptr():
             ws.x_t.copy_(x_t)
