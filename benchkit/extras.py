@@ -16,9 +16,9 @@ from .roofline import (ROOT, _latest_profile_json, graph_burst_us_per_launch, me
 from .workloads import HYPER, WORKLOADS, Job, StubBackbone, euler_ratios, karras_sigmas, make_inputs, schedule_pass, times_from_sigma
 
 
-def node_default_schedule(args, dev, rng=None, passes=None):
-    """C2 driven through KSamplerX0Inpaint with the node defaults (MinStepFrac = 1.0 => n_eff = round(N (1 - abt)), last
-    sigma skipped: SURVEY.md 8d's second line): the path ComfyUI's sampler functions call."""
+def build_node_sampler(args, dev, rng=None, **engine_kw):
+    """C2 behind KSamplerX0Inpaint with the node defaults (MinStepFrac = 1.0, EarlyStop = 1): (the sampler callable, a function
+    that walks the schedule once with k-diffusion's Euler update, the number of sigmas)."""
     from lanpaint_amd import LanPaint
     from lanpaint_amd import nodes as lpn
     shape, flow, n_sig, n_think = WORKLOADS["c2_sdxl"]
@@ -31,23 +31,33 @@ def node_default_schedule(args, dev, rng=None, passes=None):
     model.model_type = "EPS"
     k = lpn.KSamplerX0Inpaint(model, torch.cat([tt(sig_np), torch.zeros(1, device=dev)]))
     k.latent_image, k.noise = y, noise
-    kw = {} if rng is None else {"rng": rng, "philox_seed": args.seed}
-    if rng is not None and args.graph is not None:
-        kw["graph"] = bool(args.graph)
+    kw = dict(engine_kw)
+    if rng is not None:
+        kw.update({"rng": rng, "philox_seed": args.seed})
+        if args.graph is not None:
+            kw["graph"] = bool(args.graph)
     k.PaintMethod = LanPaint(model, n_think, HYPER["Friction"], HYPER["Lambda"], HYPER["Beta"], HYPER["StepSize"],
                              MinStepFrac=1.0, **kw)
     k.LanPaint_early_stop, k.LanPaint_min_step_frac = 1, 1.0
     denoise_mask = 1.0 - mask
     model_options = {}                     # ComfyUI hands the SAME dict to every step
 
-    def node_pass():
+    def node_pass(record=None):
         x = x0.clone()
         for i in range(n_sig):
             den = k(x, sig_list[i], denoise_mask, model_options=model_options, seed=args.seed)
+            if record is not None:
+                record.append(int(k._node_desc.n_eff) if k._node_desc is not None else None)
             if i + 1 < n_sig:
                 x = torch.lerp(den, x, ratios[i])
         return x
+    return k, node_pass, n_sig
 
+
+def node_default_schedule(args, dev, rng=None, passes=None):
+    """C2 driven through KSamplerX0Inpaint with the node defaults (MinStepFrac = 1.0 => n_eff = round(N (1 - abt)), last
+    sigma skipped: SURVEY.md 8d's second line): the path ComfyUI's sampler functions call."""
+    k, node_pass, n_sig = build_node_sampler(args, dev, rng=rng)
     for _ in range(8):          # (captures for every inner-step count of the ramp, then a few steady passes)
         node_pass()
     torch.cuda.synchronize()
@@ -86,6 +96,16 @@ def summary_scalars(args, dev, value, _cabi):
         detail["node_default_schedule"] = nd
     except Exception as e:
         detail["node_default_schedule"] = {"error": repr(e)}
+    try:
+        from .floor import engine_floor
+        fl = engine_floor(_cabi, dev, workload=args.workload, seed=args.seed, steps=max(10, args.steps), mask_kind=args.mask,
+                          **({} if args.rng is None else {"rng": args.rng, "graph": True if args.graph is None else bool(args.graph)}))
+        detail["launch_floor"] = fl
+        if "error" not in fl:
+            out["launch_floor_it_s"] = fl["floor_it_s"]
+            out["value_over_launch_floor"] = (value / fl["floor_it_s"]) if value else None
+    except Exception as e:
+        detail["launch_floor"] = {"error": repr(e)}
     if not args.no_large_shape:
         for key, wl, rng in (("hbm_frac_c5_wan", "c5_wan", "philox"), ("hbm_frac_c5_wan_torch_stream", "c5_wan", "torch"),
                              ("hbm_frac_past_l3", "x_wan_b16", "philox")):

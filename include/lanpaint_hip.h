@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 18
+#define LP_ABI_VERSION 19
 
 /* The library is built with -fvisibility=hidden: the entry points declared LP_API below are its ONLY dynamic symbols (the
  * dispatch functions, kernel handles and device stubs of the C++ side stay internal; tests/test_cabi_exports.py checks
@@ -438,7 +438,11 @@ typedef struct lp_graph_binding {
     void*    func;                      /* its kernel                                                              */
     uint32_t grid[3], block[3];
     uint32_t shared_bytes;
-    uint32_t reserved;
+    uint32_t fingerprint;               /* of everything in the captured descriptor that selected this kernel instantiation
+                                           and its grid (phases, the flag bits the dispatcher reads, replace_kind, rng_kind,
+                                           sizes): a later argument rewrite with a descriptor that would have dispatched to
+                                           ANOTHER kernel is refused (LP_E_INVALID) instead of running the captured one on
+                                           arguments it does not understand                                              */
 } lp_graph_binding;
 LP_API int lp_graph_bind_replace(void* graph, const lp_step_desc* captured_replace, lp_graph_binding* out);
 LP_API int lp_graph_clone_tail(void* graph, void** tail_graph_out, void** tail_exec_out);
@@ -528,6 +532,15 @@ LP_API int lp_step_timed(const lp_step_desc* desc, void* stream, void* timer);  
  * starts on an idle chip (measured 13.0 us instead of the 10.5 us rocprofv3 reports for the same kernel). */
 LP_API int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* timers, int32_t n);
 LP_API int lp_timer_elapsed_ns(void* timer, double* ns);
+
+/* Measurement utility, like lp_step_timed_burst (bench.py's `launch_floor`; no reference counterpart -- the reference has no
+ * launch structure to measure): ONE host call enqueues `repeats` x [ for i in 0 .. n-1: `before` (an lp_step launch, NULL =
+ * none), hipGraphLaunch(graph_execs[i]) (NULL entry = none), `after` (an lp_step launch, NULL = none) ] on `stream`.  With the
+ * hipGraphExec_t handles of a job's captured sigma calls and an elementwise launch standing for the sampler's update between
+ * them, the wall time of the burst is what the schedule costs with NO host code between the launches: the floor a
+ * host-driven loop over the same graphs can reach.  Not capture-safe (drives graph handles). */
+LP_API int lp_replay_burst(void* const* graph_execs, int32_t n, const lp_step_desc* before, const lp_step_desc* after,
+                           int32_t repeats, void* stream);
 
 /* K3  finalise: known-region reprojection + in-place write-back.
  * Replaces: lanpaint.py:154,156.                                               */

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -97,7 +97,7 @@ class LpFinalDesc(C.Structure):
 
 class LpGraphBinding(C.Structure):
     _fields_ = [("node", C.c_void_p), ("func", C.c_void_p), ("grid", C.c_uint32 * 3), ("block", C.c_uint32 * 3),
-                ("shared_bytes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("shared_bytes", C.c_uint32), ("fingerprint", C.c_uint32)]
 
 
 class LpCallDesc(C.Structure):
@@ -150,6 +150,7 @@ EXPORTS = {
     "lp_step_timed": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.c_void_p]),
     "lp_step_timed_burst": (C.c_int, [C.POINTER(LpStepDesc), C.c_void_p, C.POINTER(C.c_void_p), C.c_int32]),
     "lp_timer_elapsed_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "lp_replay_burst": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(LpStepDesc), C.POINTER(LpStepDesc), C.c_int32, C.c_void_p]),
     "lp_torch_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "lp_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "lp_boundary_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

@@ -10,6 +10,7 @@
 namespace lp {
 int step_dispatch(const lp_step_desc* d, hipStream_t stream, void* timer);
 int replace_node_update(const lp_step_desc* d, hipGraphExec_t exec, const lp_graph_binding* b);
+uint32_t replace_fingerprint(const lp_step_desc& d);
 int timer_create(void** out);
 int timer_destroy(void* h);
 int timer_elapsed_ns(void* h, double* ns);
@@ -139,7 +140,7 @@ int lp_graph_bind_replace(void* graph, const lp_step_desc* captured, lp_graph_bi
     out->node = root; out->func = p.func;
     out->grid[0] = p.gridDim.x; out->grid[1] = p.gridDim.y; out->grid[2] = p.gridDim.z;
     out->block[0] = p.blockDim.x; out->block[1] = p.blockDim.y; out->block[2] = p.blockDim.z;
-    out->shared_bytes = p.sharedMemBytes; out->reserved = 0;
+    out->shared_bytes = p.sharedMemBytes; out->fingerprint = lp::replace_fingerprint(*captured);
     return LP_OK;
 }
 
@@ -282,6 +283,26 @@ int lp_step_timed_burst(const lp_step_desc* desc, void* stream, void* const* tim
         d.rng_offset = desc->rng_offset + static_cast<uint64_t>(i);
         const int rc = lp::step_dispatch(&d, as_stream(stream), timers[i]);
         if (rc != LP_OK) return rc;
+    }
+    return LP_OK;
+}
+
+int lp_replay_burst(void* const* graph_execs, int32_t n, const lp_step_desc* before, const lp_step_desc* after,
+                    int32_t repeats, void* stream) {
+    if (!graph_execs || n <= 0 || repeats <= 0) return LP_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    for (int32_t r = 0; r < repeats; ++r) {
+        for (int32_t i = 0; i < n; ++i) {
+            if (before) {
+                const int rc = lp::step_dispatch(before, s, nullptr);
+                if (rc != LP_OK) return rc;
+            }
+            if (graph_execs[i] && hipGraphLaunch(static_cast<hipGraphExec_t>(graph_execs[i]), s) != hipSuccess) return LP_E_LAUNCH;
+            if (after) {
+                const int rc = lp::step_dispatch(after, s, nullptr);
+                if (rc != LP_OK) return rc;
+            }
+        }
     }
     return LP_OK;
 }

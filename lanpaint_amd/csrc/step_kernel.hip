@@ -75,7 +75,11 @@ __device__ __forceinline__ RowCoef load_row_early(const float* coef, int row) {
     r.scale = w[LP_C_SCALE]; r.sqrt_abt = w[LP_C_SQRT_ABT]; r.oma = w[LP_C_OMA]; r.abt = w[LP_C_ABT];
     r.rsigma = w[LP_C_RSIGMA]; r.dtx = w[LP_C_DTX]; r.dty = w[LP_C_DTY]; r.ax = w[LP_C_AX]; r.ay = w[LP_C_AY];
     r.dx = w[LP_C_DX]; r.dy = w[LP_C_DY]; r.valid = w[LP_C_VALID];
-    r.rscale = 0.0f;       // (slot 33 lies past the eight quads fetched here; nothing at one element per lane reads it)
+    // slot 33 (LP_C_RSCALE) lies past the eight quads fetched here.  Only the VEC == 4 paths divide through rc.rscale (div_shared
+    // in the replace and emit phases, both under `VEC == 4 && PH != 0`) and they load their row with load_row; this loader is
+    // reached under `VEC == 1 && PH != 0` alone.  Poisoned, so that a future VEC == 1 use shows up as NaN in the first parity test
+    // instead of as a silent division by zero.
+    r.rscale = __builtin_nanf("");
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const float* q = w + (g ? LP_C_REGION1 : LP_C_REGION0);
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ES == 2 &&
         }
         if constexpr (!PER_EL) {
             if constexpr (SMALL && PH != 0) {
+                static_assert(VEC == 1, "load_row_early leaves rc.rscale poisoned: the div_shared paths (VEC == 4) must use load_row");
                 rc = load_row_early(d.coef, row);
             } else {
                 // AV packs (LP_FL_AV, see below): which of the batch row's two table rows this wave runs on is decided HERE, so that
@@ -1773,10 +1778,29 @@ int step_dispatch(const lp_step_desc* dp, hipStream_t stream, void* timer_handle
 // argument list is LP_STEP_ARGS of a replace launch (PH & LP_PH_REPLACE): x_t, C, x, known | noise, y, mask, row length,
 // flags, the descriptor by value.  Which instantiation / grid the node runs was fixed at capture; the caller keeps
 // shape, flags, phases and pointer alignment what they were (the engine's identity pre-check).
+// What step_dispatch looks at when it picks the kernel and the grid of a replace launch.  A captured node keeps its kernel;
+// only its arguments are rewritten per call (replace_node_update), so a rewritten descriptor has to be one the dispatcher
+// would have sent to the SAME instantiation -- otherwise the captured kernel would read fields it was not compiled for
+// (a phase-specialised kernel ignores host noise tensors and treats x0 as backbone heads, for one).
+uint32_t replace_fingerprint(const lp_step_desc& d) {
+    const uint32_t sel = LP_FL_FLOW | LP_FL_MASK_BITS | LP_FL_MASK_U8 | LP_FL_MASK_DENOISE | LP_FL_PER_ELEMENT | LP_FL_AV |
+                         LP_FL_XIN_BF16 | LP_FL_XIN_F16 | LP_FL_X0S_GIVEN | LP_FL_NO_REGION_SKIP;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    const uint64_t parts[] = {d.phases, d.flags & sel, static_cast<uint64_t>(static_cast<uint32_t>(d.replace_kind)),
+                              static_cast<uint64_t>(static_cast<uint32_t>(d.rng_kind)), static_cast<uint64_t>(d.n_el),
+                              static_cast<uint64_t>(d.rows), static_cast<uint64_t>(d.tune), d.es ? 1ull : 0ull,
+                              d.corr_el ? 1ull : 0ull};
+    for (uint64_t v : parts) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); }
+    return static_cast<uint32_t>(h ^ (h >> 32)) | 1u;          // never 0: 0 = "not recorded" (a binding filled in by hand)
+}
+
 int replace_node_update(const lp_step_desc* dp, hipGraphExec_t exec, const lp_graph_binding* b) {
     if (!dp || !exec || !b || !b->node || !b->func) return LP_E_INVALID;
     lp_step_desc d = *dp;
     if (!(d.phases & LP_PH_REPLACE) || !d.x || !d.x_t) return LP_E_INVALID;
+    // a replace launch carries neither host noise tensors nor given x0s; and it must still be the launch that was captured
+    if (d.xi_post || d.xi_pre || (d.flags & LP_FL_X0S_GIVEN)) return LP_E_INVALID;
+    if (b->fingerprint != 0u && b->fingerprint != replace_fingerprint(d)) return LP_E_INVALID;
     void* a0 = d.x_t;
     void* a1 = d.C;
     const void* a2 = d.x;

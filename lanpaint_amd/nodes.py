@@ -28,6 +28,8 @@ import torch
 
 from . import _cabi, interp_rule
 from .blend import MaskBlend, gaussian_kernel_2d, merge_video_with_mask  # noqa: F401
+from .image_nodes import LanPaint_ImageDecode, LanPaint_ImageEncode, _snap_mask_nearest_exact  # noqa: F401
+from .resample import _hip_device, _resample  # noqa: F401
 from .lanpaint import LanPaint, pack_mask, raw_stream, refresh_packed_mask, tensor_version
 from .types import FusedCFGHeads
 
@@ -70,30 +72,6 @@ def _require_comfy(what):
 # =====================================================================================
 # mask preparation (nodes.py:59-160)
 # =====================================================================================
-def _hip_device(t, device=None):
-    if device is not None and torch.device(device).type == "cuda":
-        return torch.device(device)
-    if t.is_cuda:
-        return t.device
-    if not torch.cuda.is_available():
-        raise RuntimeError("lanpaint_amd.reshape_mask runs on a HIP device only; no CPU fallback")
-    return torch.device("cuda", torch.cuda.current_device())
-
-
-def _resample(src5, out_b, out_c, out_f, out_h, out_w, taps, rule=0):
-    """One lp_reshape_mask launch: src5 is [B', C', F, H, W] fp32 on the device; `rule`: the LP_NN_ATEN_* source-index rule
-    (interp_rule.rule_for: the one torch's kernel follows on the device the reference would have resampled on)."""
-    lib = _cabi.load()
-    sb, sc, sf, sh, sw = src5.shape
-    dst = torch.empty((out_b, out_c, out_f, out_h, out_w), dtype=torch.float32, device=src5.device)
-    with torch.cuda.device(src5.device):
-        _cabi.check(lib.lp_reshape_mask(src5.data_ptr(), sb, sc, sf, sh, sw, dst.data_ptr(), out_b, out_c, out_f, out_h,
-                                        out_w, taps, int(rule) << _cabi.LP_RESHAPE_RULE_SHIFT,
-                                        torch.cuda.current_stream(src5.device).cuda_stream),
-                    "lp_reshape_mask")
-    return dst
-
-
 def reshape_mask(input_mask, output_shape, video_inpainting=False, device=None):
     """nodes.py:59-133.  Nearest-exact resample to the latent grid, 5-wide temporal union for
     video, channel / batch broadcast -- computed by one HIP launch.  The source index follows the rule of the torch kernel
@@ -839,108 +817,6 @@ class LanPaint_SamplerCustomAdvanced:
                                     disable_pbar=not comfy.utils.PROGRESS_BAR_ENABLED, seed=noise.seed)
             samples = samples.to(comfy.model_management.intermediate_device())
             return _finish_custom(latent, samples, x0_output, patcher)
-
-
-# =====================================================================================
-# image encode / decode nodes: the callers either side of the mask snap (lp_reshape_mask) and of the
-# post-decode merge (lp_mask_blend); nodes.py:1230-1342.  The VAE is the caller's object.
-# =====================================================================================
-def _snap_mask_nearest_exact(mask_hw, out_h, out_w):
-    """[H, W] mask -> [out_h, out_w], F.interpolate(mode="nearest-exact") semantics, on the HIP kernel; the result
-    goes back to the mask's own device (node tensors normally live on the host)."""
-    if tuple(mask_hw.shape) == (out_h, out_w):
-        return mask_hw
-    dev = _hip_device(mask_hw)
-    src = mask_hw.to(device=dev, dtype=torch.float32).contiguous()
-    rule = interp_rule.rule_for(mask_hw, src.reshape(1, 1, *src.shape), (out_h, out_w))      # nodes.py:1278-1287: 2-D call on the mask's device
-    return _resample(src.reshape(1, 1, 1, *src.shape), 1, 1, 1, out_h, out_w, 1, rule)[0, 0, 0].to(mask_hw.device)
-
-
-class LanPaint_ImageEncode:
-    """nodes.py:1230-1290: VAE encode + attach the inpainting mask snapped (nearest-exact) to the latent's
-    spatial size; 4-D image latents and 5-D video-VAE latents ([1, 1, T, H, W] mask)."""
-
-    @classmethod
-    def INPUT_TYPES(s):
-        return {
-            "required": {
-                "image": ("IMAGE", {"tooltip": "The image to encode (1 = regenerate region comes from the mask)."}),
-                "vae": ("VAE", {"tooltip": "The VAE."}),
-            },
-            "optional": {
-                "mask": ("MASK", {"tooltip": "Inpainting mask [H, W] (1 = regenerate, 0 = keep). Snapped to the latent size automatically."}),
-            },
-        }
-
-    RETURN_TYPES = ("LATENT",)
-    RETURN_NAMES = ("latent",)
-    FUNCTION = "encode"
-    CATEGORY = "image"
-    DESCRIPTION = "Encode an image and attach an inpainting mask to the latent (replaces VAEEncode + SetLatentNoiseMask)."
-
-    def encode(self, image, vae, mask=None):
-        z = vae.encode(image)
-        ndim = len(z.shape)
-        if ndim not in (4, 5):
-            raise ValueError(f"LanPaint_ImageEncode expects a 4D or 5D latent, got {ndim}D")
-        latent = {"samples": z}
-        if mask is not None:
-            m = mask.float()
-            if m.ndim == 4:        # [1, 1, H, W] from SetLatentNoiseMask
-                m = m[0, 0]
-            elif m.ndim == 3:
-                m = m[0]
-            h, w = z.shape[-2:]
-            m = _snap_mask_nearest_exact(m, h, w)
-            if ndim == 4:
-                latent["noise_mask"] = m.unsqueeze(0).unsqueeze(0)
-            else:                  # one mask slice per latent frame
-                latent["noise_mask"] = m.unsqueeze(0).unsqueeze(0).unsqueeze(2).expand(1, 1, z.shape[-3], h, w)
-        return (latent,)
-
-
-class LanPaint_ImageDecode:
-    """nodes.py:1292-1342: VAE decode, resize to the original's exact size, merge with the original inside the
-    mask with a MaskBlend-style boundary (one lp_mask_blend launch)."""
-
-    @classmethod
-    def INPUT_TYPES(s):
-        return {
-            "required": {
-                "samples": ("LATENT", {"tooltip": "The inpainted latent to decode."}),
-                "vae": ("VAE", {"tooltip": "The VAE."}),
-            },
-            "optional": {
-                "image": ("IMAGE", {"tooltip": "The original image. When given, the decoded output is resized to its exact dimensions."}),
-                "mask": ("MASK", {"tooltip": "The inpainting mask (1 = take the inpainted pixels, 0 = keep the original)."}),
-                "blend_overlap": ("INT", {"default": 9, "min": 1, "max": 51, "step": 2,
-                                          "tooltip": "Boundary blend width in pixels between the inpainted and original image (MaskBlend-style)."}),
-            },
-        }
-
-    RETURN_TYPES = ("IMAGE",)
-    RETURN_NAMES = ("image",)
-    FUNCTION = "decode"
-    CATEGORY = "image"
-    DESCRIPTION = ("Decode an inpainted latent, resize to the original image's exact dimensions, and merge with the "
-                   "original inside the mask (replaces VAEDecode + MaskBlend).")
-
-    def decode(self, samples, vae, image=None, mask=None, blend_overlap=9):
-        img = vae.decode(samples["samples"])
-        if len(img.shape) == 5:    # [1, F, H, W, C]: combine batches (video-style VAE)
-            img = img.reshape(-1, img.shape[-3], img.shape[-2], img.shape[-1])
-        if image is None:
-            return (img,)
-        target_h, target_w = image.shape[1], image.shape[2]
-        if tuple(img.shape[1:3]) != (target_h, target_w):
-            img = torch.nn.functional.interpolate(img.movedim(-1, 1), size=(target_h, target_w), mode="bilinear",
-                                                  align_corners=False).movedim(1, -1)
-        if mask is None:
-            return (img,)
-        dev = _hip_device(image)
-        # (the mask is handed over where it lives: its device decides which of torch's index rules the reference's resample followed)
-        merged = merge_video_with_mask(image.to(dev), img.to(dev), mask, blend_overlap)
-        return (merged.to(image.device),)
 
 
 NODE_CLASS_MAPPINGS = {

@@ -1005,6 +1005,10 @@ def test_packed_mask_rewritten_to_soft_values_is_reported_not_binarised():
     m.mul_(0.25)                                                      # now soft
     assert refresh_packed_mask(m) is True
     torch.cuda.synchronize()
-    m.add_(0.0)                                                       # (moves the version counter: the next look re-packs)
+    # the flag is read BEFORE the version shortcut -- the very next look reports the rewrite although the version
+    # counter has not moved since the re-pack -- and the packed copy is dropped, so later calls run on the fp32 (soft) mask
+    # instead of alternating between a silently binarised run and an error
     with pytest.raises(ValueError, match="values other than 0 and 1"):
         refresh_packed_mask(m)
+    assert getattr(m, "_lp_bits", None) is None and getattr(m, "_lp_bits_of", None) is None
+    assert refresh_packed_mask(m) is False and refresh_packed_mask(m) is False

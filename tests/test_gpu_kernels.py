@@ -154,7 +154,7 @@ def test_boundary_ring_bit_exact(lib, shape):
 
 def test_wmse_pair_matches_oracle(lib):
     import torch
-    from lanpaint_amd.earlystop import _Metric
+    from lanpaint_amd.earlystop import StopState, WeightedSums, stop_rule
     rng = np.random.default_rng(3)
     # (594 elements: the 4-byte path; 65 536: 64 block sums; 786 432 and the video latent: more block sums than the totalling wave
     # has lanes / than the 1 024-block cap)
@@ -162,15 +162,18 @@ def test_wmse_pair_matches_oracle(lib):
         m = (rng.random(shape) > 0.5).astype(np.float32)
         a = rng.standard_normal(shape, dtype=np.float32)
         b = rng.standard_normal(shape, dtype=np.float32)
-        met = _Metric(tt(m))
-        (d_in, d_ring), = met.distances([(tt(a), tt(b))])
+        met = WeightedSums(tt(m))
+        six = met.six((tt(a), tt(b)), (tt(b), tt(a)))                     # pair A and -- as the drift pair -- the same two swapped
+        assert six[4] == pytest.approx(six[0], rel=1e-12) and six[5] == pytest.approx(six[2], rel=1e-12)
+        _st, rec = stop_rule(six, StopState(), 1e30, 2, have_prev=True, has_ring=met.ring is not None, have_anchor=False)
+        d_in, d_ring = rec.dist_inpaint, rec.dist_ring
         inp = (1 - m).astype(np.float32)
         assert d_in == pytest.approx(orc.weighted_mse(a, b, inp), rel=1e-5)
         if len(shape) == 4:
             assert d_ring == pytest.approx(orc.weighted_mse(a, b, orc.boundary_weight(m, inp)), rel=1e-5)
         else:
             assert d_ring is None and met.ring is None
-        assert met.inpaint_weight_sum() == pytest.approx(float(inp.sum()), rel=1e-6)
+        assert met.inpaint_weight() == pytest.approx(float(inp.sum()), rel=1e-6)
 
 
 # ---------------------------------------------------------------- K5 mask resample
