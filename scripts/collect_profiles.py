@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profiles")
 DST = os.path.join(ROOT, "profiles")
-N_EL = {"c1": ("c1_sd15", 16384), "c2": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c4": ("c4_flux", 65536),
+N_EL = {"c1": ("c1_sd15", 16384), "c2": ("c2_sdxl_torch", 65536), "c2_philox": ("c2_sdxl", 65536), "c3": ("c3_sdxl_b4", 262144), "c4": ("c4_flux", 65536),
         "c5": ("c5_wan", 2096640), "xwanb16": ("x_wan_b16", 33546240), "xwanb16_noskip": ("x_wan_b16_every_stream", 33546240),
         "c5_bf16": ("c5_wan_bf16", 2096640), "xwanb16_bf16": ("x_wan_b16_bf16", 33546240), "c5_torch": ("c5_wan_torch", 2096640)}
 BYTES_PER_EL = {"c5_wan_bf16": 30, "x_wan_b16_bf16": 30}          # bf16 x0, x0_BIG in, bf16 x_in out; 36 otherwise
@@ -58,10 +58,12 @@ def main():
         if not fe or not wr:
             continue
         tb = int(round((2 * fe[1] + wr[1]) * 1024))
-        traffic[wl] = {"kernel": f"lp::lp_step_kernel<VEC={fe[0]},MODE_HARD,POST_STEADY|PRE_HALF|EMIT,X0W=4,RNG=philox>", "FETCH_SIZE_KB": fe[1], "WRITE_SIZE_KB": wr[1],
+        traffic[wl] = {"kernel": f"lp::lp_step_kernel<VEC={fe[0]},MODE_HARD,POST_STEADY|PRE_HALF|EMIT,X0W=4,RNG={'torch' if wl.endswith('_torch') else 'philox'}>", "FETCH_SIZE_KB": fe[1], "WRITE_SIZE_KB": wr[1],
                        "dispatches": fe[2], "traffic_bytes_per_launch": tb,
                        "algorithmic_bytes_per_launch": BYTES_PER_EL.get(wl, 36) * n_el,
                        "traffic_over_algorithmic": round(tb / (BYTES_PER_EL.get(wl, 36) * n_el), 4)}
+    if "c2_sdxl_torch" in traffic and "c2_sdxl" not in traffic:       # (the noise generator does not change the bytes a launch moves)
+        traffic["c2_sdxl"] = dict(traffic["c2_sdxl_torch"], note="measured on the torch-stream launch of the same shape")
     json.dump(traffic, open(os.path.join(DST, f"r{rnd}_pmc_traffic.json"), "w"), indent=1)
     durations = {"_doc": "mean per-dispatch duration of the steady-state lp_step kernel as rocprofv3 --kernel-trace measured it "
                          "(profiles/r%s_*_kernel_trace.md); bench.py quotes it (committed_profile) next to its own live event timing" % rnd}

@@ -210,3 +210,36 @@ def test_steady_bytes_model():
     assert bench.steady_bytes_per_launch(mask, "bits", 2096640, every_stream=True)["required"] == 32.125 * 2096640
     r = bench.steady_bytes_per_launch(mask, "bits", 2096640, model_dtype="bf16")
     assert r["bytes_per_element_every_stream"] == 26.125
+
+
+def test_every_committed_round6_line_is_small_and_complete():
+    """The lines bench.py printed on the GPU boxes of round 6 (profiles/r06*_bench_*.json, side-cars excluded): each under
+    6000 bytes, every required key present, `roofline` and `cpu_baseline` carrying the contract's fields, 0 < frac <= 1, parity ok,
+    the default runs in the drop-in configuration, the eight-rank rehearsals with a compact `dist` block."""
+    import glob
+    from benchkit import line as bl
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06*_bench_*.json"))) if "sidecar" not in f]
+    assert len(files) >= 8, files
+    for f in files:
+        text = open(f).read().strip()
+        name = os.path.basename(f)
+        assert len(text) < bl.MAX_LINE_BYTES, (name, len(text))
+        line = json.loads(text)
+        for k in bl.REQUIRED_KEYS:
+            assert k in line, (name, k)
+        r = line["roofline"]
+        assert 0.0 < r["frac"] <= 1.0 and r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["kernel"].startswith("lp::lp_step_kernel<"), name
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["duration_used_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"], name
+        assert r["traffic"] is None or ("live" in r["traffic_source"] or "committed_constant" in r["traffic_source"]), name
+        assert line["parity_check"]["ok"] and line["value"] > 0 and line["vs_baseline"] is None and line["dtype"] == "f32", name
+        c = line["cpu_baseline"]
+        assert c is None or (c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "oracle/lanpaint_oracle.py" in c["sample"]), name
+        if line["n_gpus"] > 1:
+            d = line["dist"]
+            assert "per_rank" not in d and d["world_size"] == line["n_gpus"] == d["ranks_reporting"] and d["parity_ok_all_ranks"], name
+            assert d["distinct_final_checksums"] == line["n_gpus"] and d["collectives_in_timed_region"] == 0, name
+    default = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_c2_driver_form.json")))
+    assert default["config"]["rng"] == "torch" and default["config"]["graph"] == "auto" and "drop-in" in default["config"]["engine"]
+    assert default["summary"]["philox_bits_it_s"] > default["value"] and 0.9 < default["summary"]["value_over_launch_floor"] <= 1.05
+    live = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_c2_live_pmc.json")))["roofline"]
+    assert "live" in live["traffic_source"] and abs(live["traffic"] - 2173952) < 0.03 * 2173952       # within 3 % of the committed passes
