@@ -28,7 +28,7 @@ def test_no_module_of_the_product_package_exceeds_900_lines():
     sizes = {os.path.basename(f): sum(1 for _ in open(f)) for f in glob.glob(os.path.join(ROOT, "lanpaint_amd", "*.py"))}
     assert max(sizes.values()) <= 900, sorted(sizes.items(), key=lambda kv: -kv[1])[:3]
     assert {"engine.py", "capture.py", "loops.py", "masks.py", "buffers.py", "lanpaint.py"} <= set(sizes)
-    assert sum(1 for _ in open(os.path.join(ROOT, "bench.py"))) <= 400
+    assert sum(1 for _ in open(os.path.join(ROOT, "bench.py"))) <= 350
 
 
 def test_engine_class_is_assembled_from_its_parts():
