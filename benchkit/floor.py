@@ -103,12 +103,24 @@ def node_floor(_cabi, dev, args, steps=40, **engine_kw):
     for _ in range(5):
         burst()
     t_floor = _wall_us(burst, dev, steps)
+    # the whole call as ONE graph (node 0 = the replace launch with the sigma algebra folded in): what a speculated call launches
+    t_one = None
+    full = table[5] if len(table) > 5 else None
+    if full is not None and all(full[c] for c in counts):
+        execs1 = (ctypes.c_void_p * n_sig)(*[full[c] for c in counts])
+        burst1 = lambda: _cabi.check(lib.lp_replay_burst(execs1, n_sig, None, ctypes.pointer(upd), 1, st), "lp_replay_burst")   # noqa: E731
+        for _ in range(5):
+            burst1()
+        t_one = _wall_us(burst1, dev, steps)
     t_node = _wall_us(node_pass, dev, steps)
     its = sum(counts)
     del keep
     return {"inner_steps_per_sigma": counts, "iterations_per_step": its,
-            "us_per_sigma_call": {"replace_graph_update": t_floor / n_sig, "node_loop": t_node / n_sig},
-            "floor_it_s": its / (t_floor * 1e-6), "node_loop_it_s": its / (t_node * 1e-6), "node_over_floor": t_floor / t_node,
+            "us_per_sigma_call": {"replace_graph_update": t_floor / n_sig, "one_graph_and_update": (t_one / n_sig) if t_one else None,
+                                  "node_loop": t_node / n_sig},
+            "floor_it_s": its / ((t_one or t_floor) * 1e-6), "node_loop_it_s": its / (t_node * 1e-6),
+            "node_over_floor": (t_one or t_floor) / t_node,
             "steps_timed": steps,
-            "note": "floor = per sigma [replace launch, the tail graph captured for that sigma's count, update launch] from one C "
-                    "call; the node loop adds KSamplerX0Inpaint + lp_node_call (speculated count, verdict from the device) + torch.lerp"}
+            "note": "floor = per sigma [the whole-call graph captured for that sigma's count (node 0 = replace launch + sigma algebra), "
+                    "update launch] from one C call (replace_graph_update: the round-5 form, an eager replace launch in front of the "
+                    "tail graph); the node loop adds KSamplerX0Inpaint + lp_node_call (speculated count, verdict from the device) + torch.lerp"}

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 19
+#define LP_ABI_VERSION 20
 
 /* The library is built with -fvisibility=hidden: the entry points declared LP_API below are its ONLY dynamic symbols (the
  * dispatch functions, kernel handles and device stubs of the C++ side stay internal; tests/test_cabi_exports.py checks
@@ -447,6 +447,14 @@ typedef struct lp_graph_binding {
 LP_API int lp_graph_bind_replace(void* graph, const lp_step_desc* captured_replace, lp_graph_binding* out);
 LP_API int lp_graph_clone_tail(void* graph, void** tail_graph_out, void** tail_exec_out);
 LP_API int lp_graph_release(void* tail_graph, void* tail_exec);
+/* For the sampler callable (KSamplerX0Inpaint, nodes.py:229-315), which needs the device's word on the inner-step count inside
+ * every sigma call: a copy of the captured call `graph` (root = the replace launch, LP_PH_REPLACE | LP_PH_EMIT | LP_PH_COEFFS)
+ * whose root is the SAME launch with the sigma algebra folded in (`with_sigma`: the captured replace descriptor with
+ * LP_PH_SIGMA and its sg_* fields set), instantiated.  `binding_out` names the new root for lp_node_call's per-call argument
+ * refresh.  Briefly captures on a private stream to learn the launch geometry: not capture-safe.  Release with
+ * lp_graph_release.                                                                                                   */
+LP_API int lp_graph_clone_sigma_root(void* graph, const lp_step_desc* with_sigma, void** graph_out, void** exec_out,
+                                     lp_graph_binding* binding_out);
 
 /* K1a  sigma -> (VE_sigma, abt, flow_t) per batch row plus the two scalars the inner-step rule needs,
  * in ONE launch.  Replaces the ~15 eager scalar ops + 2 host syncs of KSamplerX0Inpaint.__call__
@@ -507,6 +515,17 @@ typedef struct lp_node_call_desc {
     int32_t             speculated;     /* out: 1 = a run was queued for `guess`                                  */
     int32_t             hit;            /* out: 1 = ... and the guess was right                                   */
     float               step_f, frac;   /* out: the two scalars as read from the mailbox                          */
+    void* const*        full_exec_by_count;
+                                        /* optional, per inner-step count like exec_by_count: hipGraphExec_t of the WHOLE sigma
+                                           call whose first node is the replace launch with the sigma algebra folded in
+                                           (lp_graph_clone_sigma_root).  A speculated call then is ONE hipGraphLaunch: the
+                                           node's arguments are refreshed from `replace` + the sigma fields of this
+                                           descriptor (hipGraphExecKernelNodeSetParams), nothing is launched in front of
+                                           the graph.  NULL / NULL entry: the replace launch goes eagerly in front of
+                                           exec_by_count[guess] as before                                           */
+    const struct lp_graph_binding* const* full_binding_by_count;   /* the root node of each full_exec_by_count entry */
+    int32_t             one_launch;     /* out: 1 = the speculated call went out as one graph launch              */
+    int32_t             reserved0;
 } lp_node_call_desc;
 LP_API int lp_node_call(lp_node_call_desc* call, void* stream);
 /* the rule alone (host arithmetic; tests pin it against the reference's min_step_frac_effective_steps table)   */

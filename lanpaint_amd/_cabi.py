@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "liblanpaint_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # --- constants mirrored from include/lanpaint_hip.h -------------------------------
 LP_OK, LP_E_INVALID, LP_E_UNSUPPORTED, LP_E_LAUNCH, LP_E_ALIGN = 0, -1, -2, -3, -4
@@ -123,7 +123,9 @@ class LpNodeCallDesc(C.Structure):
                 ("early_stop", C.c_int32), ("total_steps", C.c_int32), ("n_counts", C.c_int32),
                 ("min_step_frac", C.c_double), ("exec_by_count", C.POINTER(C.c_void_p)), ("spin_limit", C.c_int32),
                 ("guess", C.c_int32), ("valid_word", C.c_void_p), ("fold_sigma", C.c_int32), ("n_eff", C.c_int32), ("launched", C.c_int32),
-                ("speculated", C.c_int32), ("hit", C.c_int32), ("step_f", C.c_float), ("frac", C.c_float)]
+                ("speculated", C.c_int32), ("hit", C.c_int32), ("step_f", C.c_float), ("frac", C.c_float),
+                ("full_exec_by_count", C.POINTER(C.c_void_p)), ("full_binding_by_count", C.POINTER(C.POINTER(LpGraphBinding))),
+                ("one_launch", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class LpBlendDesc(C.Structure):
@@ -160,6 +162,8 @@ EXPORTS = {
     "lp_graph_bind_replace": (C.c_int, [C.c_void_p, C.POINTER(LpStepDesc), C.POINTER(LpGraphBinding)]),
     "lp_graph_clone_tail": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "lp_graph_release": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lp_graph_clone_sigma_root": (C.c_int, [C.c_void_p, C.POINTER(LpStepDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(LpGraphBinding)]),
     "lp_node_call": (C.c_int, [C.POINTER(LpNodeCallDesc), C.c_void_p]),
     "lp_effective_inner_steps": (C.c_int32, [C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double]),
     "lp_pack_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -143,8 +143,16 @@ class _CapturedCall:
         self.node_table = None        # (exec array by inner-step count, captures, -, graphs seen, options): lp_node_call's table
         self.binding = None           # lp_graph_binding: the replace launch is node 0 of the graph (ONE hipGraphLaunch per call)
         self.tail_handles = None      # (hipGraph_t, hipGraphExec_t) of the same graph without node 0 (begin_call / finish_call)
+        self.sigma_root = None        # (hipGraph_t, hipGraphExec_t, LpGraphBinding) of the same graph with the sigma algebra folded
+                                      # into node 0 (lp_graph_clone_sigma_root): the node path's ONE launch per call; False = tried, no
 
     def __del__(self):
+        sr, self.sigma_root = self.sigma_root, None
+        if sr:
+            try:
+                _cabi.load().lp_graph_release(sr[0], sr[1])
+            except Exception:
+                pass
         h, self.tail_handles = self.tail_handles, None
         if h is not None:
             try:

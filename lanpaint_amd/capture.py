@@ -103,7 +103,8 @@ class GraphReplay:
             return None
         table = cap0.node_table
         if table is None or table[3] != len(self._graphs) or table[4] is not model_options:
-            table = self._node_table(cap0, nd.n_steps, model_options)
+            nd.valid_word = self._rng_state(x.device).data_ptr() + 32
+            table = self._node_table(cap0, nd.n_steps, model_options, nd)
         stream = self._stream(x.device)
         ve, abt = current_times[0], current_times[1]
         out = torch.empty_like(x)
@@ -121,6 +122,7 @@ class GraphReplay:
             nd._lp_table = table
             nd.replace, nd.exec_by_count, nd.n_counts = table[2], table[0], len(table[1])
             nd.valid_word = self._rng_state(x.device).data_ptr() + 32
+            nd.full_exec_by_count, nd.full_binding_by_count = table[5], table[6]
         rc = self._lib.lp_node_call(ctypes.byref(nd), stream)
         if rc != _cabi.LP_OK:
             # A failed call may have left a speculated, self-voided run in the queue.  The library tries to restore the word
@@ -155,9 +157,11 @@ class GraphReplay:
             cap.siblings = {}
         self._graphs.clear()
 
-    def _node_table(self, cap0, n_max, model_options):
+    def _node_table(self, cap0, n_max, model_options, nd=None):
         """hipGraphExec_t of the tail graph captured for every inner-step count 0 .. n_max of this call shape (NULL where
-        none exists yet), as the array lp_node_call indexes; holds the captures alive."""
+        none exists yet), as the array lp_node_call indexes; holds the captures alive.  With the caller's node descriptor
+        `nd`, also the whole-call graphs whose first node is the replace launch with the sigma algebra folded in
+        (`_sigma_root`): a speculated call is then one hipGraphLaunch."""
         caps = []
         for n in range(int(n_max) + 1):
             cap = cap0 if cap0.ident[4] == n else cap0.siblings.get(n)
@@ -169,8 +173,46 @@ class GraphReplay:
                     cap0.siblings[n] = cap
             caps.append(cap if (cap is not None and cap.tail is not None) else None)
         arr = (ctypes.c_void_p * len(caps))(*[(c.tail.graph_exec if c is not None else None) for c in caps])
-        cap0.node_table = (arr, caps, ctypes.pointer(cap0.k0_desc), len(self._graphs), model_options)
+        full = full_b = None
+        if nd is not None and os.environ.get("LANPAINT_AMD_NODE_ONE_LAUNCH", "1") != "0":
+            roots = [self._sigma_root(c, cap0, nd) if c is not None else None for c in caps]
+            if any(r is not None for r in roots):
+                full = (ctypes.c_void_p * len(caps))(*[(r[1] if r is not None else None) for r in roots])
+                full_b = (ctypes.POINTER(_cabi.LpGraphBinding) * len(caps))(
+                    *[(ctypes.pointer(r[2]) if r is not None else ctypes.POINTER(_cabi.LpGraphBinding)()) for r in roots])
+        cap0.node_table = (arr, caps, ctypes.pointer(cap0.k0_desc), len(self._graphs), model_options, full, full_b)
         return cap0.node_table
+
+    def _sigma_root(self, cap, cap0, nd):
+        """The copy of `cap`'s graph whose node 0 is the replace launch WITH the sigma algebra (LP_PH_SIGMA), made once per
+        capture, or None where the call does not qualify (lp_node_call's own conditions for folding the algebra: bit-packed
+        mask, a fused replace form, no correction tensor, no early-stop reset) or the runtime refuses."""
+        if cap.sigma_root is not None:
+            return cap.sigma_root or None
+        cap.sigma_root = False
+        k0 = cap0.k0_desc
+        ok = (cap.binding is not None and k0 is not None
+              and k0.phases == (_cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS) and (k0.flags & _cabi.LP_FL_MASK_BITS)
+              and not k0.corr_el and not k0.es_reset and k0.replace_kind != _cabi.LP_REPLACE_KNOWN
+              and bool(nd.is_flow) == bool(k0.flags & _cabi.LP_FL_FLOW) and nd.rows == k0.rows and nd.fold_sigma)
+        if not ok:
+            return None
+        try:
+            raw_graph = int(cap.graph.raw_cuda_graph())
+        except Exception:
+            return None
+        d = _cabi.LpStepDesc.from_buffer_copy(k0)
+        d.phases = k0.phases | _cabi.LP_PH_SIGMA
+        d.io_valid = 0
+        d.sg_sigma, d.sg_schedule, d.sg_schedule_len, d.sg_times_out = nd.sigma, nd.schedule, nd.schedule_len, nd.times_out
+        d.sg_scalars_out, d.sg_seq_out, d.sg_seq, d.sg_valid_out = nd.scalars_out, nd.seq_out, 0, nd.valid_word
+        d.sg_n_steps, d.sg_early_stop, d.sg_total_steps, d.sg_guess = nd.n_steps, nd.early_stop, nd.total_steps, 0
+        d.sg_min_step_frac = nd.min_step_frac
+        g, e, b = ctypes.c_void_p(), ctypes.c_void_p(), _cabi.LpGraphBinding()
+        if self._lib.lp_graph_clone_sigma_root(raw_graph, ctypes.byref(d), ctypes.byref(g), ctypes.byref(e), ctypes.byref(b)) != _cabi.LP_OK:
+            return None
+        cap.sigma_root = (g.value, e.value, b)
+        return cap.sigma_root
 
     # ------------------------------------------------------------------ hipGraph replay of one sigma call
     def _same_call(self, cap, x, sigma, latent_mask, current_times, n_steps, model_options, seed):

@@ -36,7 +36,8 @@ def table(title, d):
         return
     print("| layer | us per sigma call |\n|---|---|")
     for k, v in d["us_per_sigma_call"].items():
-        print(f"| {k} | {v:.2f} |")
+        if v is not None:
+            print(f"| {k} | {v:.2f} |")
     rest = {k: v for k, v in d.items() if k not in ("us_per_sigma_call", "note")}
     print("\n```json\n" + json.dumps(rest, default=float) + "\n```\n" + d.get("note", ""))
 
