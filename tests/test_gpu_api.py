@@ -1,6 +1,8 @@
 """The reference's own unit tests, re-run against lanpaint_amd on the GPU (same stubs, same
 assertions): tests/test_sho_regression.py, test_lanpaint_semantic_stop.py, test_av_schedule.py,
 test_reshape_mask.py, test_videomask.py:475-713 -- plus the KSamplerX0Inpaint sampler callable."""
+import os
+
 import numpy as np
 import pytest
 
@@ -468,6 +470,7 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
             if r is not None:
                 one_call["spec"] = one_call.get("spec", 0) + int(a[-1].speculated)
                 one_call["hit"] = one_call.get("hit", 0) + int(a[-1].hit)
+                one_call["one"] = one_call.get("one", 0) + int(a[-1].one_launch)
             return r
         k.PaintMethod.node_call = counted
         dm, mo = tt(denoise_mask), {}
@@ -486,7 +489,8 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
                 x = torch.lerp(den, x, float(sig[i + 1] / sig[i]))
         torch.cuda.synchronize()
         res[graph] = ([o.cpu().numpy() for o in outs], x.cpu().numpy(), n_effs, model.calls, split,
-                      torch.cuda.get_rng_state(DEV).clone(), one_call["n"], one_call.get("spec", 0), one_call.get("hit", 0))
+                      torch.cuda.get_rng_state(DEV).clone(), one_call["n"], one_call.get("spec", 0), one_call.get("hit", 0),
+                      one_call.get("one", 0))
     expect = []
     for i in range(len(sig) - 1):
         s = np.full((shape[0],), sig[i], dtype=np.float32)
@@ -499,11 +503,22 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
     # the wrap-around from the last sigma of a pass to the first of the next is a miss the device voided -- with no trace in
     # the results (bitwise equality below) or in the generator state
     assert res[True][7] >= len(sig) and res[True][8] >= res[True][7] - 3 and res[True][8] < res[True][7]
+    # round 6: a speculated call is ONE hipGraphLaunch -- the replace launch with the sigma algebra folded in is node 0 of a copy
+    # of the captured call (lp_graph_clone_sigma_root), its arguments refreshed per call; LANPAINT_AMD_NODE_ONE_LAUNCH=0 (the
+    # round-5 form: eager replace launch in front of the tail graph) is covered by the parametrised run below
+    want_one = os.environ.get("LANPAINT_AMD_NODE_ONE_LAUNCH", "1") != "0"
+    assert (res[True][9] == res[True][7]) if want_one else (res[True][9] == 0), (res[True][9], res[True][7])
     assert res[True][3] < res[False][3]          # the Python backbone only ran while capturing
     for a, b in zip(res[False][0], res[True][0]):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(res[False][1], res[True][1])
     assert torch.equal(res[False][5], res[True][5])                      # the generator ends where eager leaves it
+
+
+def test_node_path_with_the_eager_replace_launch_in_front_of_the_tail_graph(monkeypatch):
+    """The round-5 form of a speculated call (LANPAINT_AMD_NODE_ONE_LAUNCH=0) stays available and equal."""
+    monkeypatch.setenv("LANPAINT_AMD_NODE_ONE_LAUNCH", "0")
+    test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(False, False, monkeypatch)
 
 
 # ---- argument forms the reference accepts through plain torch broadcasting -------------------------------
