@@ -145,12 +145,20 @@ def run_schedule(name):
     y, noise, mask = _t(sc["y"]), _t(sc["noise"]), _t(sc["mask"])
     sig = sc["sigmas"]
     b = sc["shape"][0]
-    denoised_all = []
+    denoised_all, iters, traces = [], [], []
     with XiRecorder() as rec:
         for i in range(len(sig) - 1):
             s = torch.full((b,), float(sig[i]), dtype=torch.float32)
             ve, abt, ft = gc.times_from_sigma(s, sc["flow"])
-            den = eng(x, y, noise, s, mask, (ve, abt, ft), None, 0)
+            mo = None
+            if sc.get("model_options") is not None:      # a fresh options dict per call, with a trace list (earlystop.py:121)
+                mo = {k: dict(v) if isinstance(v, dict) else v for k, v in sc["model_options"].items()}
+                mo["lanpaint_semantic_trace"] = []
+            calls = model.calls
+            den = eng(x, y, noise, s, mask, (ve, abt, ft), mo, 0)
+            iters.append(model.calls - calls - 1)
+            if mo is not None:
+                traces.append(mo["lanpaint_semantic_trace"])
             denoised_all.append(den.numpy().copy())
             d = (x - den) / float(sig[i])
             x = x + d * float(sig[i + 1] - sig[i])
@@ -158,6 +166,15 @@ def run_schedule(name):
                  x_final=x.numpy(), denoised=np.stack(denoised_all), n_draws=np.int64(len(rec.draws)))
     for i, d in enumerate(rec.draws):
         rec_d[f"xi_{i}"] = d
+    if traces:      # iterations the reference ran per sigma call and its stopper's records, call after call
+        nan = lambda v: np.nan if v is None else float(v)      # noqa: E731
+        flat = [t for tr in traces for t in tr]
+        rec_d["iterations"] = np.asarray(iters, dtype=np.int64)
+        rec_d["trace_call"] = np.asarray([k for k, tr in enumerate(traces) for _ in tr], dtype=np.int64)
+        for key in ("dist", "dist_inpaint", "dist_ring", "dist_drift", "threshold_eff", "abt"):
+            rec_d["trace_" + key] = np.asarray([nan(t[key]) for t in flat], dtype=np.float64)
+        rec_d["trace_counter"] = np.asarray([t["patience_counter"] for t in flat], dtype=np.int64)
+        rec_d["trace_stopped"] = np.asarray([t["stopped"] for t in flat], dtype=np.bool_)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec_d)
     return len(rec.draws)
 
@@ -348,6 +365,9 @@ def main():
     for name in gc.FULL_SCHEDULES:
         if name in only:
             print(f"{name:24s} draws, model calls = {run_full_schedule(name)}")
+    for name in gc.SCHEDULES:
+        if name in only:
+            print(f"{name:24s} draws={run_schedule(name)}")
     for name in gc.CASES:
         if only and name not in only:
             continue

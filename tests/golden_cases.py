@@ -160,6 +160,11 @@ SCHEDULES = {
     "sched_flow5":      dict(shape=(1, 16, 4, 4), flow=True, n_sigmas=5, hyper=dict(NSteps=2), seed=41),
     "sched_ve_batch2":  dict(shape=(2, 4, 8, 8), flow=False, n_sigmas=4, sigma_max=10.0, sigma_min=0.1,
                              hyper=dict(NSteps=2, MinStepFrac=1.0), seed=42),
+    # the inner early stop (earlystop.py) over a schedule: a fresh stopper per sigma call, the abt-scaled threshold moving with
+    # sigma -- the noisy head of the schedule runs all iterations, the middle stops early, the tail's threshold scales to ~0
+    "sched_ve_earlystop8": dict(shape=(1, 4, 12, 12), flow=False, n_sigmas=8, sigma_max=8.0, sigma_min=0.05, mask="blob",
+                                hyper=dict(NSteps=8), seed=43,
+                                model_options={"lanpaint_semantic_stop": {"threshold": 6.0, "patience": 1}}),
 }
 
 
@@ -169,6 +174,8 @@ NODE_SCHEDULES = {
     "node_ve_karras12": dict(shape=(2, 4, 16, 16), flow=False, n_sigmas=12, sigma_max=14.6146, sigma_min=0.0292, seed=50,
                              xi_seed=4250),
     "node_flow12":      dict(shape=(1, 16, 8, 8), flow=True, n_sigmas=12, seed=51, xi_seed=4251),
+    # a 5-D video latent (BASELINE configs[4] in small) through the reference's sampler callable
+    "node_flow_video5d": dict(shape=(1, 16, 3, 8, 10), flow=True, n_sigmas=12, seed=52, xi_seed=4252),
 }
 NODE_DEFAULTS = dict(NSteps=5, Friction=15.0, Lambda=5.0, Beta=1.0, StepSize=0.2, MinStepFrac=1.0, EarlyStop=1)
 
@@ -274,5 +281,10 @@ def build_schedule(name):
         x = (y + noise * sig[0]).astype(np.float32)
     hyper = dict(HYPER_DEFAULT)
     hyper.update(c.get("hyper", {}))
-    return dict(name=name, shape=shape, flow=flow, sigmas=sig, x=x, y=y, noise=noise, mask=box_mask(shape),
-                hyper=hyper, model="linear_tuple")
+    mask = box_mask(shape)
+    if c.get("mask") == "blob":
+        mask = np.ones(shape, dtype=np.float32)
+        h, w = shape[-2], shape[-1]
+        mask[..., h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 0.0
+    return dict(name=name, shape=shape, flow=flow, sigmas=sig, x=x, y=y, noise=noise, mask=mask,
+                hyper=hyper, model="linear_tuple", model_options=c.get("model_options"))

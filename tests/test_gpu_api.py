@@ -423,8 +423,10 @@ def test_ksampler_x0_inpaint_matches_the_reference_sampler_callable(name):
     assert_close(x.cpu().numpy(), g["x_final"], f"{name}: final x", rel=5e-5)
 
 
-@pytest.mark.parametrize("flow,inference", [(False, False), (True, False), (False, True)])
-def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference, monkeypatch):
+@pytest.mark.parametrize("flow,inference,shape", [(False, False, (2, 4, 16, 16)), (True, False, (2, 4, 16, 16)), (False, True, (2, 4, 16, 16)),
+                                                  (True, False, (2, 16, 3, 8, 10))],       # 5-D video latent (BASELINE configs[4] in small; two rows: a per-row sigma takes the fused flow-form replace step, lanpaint.py:89-92)
+                         ids=["ve", "flow", "ve_inference_mode", "flow_video5d"])
+def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference, shape, monkeypatch):
     """(`inference`: the whole run inside torch.inference_mode(), as ComfyUI executes its nodes -- inference tensors
     do not track `_version`, which the per-tensor caches of the engine and the sampler callable used to read.)
     The replayed node path (replace step enqueued before the host knows n_eff, mailbox read, graph picked
@@ -434,12 +436,18 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
     import torch
     from lanpaint_amd import LanPaint
     from lanpaint_amd import nodes
-    shape, n_think = (2, 4, 16, 16), 5
+    n_think = 5
     sig = gc.flow_sigmas(12) if flow else gc.karras_sigmas(12, 0.05, 12.0)
     rng = np.random.default_rng(21)
     y = rng.standard_normal(shape, dtype=np.float32)
     noise = rng.standard_normal(shape, dtype=np.float32)
     denoise_mask = (rng.random(shape) > 0.4).astype(np.float32)
+    if len(shape) == 5:          # the job's mask as a video workflow builds it: pixel-resolution frames through reshape_mask's video path
+        pix = np.zeros((4 * (shape[2] - 1) + 1, shape[3] * 8, shape[4] * 8), np.float32)
+        pix[pix.shape[0] // 2:, :, : pix.shape[2] // 2] = 1.0
+        dm5 = nodes.reshape_mask(torch.from_numpy(pix).to(DEV), shape, video_inpainting=True)
+        assert tuple(dm5.shape) == shape and 0 < float(dm5.mean()) < 1
+        denoise_mask = dm5.cpu().numpy()
     x0 = (sig[0] * noise + (1 - sig[0]) * y) if flow else (y + noise * sig[0])
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)   # noqa: E731
 
@@ -518,7 +526,7 @@ def test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(flow, inference
 def test_node_path_with_the_eager_replace_launch_in_front_of_the_tail_graph(monkeypatch):
     """The round-5 form of a speculated call (LANPAINT_AMD_NODE_ONE_LAUNCH=0) stays available and equal."""
     monkeypatch.setenv("LANPAINT_AMD_NODE_ONE_LAUNCH", "0")
-    test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(False, False, monkeypatch)
+    test_ksampler_x0_inpaint_split_phase_graph_path_equals_eager(False, False, (2, 4, 16, 16), monkeypatch)
 
 
 # ---- argument forms the reference accepts through plain torch broadcasting -------------------------------

@@ -49,8 +49,14 @@ def test_hip_matches_cpu_oracle(name):
 
 @pytest.mark.parametrize("name", sorted(gc.SCHEDULES))
 def test_hip_matches_reference_schedule(name):
+    """Whole schedules the unmodified reference walked (fixtures), its recorded xi stream fed to the kernels (a callable rng:
+    eager launches).  `sched_ve_earlystop8` runs with the inner early stop armed: the iterations run per sigma call (8, 8, 4, 2,
+    ...: the abt-scaled threshold moves with sigma) and every record of the stopper's trace must be the reference's -- here
+    through the device-side rule with the host reading one verdict per iteration; the device-gated launches of a replayed graph
+    are compared with the port under one torch seed in tests/test_gpu_port_on_device.py."""
     import torch
     from lanpaint_amd import LanPaint
+    from tests.test_oracle_golden import _options_for_call, check_schedule_traces
     sc = gc.build_schedule(name)
     g = load_golden(name)
     dev = "cuda"
@@ -62,14 +68,20 @@ def test_hip_matches_reference_schedule(name):
                    MinStepFrac=h["MinStepFrac"], rng=lambda like: next(it))
     x, y, noise, mask = tt(sc["x"].copy()), tt(sc["y"]), tt(sc["noise"]), tt(sc["mask"])
     sig = sc["sigmas"]
+    iterations, traces = [], []
     for i in range(len(sig) - 1):
         s = torch.full((sc["shape"][0],), float(sig[i]), dtype=torch.float32, device=dev)
         times = gc.times_from_sigma(s, sc["flow"])
-        den = eng(x, y, noise, s, mask, times, None, 0)
+        mo, before = _options_for_call(sc), eng.iterations_run
+        den = eng(x, y, noise, s, mask, times, mo, 0)
+        iterations.append(eng.iterations_run - before)
+        traces.append(mo["lanpaint_semantic_trace"] if mo is not None else [])
         assert_close(den.cpu().numpy(), g["denoised"][i], f"{name}: denoised[{i}]", rel=5e-5)
         x = x + (x - den) / float(sig[i]) * float(sig[i + 1] - sig[i])
     assert sum(1 for _ in it) == 0
     assert_close(x.cpu().numpy(), g["x_final"], f"{name}: final x", rel=5e-5)
+    if "iterations" in g.files:
+        check_schedule_traces(g, iterations, traces, name, rtol=2e-4)
 
 
 def test_noise_scaling_callback_path_equals_fused():

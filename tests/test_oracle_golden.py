@@ -26,6 +26,29 @@ def test_oracle_matches_reference_golden(name):
         assert [t["stopped"] for t in tr] == list(g["trace_stopped"])
 
 
+def _options_for_call(sc):
+    """A fresh copy of the schedule's model_options with a trace list, per sigma call -- what the fixture's generator handed the
+    reference (tests/golden/make_golden.py::run_schedule); None for schedules without the inner early stop."""
+    if sc.get("model_options") is None:
+        return None
+    mo = {k: dict(v) if isinstance(v, dict) else v for k, v in sc["model_options"].items()}
+    mo["lanpaint_semantic_trace"] = []
+    return mo
+
+
+def check_schedule_traces(g, iterations, traces, name, rtol=2e-5):
+    """Iterations run per sigma call and the stopper's records, call after call, against the reference's (fixture)."""
+    assert iterations == list(g["iterations"]), f"{name}: iterations per sigma call"
+    flat = [t for tr in traces for t in tr]
+    assert [k for k, tr in enumerate(traces) for _ in tr] == list(g["trace_call"])
+    assert [t["patience_counter"] for t in flat] == list(g["trace_counter"]) and [t["stopped"] for t in flat] == list(g["trace_stopped"])
+    for key in ("dist", "dist_inpaint", "dist_ring", "dist_drift", "threshold_eff", "abt"):
+        want = g["trace_" + key]
+        got = np.asarray([np.nan if t[key] is None else t[key] for t in flat], dtype=np.float64)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: {key}"
+        np.testing.assert_allclose(got[~np.isnan(got)], want[~np.isnan(want)], rtol=rtol, err_msg=f"{name}: {key}")
+
+
 @pytest.mark.parametrize("name", sorted(gc.SCHEDULES))
 def test_oracle_matches_reference_schedule(name):
     sc = gc.build_schedule(name)
@@ -37,13 +60,20 @@ def test_oracle_matches_reference_schedule(name):
                          min_step_frac=h["MinStepFrac"], randn=lambda like: next(it))
     x = sc["x"].copy()
     sig = sc["sigmas"]
+    iterations, traces = [], []
     for i in range(len(sig) - 1):
         s = np.full((sc["shape"][0],), sig[i], dtype=np.float32)
-        den = eng(x, sc["y"], sc["noise"], s, sc["mask"], gc.times_from_sigma(s, sc["flow"]), None, 0)
+        mo, calls = _options_for_call(sc), model.calls
+        den = eng(x, sc["y"], sc["noise"], s, sc["mask"], gc.times_from_sigma(s, sc["flow"]), mo, 0)
+        iterations.append(model.calls - calls - 1)
+        traces.append(mo["lanpaint_semantic_trace"] if mo is not None else [])
         assert_close(den, g["denoised"][i], f"{name}: denoised[{i}]", rel=2e-5)
         x = (x + (x - den) / sig[i] * (sig[i + 1] - sig[i])).astype(np.float32)
     assert sum(1 for _ in it) == 0
     assert_close(x, g["x_final"], f"{name}: final x", rel=2e-5)
+    if "iterations" in g.files:          # the inner early stop over a schedule: a fresh stopper per call, the threshold moving with abt
+        check_schedule_traces(g, iterations, traces, name)
+        assert len(set(iterations)) >= 3 and min(iterations) < h["NSteps"] == max(iterations)
 
 
 @pytest.mark.parametrize("name", sorted(gc.NODE_SCHEDULES))
