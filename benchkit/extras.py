@@ -106,6 +106,13 @@ def summary_scalars(args, dev, value, _cabi):
             out["value_over_launch_floor"] = (value / fl["floor_it_s"]) if value else None
     except Exception as e:
         detail["launch_floor"] = {"error": repr(e)}
+    try:      # what one steady launch costs as a node of a replayed graph (kernel + the dependent-dispatch gap), the form the timed
+        # region launches it in: beside roofline.duration_used_us, which is the begin -> end of an eager dispatch
+        from .roofline import graph_burst_us_per_launch
+        out["steady_graph_node_us"] = graph_burst_us_per_launch(_cabi, args.workload, dev, reps=200, replays=10, mask_kind=args.mask,
+                                                                rng="torch" if (args.rng or "torch").startswith("torch") else "philox")
+    except Exception as e:
+        detail["steady_graph_node_us"] = {"error": repr(e)}
     if not args.no_large_shape:
         for key, wl, rng in (("hbm_frac_c5_wan", "c5_wan", "philox"), ("hbm_frac_c5_wan_torch_stream", "c5_wan", "torch"),
                              ("hbm_frac_past_l3", "x_wan_b16", "philox")):
