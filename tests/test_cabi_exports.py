@@ -39,6 +39,23 @@ def test_the_c_abi_is_the_only_dynamic_surface(hip_lib):
         assert re.search(r"LP_API\s+[a-z_0-9 \*]+\b%s\s*\(" % n, hdr), n
 
 
+def test_graph_utilities_reject_bad_arguments_without_touching_the_device(hip_lib):
+    """lp_replay_burst / lp_graph_clone_sigma_root / lp_graph_bind_replace validate before any HIP call: usable error codes on a
+    box without a GPU."""
+    import ctypes as C
+    d = _cabi.LpStepDesc()
+    one = (C.c_void_p * 1)(None)
+    assert hip_lib.lp_replay_burst(None, 1, None, None, 1, None) == _cabi.LP_E_INVALID
+    assert hip_lib.lp_replay_burst(one, 0, None, None, 1, None) == _cabi.LP_E_INVALID
+    assert hip_lib.lp_replay_burst(one, 1, None, None, 0, None) == _cabi.LP_E_INVALID
+    g, e, b = C.c_void_p(), C.c_void_p(), _cabi.LpGraphBinding()
+    assert hip_lib.lp_graph_clone_sigma_root(None, C.byref(d), C.byref(g), C.byref(e), C.byref(b)) == _cabi.LP_E_INVALID
+    d.phases = _cabi.LP_PH_REPLACE | _cabi.LP_PH_EMIT | _cabi.LP_PH_COEFFS          # without LP_PH_SIGMA: not the launch this entry is for
+    assert hip_lib.lp_graph_clone_sigma_root(C.c_void_p(1), C.byref(d), C.byref(g), C.byref(e), C.byref(b)) == _cabi.LP_E_INVALID
+    assert hip_lib.lp_graph_bind_replace(None, C.byref(d), C.byref(b)) == _cabi.LP_E_INVALID
+    assert g.value is None and e.value is None
+
+
 def test_abi_version_and_strerror(hip_lib):
     assert hip_lib.lp_abi_version() == _cabi.ABI_VERSION
     assert hip_lib.lp_strerror(0) == b"ok"
