@@ -17,6 +17,8 @@ import contextlib
 import ctypes
 
 import numpy as np
+import os
+
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
@@ -248,8 +250,9 @@ def _run_sequence(mode, rng, shape_i, flow, packed, events, seed):
 
 
 _events = st.lists(st.tuples(st.sampled_from(EVENTS), st.integers(0, 1000)), min_size=6, max_size=18)
-_common = dict(max_examples=100, deadline=None, derandomize=True, database=None,
-               suppress_health_check=list(HealthCheck))
+# LP_FUZZ_EXAMPLES / LP_FUZZ_RANDOM=1: a soak (more sequences, fresh randomness) instead of the suite's fixed 4 x 100 walks
+_common = dict(max_examples=int(os.environ.get("LP_FUZZ_EXAMPLES", "100")), deadline=None,
+               derandomize=os.environ.get("LP_FUZZ_RANDOM", "0") != "1", database=None, suppress_health_check=list(HealthCheck))
 
 
 @pytest.fixture(autouse=True)
